@@ -1,0 +1,195 @@
+/*
+ * yolort_amd.h -- C ABI of libyolort_amd.so, the MI355X (gfx950) YOLOv5 inference hot path.
+ *
+ * This is the drop-in boundary.  The reference (zhiqwang/yolort) has no C
+ * plugin ABI of its own: its plug points are Python constructor injection and ATen/torchvision
+ * operators.  Each entry point below therefore replaces one ATen/torchvision call site of the
+ * reference's hot path and cites it (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + explicit sizes, no torch types; `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream).  The caller owns every buffer.
+ *   - every function returns 0 on success or a negative YMI_E* code and never throws; the message
+ *     of the last failure on the calling thread is available from ymi_last_error().
+ *   - no hidden hipDeviceSynchronize / hipMalloc; thread-safe for distinct streams.
+ *   - activations are NHWC ("pixel-major"): element (n,y,x,c) of a view lives at
+ *       base + ((n*H + y)*W + x) * cstride + c        (cstride >= C lets a view be a channel slice
+ *     of a wider concat buffer -- this is how torch.cat is eliminated).
+ */
+#ifndef YOLORT_AMD_H
+#define YOLORT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMI_ABI_VERSION 1
+
+/* error codes */
+#define YMI_OK 0
+#define YMI_EINVAL -1   /* bad argument / unsupported shape */
+#define YMI_EHIP -2     /* HIP runtime error (message has hipGetErrorString) */
+#define YMI_ENOMEM -3   /* caller-provided capacity too small (retry with the reported size) */
+
+/* element types */
+#define YMI_F16 0
+#define YMI_BF16 1
+#define YMI_F32 2
+#define YMI_U8 3
+
+/* activation after conv */
+#define YMI_ACT_NONE 0
+#define YMI_ACT_SILU 1
+
+int ymi_abi_version(void);
+const char* ymi_last_error(void);
+/* number of HIP devices visible, or a negative error; used by the loud "no GPU" check */
+int ymi_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Letterbox: per-image aspect-preserving bilinear resize + centred constant pad + dtype cast +
+ * CHW -> NHWC(c_out) layout change, one launch for the whole batch.
+ * Replaces yolort/models/transform.py:53-97 (_resize_image_and_masks -> F.interpolate bilinear,
+ * align_corners=False, recompute_scale_factor=True) and :297-330 (batch_images: new_full + copy_).
+ * The host computes resized sizes / pad offsets with the reference's float recipe
+ * (yolort_amd.models.transform) and passes them in `geom`.
+ *   imgs[i]     device pointer to image i, planar CHW (3,h,w), contiguous, dtype in_dtype
+ *               (YMI_F32 / YMI_F16 / YMI_BF16 in [0,1], or YMI_U8 in [0,255] which is scaled by 1/255)
+ *   geom[i*6..] {h_in, w_in, h_resized, w_resized, pad_top, pad_left}
+ *   out         (n, hb, wb, c_out) NHWC, dtype out_dtype, channels 3..c_out-1 zero-filled
+ *   fill        pad value (reference: 114/255, transform.py:141)
+ * ---------------------------------------------------------------------------------------- */
+int ymi_letterbox(const void* const* imgs, const int32_t* geom, int n, int in_dtype, void* out, int hb,
+                  int wb, int c_out, int out_dtype, float fill, void* stream);
+
+/* NCHW (n,c,h,w) -> NHWC view and back (module-level API edges; not on the fused path). */
+int ymi_nchw_to_nhwc(const void* x, int n, int c, int h, int w, int in_dtype, void* y, int y_cstride,
+                     int c_pad, int out_dtype, void* stream);
+int ymi_nhwc_to_nchw(const void* x, int x_cstride, int n, int c, int h, int w, int in_dtype, void* y,
+                     int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused convolution: y = act(conv2d(x, W) + bias) (+ residual), implicit GEMM on MFMA.
+ * Replaces yolort/v5/models/common.py:69-70 `Conv.forward` = SiLU(BN(conv2d(x))) with BatchNorm
+ * folded into W/bias on the host (formula of yolort/v5/utils/torch_utils.py:238-245, eps 1e-3),
+ * the residual add of common.py:115-116 (Bottleneck) and, with act=NONE and a real bias, the
+ * biased 1x1 head conv of yolort/models/box_head.py:36,74.
+ *   x        NHWC view (n,h,w,cin) with pixel stride x_cstride; cin % 8 == 0
+ *   w        packed weights [cout_pad][k_pad], k index = (ky*kw + kx)*cin + c, dtype = `dtype`,
+ *            zero padded; cout_pad % 32 == 0, k_pad % 32 == 0  (see ymi_conv_pack_dims)
+ *   bias     fp32 [cout_pad]
+ *   ktab     int32 [k_pad/8][2] im2col table: {element offset (dy*w + dx)*x_cstride + c, dy<<16|dx}
+ *            for every 8-channel chunk (built by ymi_conv_build_ktab); entries past K are {0,-1}
+ *   y        NHWC view (n,ho,wo,cout) with pixel stride y_cstride, dtype out_dtype (dtype or F32)
+ *   res      optional residual view, same shape as y, dtype `dtype` (NULL = none); added AFTER act
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ymi_conv_desc {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const int32_t* ktab;
+    void* y;
+    const void* res;
+    int32_t n, h, w_in, cin, x_cstride;
+    int32_t ho, wo, cout, cout_pad, y_cstride, res_cstride;
+    int32_t kh, kw, sh, sw, ph, pw, k_pad;
+    int32_t act, dtype, out_dtype;
+    int32_t tile; /* 0 = auto, else forces a tile configuration (tuning / tests) */
+} ymi_conv_desc;
+
+int ymi_conv2d(const ymi_conv_desc* d, void* stream);
+/* fills host array ktab[k_pad/8][2] for the geometry in d (x_cstride, w_in, cin, kh, kw) */
+int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_pad, int32_t* ktab_host);
+
+/* ------------------------------------------------------------------------------------------
+ * SPP max-pool pyramid: given x = channels [0,c) of a (n,h,w,4c) concat buffer, writes
+ * maxpool5(x), maxpool9(x), maxpool13(x) (stride 1, "same", -inf padding) into channel slices
+ * [c,2c) [2c,3c) [3c,4c).  Replaces common.py:183-187 (SPP.forward: cat([x]+[m(x) for m in self.m])).
+ * ---------------------------------------------------------------------------------------- */
+int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, int dtype, void* stream);
+
+/* nearest x2 upsample of view x (n,h,w,c) into view y (n,2h,2w,c) -- nn.Upsample(scale_factor=2),
+ * yolort/models/path_aggregation_network.py:123,131,134 -- written straight into its concat slot. */
+int ymi_upsample2x(const void* x, int x_cstride, int n, int h, int w, int c, void* y, int y_cstride,
+                   int dtype, void* stream);
+/* strided channel-slice copy (only used where a producer cannot write into its concat slot) */
+int ymi_copy_view(const void* x, int x_cstride, int npix, int c, void* y, int y_cstride, int dtype,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Post-process (yolort/models/box_head.py:328-360,414-427 + torchvision batched_nms).
+ * ymi_postprocess runs, on `stream`, with no host sync:
+ *   1. decode   sigmoid, xy=(s*2-0.5+grid)*stride, wh=(s*2)^2*anchor (yolort/models/_utils.py:59-60,
+ *               grids/shifts of anchor_utils.py in closed form), score = cls*obj (box_head.py:357),
+ *               strict threshold score > score_thresh over ALL (anchor,class) pairs (box_head.py:418)
+ *   2. sort     candidates per image by score descending, ties by candidate index (anchor asc,
+ *               class asc) -- the stable order of torchvision.ops.nms
+ *   3. nms      class-aware greedy suppression, IoU > nms_thresh strict, fp32 (box_head.py:422)
+ *   4. top-k    first detections_per_img kept (box_head.py:424) and box rescale to the original
+ *               image (yolort/models/transform.py:354-367 scale_coords, no clipping)
+ * Inputs: logits[l] = fp32 NHWC (n, H_l, W_l, lcstride) with channel a*K + k (K = num_classes+5).
+ * Outputs (fixed slab, the reference TensorRT wire format of relay/trt_graphsurgeon.py:223-244):
+ *   out_boxes (n, K, 4) fp32, out_scores (n, K) fp32, out_labels (n, K) int64, out_count (n) int32.
+ * Workspace: `ws` of `ws_bytes` bytes (query with ymi_postprocess_ws_bytes); candidate capacity
+ * `cand_cap` is the batch-wide maximum number of (anchor,class) candidates; on overflow nothing is
+ * truncated silently: the needed count is left in status[0] and status[1] is set to 1.
+ * ---------------------------------------------------------------------------------------- */
+#define YMI_MAX_LEVELS 4
+typedef struct ymi_post_desc {
+    const float* logits[YMI_MAX_LEVELS];
+    int32_t lh[YMI_MAX_LEVELS], lw[YMI_MAX_LEVELS], lcstride[YMI_MAX_LEVELS];
+    float stride[YMI_MAX_LEVELS];
+    float anchors[YMI_MAX_LEVELS][6]; /* 3 anchors x (w,h) in pixels */
+    int32_t num_levels, n, num_classes;
+    float score_thresh, nms_thresh;
+    int32_t detections_per_img;
+    /* per-image rescale (transform.py:358-367): box = (box - pad) / gain; gain<=0 disables */
+    const float* rescale; /* device (n,3) {gain, pad_x, pad_y} or NULL */
+    float* out_boxes;
+    float* out_scores;
+    int64_t* out_labels;
+    int32_t* out_count;
+    int32_t* status; /* device int32[4]: {candidates_needed, overflow, total_kept, reserved} */
+    void* ws;
+    int64_t ws_bytes;
+    int32_t cand_cap;
+} ymi_post_desc;
+
+int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_cap);
+int ymi_postprocess(const ymi_post_desc* d, void* stream);
+
+/* Stand-alone class-aware NMS on caller-provided candidates of ONE image (kept indices in
+ * score-descending stable order, like torchvision.ops.batched_nms called at box_head.py:422).
+ * boxes (n,4) fp32 xyxy, scores (n) fp32, labels (n) int32; keep_out (n) int32, count_out int32[1]. */
+int64_t ymi_nms_ws_bytes(int n);
+int ymi_batched_nms(const float* boxes, const float* scores, const int32_t* labels, int n, float nms_thresh,
+                    int32_t* keep_out, int32_t* count_out, void* ws, int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan: a recorded sequence of the launches above for one (arch, N, H, W, dtype), replayed with a
+ * single call (and optionally captured into a hipGraph).  Replaces the Python module-by-module
+ * dispatch of yolort/models/yolo.py:159-175.  The plan copies descriptors; buffers stay owned by
+ * the caller and must outlive the plan.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ymi_plan ymi_plan;
+ymi_plan* ymi_plan_create(void);
+void ymi_plan_destroy(ymi_plan* p);
+int ymi_plan_add_conv(ymi_plan* p, const ymi_conv_desc* d);
+int ymi_plan_add_spp_pool(ymi_plan* p, void* buf, int n, int h, int w, int c, int cstride, int dtype);
+int ymi_plan_add_upsample2x(ymi_plan* p, const void* x, int x_cstride, int n, int h, int w, int c, void* y,
+                            int y_cstride, int dtype);
+int ymi_plan_add_copy_view(ymi_plan* p, const void* x, int x_cstride, int npix, int c, void* y,
+                           int y_cstride, int dtype);
+int ymi_plan_add_postprocess(ymi_plan* p, const ymi_post_desc* d);
+int ymi_plan_num_ops(const ymi_plan* p);
+/* runs ops [first, last) on stream (last < 0 = all); use_graph != 0 replays a captured hipGraph */
+int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream);
+/* per-op timing with HIP events on `stream`: ms_out[num_ops], averaged over iters */
+int ymi_plan_profile(ymi_plan* p, int iters, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLORT_AMD_H */

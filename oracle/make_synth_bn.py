@@ -1,0 +1,47 @@
+"""TEST INFRASTRUCTURE -- produces yolort_amd/data/synth_bn_<arch>_s<seed>.npz.
+
+Runs the oracle's conv stack once in calibration mode (every Conv-BN takes the batch statistics of
+its own conv output on a seeded calibration batch) and stores only the
+BatchNorm running statistics (a few hundred KB).  Key/shape templates come from the reference
+itself when /root/reference is importable (this container), else from yolort_amd.
+
+usage: python oracle/make_synth_bn.py [arch ...]   (default: n s m l6 r60 variants)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import yolov5_oracle as O  # noqa: E402
+from yolort_amd.utils.synth import synth_bn_path, synth_images, synth_state_dict  # noqa: E402
+
+
+def reference_template(arch: str):
+    from oracle.reference_loader import load_reference
+    yolo = load_reference().models.yolo
+    return yolo.__dict__[arch]().state_dict()
+
+
+def calibrate(arch: str, seed: int = 0, calib_hw: int = 320, calib_n: int = 2):
+    sd = synth_state_dict(reference_template(arch), seed=seed)
+    x = synth_images(calib_n, calib_hw, calib_hw, seed=1000 + seed)
+    O.CALIB.active = True
+    try:
+        with torch.no_grad():
+            feats = O.backbone(x, sd, "backbone")
+    finally:
+        O.CALIB.active = False
+    stats = {k: v.numpy().astype(np.float32) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    os.makedirs(os.path.dirname(synth_bn_path(arch, seed)), exist_ok=True)
+    np.savez(synth_bn_path(arch, seed), **stats)
+    print(arch, "features std", [round(float(f.std()), 3) for f in feats], "absmax", [round(float(f.abs().max()), 1) for f in feats],
+          "->", synth_bn_path(arch, seed), os.path.getsize(synth_bn_path(arch, seed)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    archs = sys.argv[1:] or ["yolov5_darknet_pan_n_r60", "yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60", "yolov5_darknet_pan_l6_r60"]
+    for a in archs:
+        calibrate(a)

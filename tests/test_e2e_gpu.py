@@ -1,0 +1,170 @@
+"""End-to-end parity of the HIP path against the oracle / reference goldens (MI355X)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _iou(a, b):
+    x1, y1 = np.maximum(a[0], b[:, 0]), np.maximum(a[1], b[:, 1])
+    x2, y2 = np.minimum(a[2], b[:, 2]), np.minimum(a[3], b[:, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter)
+
+
+def match_fraction(ref, got, iou_thr=0.9, score_tol=0.03):
+    """fraction of reference detections that have a same-label detection with IoU >= iou_thr"""
+    rb, rs, rl = ref["boxes"], ref["scores"], ref["labels"]
+    gb, gs, gl = got["boxes"], got["scores"], got["labels"]
+    if len(rs) == 0:
+        return 1.0, 0.0
+    hit, ds = 0, []
+    for i in range(len(rs)):
+        cand = np.where(gl == rl[i])[0]
+        if len(cand) == 0:
+            continue
+        ious = _iou(rb[i], gb[cand])
+        j = int(np.argmax(ious))
+        if ious[j] >= iou_thr and abs(gs[cand[j]] - rs[i]) <= score_tol:
+            hit += 1
+            ds.append(abs(gs[cand[j]] - rs[i]))
+    return hit / len(rs), float(max(ds)) if ds else 0.0
+
+
+def _np(d):
+    return {k: (v.detach().float().cpu().numpy() if k != "labels" else v.detach().cpu().numpy()) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from yolort_amd import _lib
+    _lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _model(arch, dev, dtype, **kw):
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_weights
+    head_gain = kw.pop("head_gain", 2.0)
+    m = YOLOv5(arch=arch, **kw)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=head_gain))
+    return m.to(dev).to(dtype).eval()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_yolov5n_against_reference_golden(dev, golden_dir, dtype):
+    """Same seeded weights/images as tests/golden/e2e_n.npz, which holds the UNMODIFIED reference's
+    fp32 CPU outputs.  Conv stack in fp16/bf16 with fp32 accumulation, decode/NMS in fp32."""
+    from yolort_amd.utils.synth import synth_images
+    z = np.load(os.path.join(golden_dir, "e2e_n.npz"))
+    S = int(z["S"])
+    m = _model("yolov5_darknet_pan_n_r60", dev, dtype, size=(S, S), score_thresh=float(z["thr"]), nms_thresh=0.45, head_gain=float(z["head_gain"]))
+    imgs = [synth_images(1, int(h), int(w), seed=11 + i)[0].to(dev) for i, (h, w) in enumerate(z["sizes"])]
+    dets = m.predict(imgs)
+    e = next(iter(m.model._entries.values()))
+    rel = 2e-2 if dtype == torch.float16 else 8e-2
+    for i, v in enumerate(e.feats):
+        got = v.as_tensor().float().cpu().permute(0, 3, 1, 2).numpy()
+        ref = z[f"feat{i}"]
+        err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        assert err < rel, f"feature {i}: rel err {err}"
+    for i, v in enumerate(e.logits):
+        n, h, w = v.n, v.h, v.w
+        got = v.as_tensor().cpu().view(n, h, w, 3, 85).permute(0, 3, 1, 2, 4).numpy()
+        err = np.abs(got - z[f"head{i}"]).max()
+        assert err < (0.15 if dtype == torch.float16 else 0.6), f"head {i}: abs err {err}"
+    assert len(dets) == 3
+    for i, d in enumerate(dets):
+        assert list(d.keys()) == ["scores", "labels", "boxes"] and d["labels"].dtype == torch.int64 and d["boxes"].dtype == torch.float32
+        ref = {"boxes": z[f"det{i}_boxes"], "scores": z[f"det{i}_scores"], "labels": z[f"det{i}_labels"]}
+        frac, ds = match_fraction(ref, _np(d), iou_thr=0.9 if dtype == torch.float16 else 0.75, score_tol=0.03 if dtype == torch.float16 else 0.1)
+        assert frac >= (0.9 if dtype == torch.float16 else 0.6), f"image {i}: only {frac:.3f} of reference detections matched (max dscore {ds})"
+
+
+def test_postprocess_exact_given_oracle_logits(dev, golden_dir):
+    """Feeding the reference's own fp32 head outputs through the HIP post-process must reproduce
+    the reference detections: labels/order bit-exact, boxes within 1e-3 IoU-equivalent tolerance."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.ops import postprocess_logits
+    z = np.load(os.path.join(golden_dir, "e2e_n.npz"))
+    heads = [torch.from_numpy(z[f"head{i}"]).to(dev) for i in range(3)]
+    strides, anchors = O.anchors_for(3)
+    got = postprocess_logits(heads, strides, anchors, 80, float(z["thr"]), 0.45, 300)
+    hb, wb = int(z["batch_shape"][2]), int(z["batch_shape"][3])
+    for i, d in enumerate(got):
+        boxes = O.scale_coords(d["boxes"].cpu(), (hb, wb), tuple(int(v) for v in z["sizes"][i]))
+        np.testing.assert_array_equal(d["labels"].cpu().numpy(), z[f"det{i}_labels"])
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), z[f"det{i}_scores"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(boxes.numpy(), z[f"det{i}_boxes"], rtol=1e-5, atol=2e-3)
+
+
+def test_yolov5s_640_vs_oracle(dev):
+    """BASELINE config 2 shape (yolov5s fp16 640x640) at batch 2 against the CPU oracle."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    arch = "yolov5_darknet_pan_s_r60"
+    m = _model(arch, dev, torch.float16, score_thresh=0.25, head_gain=1.0)
+    x = synth_images(2, 640, 640, seed=1)
+    dets = m.predict([x[0].to(dev), x[1].to(dev)])
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward([x[0], x[1]], sd, score_thresh=0.25)
+    for r, d in zip(ref, dets):
+        frac, ds = match_fraction(_np(r), _np(d))
+        assert len(r["scores"]) > 10
+        assert frac >= 0.9, f"matched {frac:.3f} (max dscore {ds}) of {len(r['scores'])}"
+
+
+def test_mixed_sizes_and_yolo_forward(dev):
+    """dynamic-shape letterbox batch + YOLO.forward on a pre-batched tensor (no rescale)."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    arch = "yolov5_darknet_pan_n_r60"
+    m = _model(arch, dev, torch.float16, size=(320, 320), score_thresh=0.3)
+    shapes = [(270, 203), (240, 320), (180, 320), (375, 500)]
+    imgs = [synth_images(1, h, w, seed=5 + i)[0] for i, (h, w) in enumerate(shapes)]
+    dets = m.predict([im.to(dev) for im in imgs])
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs, sd, size=(320, 320), score_thresh=0.3)
+    for r, d in zip(ref, dets):
+        frac, _ = match_fraction(_np(r), _np(d))
+        assert frac >= 0.85
+    xb = synth_images(2, 128, 160, seed=9)
+    out = m.model(xb.to(dev).half())
+    with torch.no_grad():
+        ref2 = O.yolo_forward(xb, sd, 0.3, 0.45, 300, p="model.")
+    for r, d in zip(ref2, out):
+        frac, _ = match_fraction(_np(r), _np(d))
+        assert frac >= 0.85
+
+
+def test_p6_model_runs(dev):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    arch = "yolov5_darknet_pan_l6_r60"
+    m = _model(arch, dev, torch.float16, size=(256, 256), size_divisible=64, score_thresh=0.3)
+    imgs = [synth_images(1, 200, 256, seed=3)[0]]
+    dets = m.predict([imgs[0].to(dev)])
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs, sd, size=(256, 256), size_divisible=64, score_thresh=0.3)
+    frac, _ = match_fraction(_np(ref[0]), _np(dets[0]))
+    assert frac >= 0.85
+
+
+def test_api_errors(dev):
+    from yolort_amd._lib import YmiError
+    from yolort_amd.models import yolov5n
+    m = yolov5n().to(dev).half().eval()
+    with pytest.raises(ValueError):
+        m.predict(torch.rand(2, 3, 64, 64, device=dev))  # 4-D tensor to predict (reference Appendix G)
+    with pytest.raises(NotImplementedError):
+        m.predict({"a": 1})
+    with pytest.raises(YmiError):
+        m.forward([torch.rand(3, 64, 64)])  # CPU tensor: no fallback
+    out = m.predict(torch.rand(3, 64, 64, device=dev))
+    assert out[0]["boxes"].shape == (0, 4) and out[0]["scores"].shape == (0,) and out[0]["labels"].dtype == torch.int64

@@ -1,0 +1,256 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes), against the
+CPU oracle / plain torch fp32 references on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from yolort_amd import _lib
+    _lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _nhwc(x):  # (n,c,h,w) -> dense NHWC tensor
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _run_conv(dev, dtype, n, cin, cout, h, w, k, s, p, act=True, residual=False, tile=0, x_cs_extra=0, y_cs_extra=0, seed=0):
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g) * 0.1
+    xq, wq = x.to(dtype).float(), wt.to(dtype).float()
+    ref = F.conv2d(xq, wq, bias, s, p)
+    if act:
+        ref = F.silu(ref)
+    plan = engine.Plan(dev, dtype)
+    # input view with optional extra channel stride (slice of a wider buffer)
+    xin = plan.alloc(n, h, w, cin + x_cs_extra, zero=True)
+    xv = xin.slice_c(x_cs_extra // 2 if x_cs_extra else 0, cin) if x_cs_extra else xin
+    xv.as_tensor().copy_(_nhwc(xq).to(dev, dtype))
+    pc = engine.PackedConv(wq, bias, None, dtype, dev)
+    ho, wo = engine.conv_out_hw(h, w, (k, k), (s, s), (p, p))
+    yb = plan.alloc(n, ho, wo, cout + y_cs_extra, zero=True)
+    yv = yb.slice_c(y_cs_extra // 2 if y_cs_extra else 0, cout) if y_cs_extra else yb
+    rv = None
+    if residual:
+        r = torch.randn(n, cout, ho, wo, generator=g).to(dtype).float()
+        ref = ref + r
+        rb = plan.alloc(n, ho, wo, cout)
+        rb.as_tensor().copy_(_nhwc(r).to(dev, dtype))
+        rv = rb
+    plan.conv(xv, pc, s, p, act=1 if act else 0, out=yv, res=rv, tile=tile)
+    plan.run()
+    torch.cuda.synchronize()
+    got = yv.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    tol = 2e-2 if dtype == torch.float16 else 6e-2
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * max(1.0, scale), f"max err {err} (scale {scale})"
+    if y_cs_extra:  # neighbours in the wider buffer untouched
+        full = yb.as_tensor().float().cpu()
+        assert full[..., : y_cs_extra // 2].abs().max().item() == 0 and full[..., y_cs_extra // 2 + cout:].abs().max().item() == 0
+    return err
+
+
+def test_mfma_layout_identity(dev):
+    """A = I style check with an ASYMMETRIC weight: 1x1 conv whose weight is a permutation-like
+    matrix with distinct values catches row/col or k-order swaps in the MFMA fragment mapping."""
+    from yolort_amd import engine
+    n, c, h, w = 1, 64, 8, 8
+    x = torch.arange(n * c * h * w, dtype=torch.float32).reshape(n, c, h, w) % 97 / 97.0
+    wt = torch.zeros(64, 64, 1, 1)
+    for o in range(64):
+        wt[o, (o * 7 + 3) % 64, 0, 0] = 1.0 + o / 64.0
+    ref = F.conv2d(x.half().float(), wt.half().float())
+    plan = engine.Plan(dev, torch.float16)
+    xv = plan.alloc(n, h, w, c)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+    pc = engine.PackedConv(wt, None, None, torch.float16, dev)
+    y = plan.conv(xv, pc, 1, 0, act=0)
+    plan.run()
+    got = y.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, cin=64, cout=32, h=40, w=36, k=1, s=1, p=0),
+    dict(n=2, cin=32, cout=64, h=33, w=31, k=3, s=1, p=1),
+    dict(n=2, cin=32, cout=64, h=40, w=40, k=3, s=2, p=1),
+    dict(n=1, cin=128, cout=256, h=20, w=20, k=3, s=2, p=1),
+    dict(n=2, cin=16, cout=16, h=24, w=20, k=3, s=1, p=1),      # yolov5n widths
+    dict(n=1, cin=48, cout=96, h=16, w=16, k=3, s=2, p=1),      # yolov5m widths (cin % 32 != 0)
+    dict(n=3, cin=256, cout=255, h=10, w=10, k=1, s=1, p=0, act=False),  # head
+    dict(n=1, cin=512, cout=512, h=20, w=20, k=1, s=1, p=0),
+])
+def test_conv_parity(dev, dtype, cfg):
+    _run_conv(dev, dtype, **cfg)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_conv_tiles(dev, tile):
+    _run_conv(dev, torch.float16, n=2, cin=64, cout=128, h=37, w=29, k=3, s=1, p=1, tile=tile)
+    _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=37, w=29, k=1, s=1, p=0, tile=tile, residual=True)
+
+
+def test_conv_views_and_residual(dev):
+    _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=20, w=20, k=3, s=1, p=1, residual=True, x_cs_extra=64, y_cs_extra=128)
+    _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)
+
+
+def test_conv_head_fp32_out(dev):
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 128, 12, 12, generator=g).half().float()
+    wt = (torch.randn(255, 128, 1, 1, generator=g) / 11).half().float()
+    b = torch.randn(255, generator=g)
+    ref = F.conv2d(x, wt, b)
+    plan = engine.Plan(dev, torch.float16)
+    xv = plan.alloc(2, 12, 12, 128)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+    y = plan.conv(xv, engine.PackedConv(wt, b, None, torch.float16, dev), 1, 0, act=0, out_dtype=torch.float32)
+    assert y.dtype == torch.float32 and y.cs == 256 and y.c == 255
+    plan.run()
+    got = y.as_tensor().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 2e-3
+
+
+def test_stem_superpixel(dev):
+    """Conv(3, c, k=6, s=2, p=2) (darknetv6.py:81) through the NHWC4 super-pixel formulation."""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 96, generator=g).half().float()
+    wt = (torch.randn(32, 3, 6, 6, generator=g) / 10).half().float()
+    b = torch.randn(32, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x, wt, b, 2, 2))
+    plan = engine.Plan(dev, torch.float16)
+    xv = plan.alloc(2, 64, 96, 4, zero=True)
+    xv.as_tensor()[..., :3].copy_(_nhwc(x).to(dev, torch.float16))
+    pc = engine.PackedConv(wt, b, None, torch.float16, dev, stem_superpixel=True)
+    y = plan.conv(xv, pc, 2, 2)
+    plan.run()
+    got = y.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-2
+
+
+def test_bn_fold(dev):
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 32, 16, 16, generator=g).half().float()
+    wt = (torch.randn(64, 32, 3, 3, generator=g) / 17)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    mean, var = torch.randn(64, generator=g) * 0.3, torch.rand(64, generator=g) + 0.2
+    ref = F.silu(F.batch_norm(F.conv2d(x, wt, None, 1, 1), mean, var, gamma, beta, False, 0.0, 1e-3))
+    plan = engine.Plan(dev, torch.float16)
+    xv = plan.alloc(1, 16, 16, 32)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+    y = plan.conv(xv, engine.PackedConv(wt, None, (gamma, beta, mean, var, 1e-3), torch.float16, dev), 1, 1)
+    plan.run()
+    got = y.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 3e-2
+
+
+def test_spp_pool_and_upsample_exact(dev):
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 20, 17, generator=g).half()
+    plan = engine.Plan(dev, torch.float16)
+    buf = plan.alloc(2, 20, 17, 256, zero=True)
+    buf.slice_c(0, 64).as_tensor().copy_(_nhwc(x.float()).to(dev, torch.float16))
+    plan.spp_pool(buf, 64)
+    up = plan.alloc(2, 40, 34, 96, zero=True)
+    plan.upsample2x(buf.slice_c(0, 64), up.slice_c(32, 64))
+    plan.run()
+    got = buf.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    xf = x.float()
+    for i, k in enumerate((5, 9, 13)):
+        ref = F.max_pool2d(xf, k, 1, k // 2)
+        assert torch.equal(got[:, 64 * (i + 1): 64 * (i + 2)], ref), f"maxpool{k} not exact"
+    gu = up.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(gu[:, 32:96], F.interpolate(xf, scale_factor=2.0, mode="nearest"))
+    assert gu[:, :32].abs().max().item() == 0
+
+
+def test_letterbox_vs_oracle(dev):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models.transform import YOLOTransform
+    from yolort_amd.utils.synth import synth_images
+    shapes = [(1080, 810), (480, 640), (720, 1280), (375, 500), (100, 37), (641, 480)]
+    imgs = [synth_images(1, h, w, seed=h + w)[0] for h, w in shapes]
+    ref, sizes = O.letterbox(imgs, 640, 640, 32)
+    t = YOLOTransform(640, 640)
+    nt, _ = t([im.to(dev) for im in imgs], None, dtype=torch.float32)
+    assert nt.image_sizes == sizes
+    got = nt.nchw().float().cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 5e-5
+    # fp16 output path + uint8 input path
+    nt16, _ = t([im.to(dev) for im in imgs], None, dtype=torch.float16)
+    assert (nt16.nchw().float().cpu() - ref).abs().max().item() <= 1e-3
+    u8 = [(im * 255).round().to(torch.uint8) for im in imgs]
+    ref8, _ = O.letterbox([u.float() / 255.0 for u in u8], 640, 640, 32)
+    nt8, _ = t([u.to(dev) for u in u8], None, dtype=torch.float32)
+    assert (nt8.nchw().float().cpu() - ref8).abs().max().item() <= 5e-5
+
+
+def _rand_boxes(rng, n, span=200.0):
+    xy = rng.random((n, 2), dtype=np.float32) * span
+    wh = rng.random((n, 2), dtype=np.float32) * 60 + 2
+    return np.concatenate([xy, xy + wh], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,ncls,ties", [(0, 3, False), (1, 1, False), (77, 3, True), (1000, 80, False), (5000, 5, True), (20000, 80, True)])
+def test_batched_nms_bit_exact(dev, n, ncls, ties):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.ops import batched_nms
+    rng = np.random.default_rng(n + ncls)
+    boxes = _rand_boxes(rng, n)
+    scores = rng.random(n, dtype=np.float32)
+    if ties:
+        scores = np.round(scores, 2).astype(np.float32)
+    labels = rng.integers(0, ncls, n).astype(np.int64)
+    ref = O.batched_nms(torch.from_numpy(boxes), torch.from_numpy(scores), torch.from_numpy(labels), 0.45).numpy()
+    got = batched_nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(labels).to(dev), 0.45).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_postprocess_vs_oracle(dev):
+    """decode + threshold + sort + NMS + top-k from the same fp32 head logits: integer outputs
+    (labels, counts, order) bit-exact; boxes/scores to fp32 rounding of expf."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.ops import postprocess_logits
+    g = torch.Generator().manual_seed(11)
+    n, nc = 3, 80
+    shapes = [(20, 24), (10, 12), (5, 6)]
+    heads = [torch.randn(n, 3, h, w, nc + 5, generator=g) * 2.0 - 1.0 for h, w in shapes]
+    strides, anchors = O.anchors_for(3)
+    for thr, k in [(0.3, 300), (0.05, 50)]:
+        pred = O.decode(heads, strides, anchors)
+        ref = O.postprocess(pred, thr, 0.45, k)
+        got = postprocess_logits([h.to(dev) for h in heads], strides, anchors, nc, thr, 0.45, k)
+        for r, d in zip(ref, got):
+            assert len(d["scores"]) == len(r["scores"])
+            np.testing.assert_array_equal(d["labels"].cpu().numpy(), r["labels"].numpy())
+            np.testing.assert_allclose(d["scores"].cpu().numpy(), r["scores"].numpy(), rtol=2e-6, atol=1e-7)
+            np.testing.assert_allclose(d["boxes"].cpu().numpy(), r["boxes"].numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_postprocess_overflow_is_reported_and_recovered(dev):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.ops import postprocess_logits
+    g = torch.Generator().manual_seed(12)
+    heads = [torch.randn(1, 3, 8, 8, 85, generator=g) + 3.0]
+    strides, anchors = [8], [O.ANCHORS_P5[0]]
+    ref = O.postprocess(O.decode(heads, strides, anchors), 0.3, 0.45, 300)
+    got = postprocess_logits([h.to(dev) for h in heads], strides, anchors, 80, 0.3, 0.45, 300, cand_cap=64)  # far too small -> grows
+    np.testing.assert_array_equal(got[0]["labels"].cpu().numpy(), ref[0]["labels"].numpy())

@@ -1,0 +1,68 @@
+"""Builds yolort_amd/lib/libyolort_amd.so with hipcc for gfx950 (in-tree, no torch extension
+machinery, no hipify).  Usage: python -m yolort_amd._build [--force]"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libyolort_amd.so")
+SOURCES = ["api.cpp", "conv_igemm.hip", "preproc_pool.hip", "postprocess.hip"]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(os.path.dirname(PKG), "include", "yolort_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr[-2000:], file=sys.stderr)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    open(stamp, "w").write(dig)
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) // 1024} KB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,127 @@
+"""ctypes binding of libyolort_amd.so (C ABI in include/yolort_amd.h).
+
+There is NO fallback: if the shared library is missing or no MI355X is visible, every compute
+entry point raises.  `import torch` happens first on purpose: the torch wheel bundles its own
+libamdhip64.so (same SONAME as /opt/rocm's), and loading ours afterwards makes the dynamic loader
+bind our HIP symbols to the runtime torch already initialised, so streams, events and device
+pointers are shared (SURVEY.md section 7 "Two ROCm runtimes in one process").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libyolort_amd.so")
+
+YMI_F16, YMI_BF16, YMI_F32, YMI_U8 = 0, 1, 2, 3
+ACT_NONE, ACT_SILU = 0, 1
+MAX_LEVELS = 4
+
+
+class YmiError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("ktab", C.c_void_p), ("y", C.c_void_p), ("res", C.c_void_p),
+        ("n", C.c_int32), ("h", C.c_int32), ("w_in", C.c_int32), ("cin", C.c_int32), ("x_cstride", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32), ("y_cstride", C.c_int32), ("res_cstride", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32), ("k_pad", C.c_int32),
+        ("act", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+class PostDesc(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p * MAX_LEVELS),
+        ("lh", C.c_int32 * MAX_LEVELS), ("lw", C.c_int32 * MAX_LEVELS), ("lcstride", C.c_int32 * MAX_LEVELS),
+        ("stride", C.c_float * MAX_LEVELS),
+        ("anchors", (C.c_float * 6) * MAX_LEVELS),
+        ("num_levels", C.c_int32), ("n", C.c_int32), ("num_classes", C.c_int32),
+        ("score_thresh", C.c_float), ("nms_thresh", C.c_float),
+        ("detections_per_img", C.c_int32),
+        ("rescale", C.c_void_p),
+        ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p), ("out_labels", C.c_void_p), ("out_count", C.c_void_p),
+        ("status", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("cand_cap", C.c_int32),
+    ]
+
+
+_SIGS = {
+    "ymi_abi_version": (C.c_int, []),
+    "ymi_last_error": (C.c_char_p, []),
+    "ymi_device_count": (C.c_int, []),
+    "ymi_letterbox": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "ymi_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ymi_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "ymi_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ymi_conv_build_ktab": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "ymi_spp_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ymi_upsample2x": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ymi_copy_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ymi_postprocess_ws_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "ymi_postprocess": (C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
+    "ymi_nms_ws_bytes": (C.c_int64, [C.c_int]),
+    "ymi_batched_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ymi_plan_create": (C.c_void_p, []),
+    "ymi_plan_destroy": (None, [C.c_void_p]),
+    "ymi_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    "ymi_plan_add_spp_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ymi_plan_add_upsample2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "ymi_plan_add_copy_view": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "ymi_plan_add_postprocess": (C.c_int, [C.c_void_p, C.POINTER(PostDesc)]),
+    "ymi_plan_num_ops": (C.c_int, [C.c_void_p]),
+    "ymi_plan_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ymi_plan_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(require_gpu: bool = False) -> C.CDLL:
+    """Loads the shared library (once).  Raises YmiError loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YmiError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m yolort_amd._build` "
+                "(needs hipcc, cross-compiles for gfx950 without a GPU). There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.ymi_abi_version() != 1:
+            raise YmiError(f"ABI version mismatch: library reports {lib.ymi_abi_version()}, binding expects 1")
+        _lib = lib
+    if require_gpu:
+        if not torch.cuda.is_available():
+            raise YmiError("no MI355X visible (torch.cuda.is_available() is False): yolort_amd has no CPU fallback")
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc < 0:
+        msg = _lib.ymi_last_error().decode("utf-8", "replace") if _lib is not None else ""
+        raise YmiError(f"{what or 'libyolort_amd'} failed (code {rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return {torch.float16: YMI_F16, torch.bfloat16: YMI_BF16, torch.float32: YMI_F32, torch.uint8: YMI_U8}[dt]
+    except KeyError:
+        raise YmiError(f"unsupported dtype {dt}") from None
+
+
+def stream_ptr(stream: Optional["torch.cuda.Stream"] = None) -> C.c_void_p:
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)

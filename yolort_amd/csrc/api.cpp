@@ -1,0 +1,209 @@
+// C-ABI glue of libyolort_amd.so: error reporting and the plan executor (recorded launch sequence,
+// optional hipGraph replay, per-op HIP-event profiling).  See include/yolort_amd.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace ymi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);
+int postprocess_launch(const ymi_post_desc* d, hipStream_t s);
+
+enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST };
+
+struct Op {
+    OpKind kind;
+    ymi_conv_desc conv;
+    ymi_post_desc post;
+    // generic small-op arguments
+    const void* x;
+    void* y;
+    int i[8];
+};
+
+static int run_op(const Op& op, hipStream_t s) {
+    switch (op.kind) {
+        case OP_CONV: return conv2d_launch(&op.conv, s);
+        case OP_SPP: return ymi_spp_pool(op.y, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
+        case OP_UP: return ymi_upsample2x(op.x, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.y, op.i[5], op.i[6], s);
+        case OP_COPY: return ymi_copy_view(op.x, op.i[0], op.i[1], op.i[2], op.y, op.i[3], op.i[4], s);
+        case OP_POST: return postprocess_launch(&op.post, s);
+    }
+    set_error("unknown op kind");
+    return YMI_EINVAL;
+}
+
+}  // namespace ymi
+
+struct ymi_plan {
+    std::vector<ymi::Op> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int graph_first = -1, graph_last = -1;
+    hipStream_t graph_stream = nullptr;
+};
+
+using namespace ymi;
+
+extern "C" int ymi_abi_version(void) { return YMI_ABI_VERSION; }
+extern "C" const char* ymi_last_error(void) { return g_err; }
+extern "C" int ymi_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return YMI_EHIP;
+    }
+    return n;
+}
+
+extern "C" ymi_plan* ymi_plan_create(void) { return new (std::nothrow) ymi_plan(); }
+
+static void drop_graph(ymi_plan* p) {
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->exec = nullptr;
+    p->graph = nullptr;
+    p->graph_first = p->graph_last = -1;
+}
+
+extern "C" void ymi_plan_destroy(ymi_plan* p) {
+    if (!p) return;
+    drop_graph(p);
+    delete p;
+}
+
+extern "C" int ymi_plan_add_conv(ymi_plan* p, const ymi_conv_desc* d) {
+    YMI_REQUIRE(p && d, "ymi_plan_add_conv: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_CONV;
+    op.conv = *d;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_spp_pool(ymi_plan* p, void* buf, int n, int h, int w, int c, int cstride, int dtype) {
+    YMI_REQUIRE(p && buf, "ymi_plan_add_spp_pool: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_SPP;
+    op.y = buf;
+    op.i[0] = n; op.i[1] = h; op.i[2] = w; op.i[3] = c; op.i[4] = cstride; op.i[5] = dtype;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_upsample2x(ymi_plan* p, const void* x, int x_cstride, int n, int h, int w, int c, void* y, int y_cstride, int dtype) {
+    YMI_REQUIRE(p && x && y, "ymi_plan_add_upsample2x: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_UP;
+    op.x = x; op.y = y;
+    op.i[0] = x_cstride; op.i[1] = n; op.i[2] = h; op.i[3] = w; op.i[4] = c; op.i[5] = y_cstride; op.i[6] = dtype;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_copy_view(ymi_plan* p, const void* x, int x_cstride, int npix, int c, void* y, int y_cstride, int dtype) {
+    YMI_REQUIRE(p && x && y, "ymi_plan_add_copy_view: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_COPY;
+    op.x = x; op.y = y;
+    op.i[0] = x_cstride; op.i[1] = npix; op.i[2] = c; op.i[3] = y_cstride; op.i[4] = dtype;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_postprocess(ymi_plan* p, const ymi_post_desc* d) {
+    YMI_REQUIRE(p && d, "ymi_plan_add_postprocess: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_POST;
+    op.post = *d;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_num_ops(const ymi_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream) {
+    YMI_REQUIRE(p != nullptr, "ymi_plan_run: null plan");
+    hipStream_t s = (hipStream_t)stream;
+    const int nops = (int)p->ops.size();
+    if (last < 0 || last > nops) last = nops;
+    if (first < 0) first = 0;
+    if (!use_graph) {
+        for (int i = first; i < last; ++i) {
+            int rc = run_op(p->ops[i], s);
+            if (rc != YMI_OK) return rc;
+        }
+        return YMI_OK;
+    }
+    if (!p->exec || p->graph_first != first || p->graph_last != last) {
+        drop_graph(p);
+        YMI_REQUIRE(s != nullptr, "ymi_plan_run: graph capture needs a non-default stream");
+        YMI_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = YMI_OK;
+        for (int i = first; i < last && rc == YMI_OK; ++i) rc = run_op(p->ops[i], s);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != YMI_OK) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess) {
+            set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            return YMI_EHIP;
+        }
+        p->graph = g;
+        YMI_CHECK_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+        p->graph_first = first;
+        p->graph_last = last;
+    }
+    YMI_CHECK_HIP(hipGraphLaunch(p->exec, s));
+    return YMI_OK;
+}
+
+extern "C" int ymi_plan_profile(ymi_plan* p, int iters, float* ms_out, void* stream) {
+    YMI_REQUIRE(p && ms_out && iters > 0, "ymi_plan_profile: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nops = (int)p->ops.size();
+    std::vector<hipEvent_t> ev(nops + 1);
+    for (auto& e : ev) YMI_CHECK_HIP(hipEventCreate(&e));
+    for (int i = 0; i < nops; ++i) ms_out[i] = 0.f;
+    int rc = YMI_OK;
+    for (int it = 0; it < iters && rc == YMI_OK; ++it) {
+        YMI_CHECK_HIP(hipEventRecord(ev[0], s));
+        for (int i = 0; i < nops && rc == YMI_OK; ++i) {
+            rc = run_op(p->ops[i], s);
+            YMI_CHECK_HIP(hipEventRecord(ev[i + 1], s));
+        }
+        YMI_CHECK_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nops && rc == YMI_OK; ++i) {
+            float ms = 0.f;
+            YMI_CHECK_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_out[i] += ms / (float)iters;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}

@@ -1,0 +1,343 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC fp16/bf16 activations, MFMA 32x32x16,
+// fused bias + SiLU (+ residual) epilogue, reads/writes channel slices of concat buffers.
+//
+// GEMM view (computed "swapped" so that each lane ends up owning consecutive output channels of
+// ONE pixel, which makes the NHWC store 8/16 bytes wide):
+//     D[cout][pixel] = sum_k  W[cout][k] * X[pixel][k],   k = (ky*kw + kx)*cin + c
+//   MFMA A operand = weight fragment (rows = cout), B operand = activation fragment (cols = pixel).
+//   v_mfma_f32_32x32x16: lane l holds A[row = l&31][k = 8*(l>>5) .. +7], B[k = 8*(l>>5)..+7][col = l&31],
+//   D reg r of lane l = D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+//
+// Tiling: block = 256 threads = 4 waves, block tile BM pixels x BN couts, BK = 32 per step.
+// Activation tile is gathered straight from the NHWC input with 16-byte loads (8 channels of one
+// tap of one pixel), zero-filled outside the image; an int32 table (ktab) gives, per 8-channel
+// k-chunk, the element offset and (dy,dx) of its tap, so 1x1, 3x3 s1/s2 and the 6x6 s2 stem share
+// one kernel.  Tiles are double-buffered in LDS (register-staged: global loads for step t+1 are
+// issued before the MFMAs of step t; the LDS write lands after them).  LDS rows are padded to
+// 80 bytes: a 16-lane ds_read_b128 group then touches 16 distinct 16-byte slots (conflict free).
+//
+// Replaces: yolort/v5/models/common.py:69-70 (Conv.forward: conv2d -> BatchNorm2d -> SiLU, BN folded),
+//           common.py:115-116 (Bottleneck residual), yolort/models/box_head.py:36,74 (head conv).
+#include "common.hpp"
+
+namespace ymi {
+
+constexpr int BK = 32;          // k elements per main-loop step
+constexpr int LDS_PITCH = 40;   // halfs per LDS row (32 + 8 pad) = 80 bytes
+
+template <int DT>
+struct Mfma;
+template <>
+struct Mfma<YMI_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mfma<YMI_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct ConvArgs {
+    const uint16_t* x;
+    const uint16_t* w;
+    const float* bias;
+    const int2* ktab;
+    void* y;
+    const uint16_t* res;
+    int n, h, w_in, cin, x_cs;
+    int ho, wo, cout, cout_pad, y_cs, res_cs;
+    int sh, sw, ph, pw, k_pad;
+    int act;
+    int M;         // n*ho*wo
+    int nblk_m, nblk_n;
+};
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+// BM x BN block tile, each wave WM x WN; IS1X1: kh=kw=1, stride 1, pad 0 (no bounds checks, no table)
+template <int DT, int ODT, int BM, int BN, int WM, int WN, bool IS1X1>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_ROWS = BM / 64, W_ROWS = (BN + 63) / 64;  // rows per thread per tile
+    constexpr int WAVES_N = BN / WN;
+    typedef typename Mfma<DT>::frag frag;
+
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2][(BM + BN) * LDS_PITCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = (wave / WAVES_N) * WM, wave_n = (wave % WAVES_N) * WN;
+
+    // block -> tile: XCD-aware remap, then cout-tile fastest so the blocks that share one
+    // activation tile run back-to-back on the same XCD (its L2 serves the re-reads).
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int bm = lb / a.nblk_n, bn = lb % a.nblk_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- per-thread gather geometry: thread loads chunk (tid&3) of rows (tid>>2) + 64*i ----
+    const int chunk = tid & 3;
+    const int row0 = tid >> 2;
+    int64_t a_base[A_ROWS];   // element offset of (img, iy0, ix0, 0); may be "negative-ish" -> int64
+    int a_iy0[A_ROWS], a_ix0[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int m = m0 + row0 + 64 * i;
+        if (m < a.M) {
+            const int img = m / (a.ho * a.wo);
+            const int rem = m - img * (a.ho * a.wo);
+            const int oy = rem / a.wo, ox = rem - oy * a.wo;
+            const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+            a_iy0[i] = iy0;
+            a_ix0[i] = ix0;
+            a_base[i] = ((int64_t)(img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
+        } else {
+            a_iy0[i] = -100000;  // every tap out of range -> zeros
+            a_ix0[i] = -100000;
+            a_base[i] = 0;
+        }
+    }
+    const uint16_t* w_ptr[W_ROWS];
+    bool w_ok[W_ROWS];
+#pragma unroll
+    for (int i = 0; i < W_ROWS; ++i) {
+        const int r = row0 + 64 * i;
+        w_ok[i] = (r < BN) && (n0 + r < a.cout_pad);
+        w_ptr[i] = a.w + (int64_t)(n0 + (w_ok[i] ? r : 0)) * a.k_pad + chunk * 8;
+    }
+
+    u32x4 a_reg[A_ROWS], w_reg[W_ROWS];
+    const int nsteps = a.k_pad / BK;
+
+    auto load_tiles = [&](int step) {
+        const int q = step * 4 + chunk;  // 8-channel chunk index along K
+        int koff, dy, dx;
+        if constexpr (IS1X1) {
+            koff = q * 8;
+            dy = 0;
+            dx = 0;
+        } else {
+            const int2 t = a.ktab[q];
+            koff = t.x;
+            dy = t.y >> 16;      // -1 for padding chunks (t.y == -1)
+            dx = t.y & 0xffff;
+        }
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            bool ok;
+            if constexpr (IS1X1) {
+                ok = (a_iy0[i] >= 0) && (koff < a.cin);
+            } else {
+                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+                ok = (dy >= 0) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w_in);
+            }
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(a.x + a_base[i] + koff);
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < W_ROWS; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (w_ok[i]) v = *reinterpret_cast<const u32x4*>(w_ptr[i] + step * BK);
+            w_reg[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        uint16_t* as = lds[buf];
+        uint16_t* ws = lds[buf] + BM * LDS_PITCH;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i)
+            *reinterpret_cast<u32x4*>(as + (row0 + 64 * i) * LDS_PITCH + chunk * 8) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < W_ROWS; ++i)
+            if (row0 + 64 * i < BN) *reinterpret_cast<u32x4*>(ws + (row0 + 64 * i) * LDS_PITCH + chunk * 8) = w_reg[i];
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) load_tiles(step + 1);  // global loads in flight under the MFMAs
+        const uint16_t* as = lds[buf] + wave_m * LDS_PITCH;
+        const uint16_t* ws = lds[buf] + (BM + wave_n) * LDS_PITCH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag af[TM], wf[TN];
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                af[j] = *reinterpret_cast<const frag*>(as + (j * 32 + frow) * LDS_PITCH + ks * 16 + fk);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                wf[i] = *reinterpret_cast<const frag*>(ws + (i * 32 + frow) * LDS_PITCH + ks * 16 + fk);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(wf[i], af[j], acc[i][j]);
+        }
+        if (step + 1 < nsteps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + act (+ residual), lane owns pixel (lane&31) and 4 groups of 4 couts ----
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wave_m + j * 32 + frow;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = n0 + wave_n + i * 32 + g * 8 + hi * 4;
+                if (co >= a.cout) continue;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][g * 4 + e] + b[e];
+                    if (a.act == YMI_ACT_SILU) t = silu(t);
+                    v[e] = t;
+                }
+                if (a.res != nullptr) {
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (int64_t)m * a.res_cs + co);
+                    v[0] += from16<DT>((uint16_t)(rv[0] & 0xffff));
+                    v[1] += from16<DT>((uint16_t)(rv[0] >> 16));
+                    v[2] += from16<DT>((uint16_t)(rv[1] & 0xffff));
+                    v[3] += from16<DT>((uint16_t)(rv[1] >> 16));
+                }
+                if constexpr (ODT == YMI_F32) {
+                    float* yp = reinterpret_cast<float*>(a.y) + (int64_t)m * a.y_cs + co;
+                    if (co + 3 < a.cout) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(yp) = o;
+                    } else {
+                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[e];
+                    }
+                } else {
+                    uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
+                    if (co + 3 < a.cout) {
+                        u32x2 o;
+                        o[0] = (uint32_t)to16<DT>(v[0]) | ((uint32_t)to16<DT>(v[1]) << 16);
+                        o[1] = (uint32_t)to16<DT>(v[2]) | ((uint32_t)to16<DT>(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(yp) = o;
+                    } else {
+                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvArgs& a0, bool is1x1, hipStream_t s) {
+    ConvArgs a = a0;
+    a.nblk_m = cdiv(a.M, BM);
+    a.nblk_n = cdiv(a.cout_pad, BN);
+    dim3 grid(a.nblk_m * a.nblk_n), block(256);
+    if (is1x1)
+        hipLaunchKernelGGL((conv_igemm_kernel<DT, ODT, BM, BN, WM, WN, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<DT, ODT, BM, BN, WM, WN, false>), grid, block, 0, s, a);
+    return check_launch("conv_igemm_kernel");
+}
+
+// tile ids: 1 = 128x128, 2 = 256x64, 3 = 256x32, 4 = 64x128, 5 = 128x64, 6 = 64x64... keep small
+template <int DT, int ODT>
+static int launch_dtype(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) {
+    if (tile == 0) {
+        const int cp = a.cout_pad;
+        if (cp <= 32) tile = 3;
+        else if (cp <= 64) tile = 2;
+        else {
+            // enough 128x128 tiles to fill 256 CUs a few times over? else halve the pixel tile
+            const long blocks = (long)cdiv(a.M, 128) * cdiv(cp, 128);
+            tile = (blocks >= 512) ? 1 : 4;
+            if (cp % 128 != 0 && cp % 64 == 0 && cp < 128) tile = 2;
+        }
+    }
+    switch (tile) {
+        case 1: return launch_cfg<DT, ODT, 128, 128, 64, 64>(a, is1x1, s);
+        case 2: return launch_cfg<DT, ODT, 256, 64, 64, 64>(a, is1x1, s);
+        case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(a, is1x1, s);
+        case 4: return launch_cfg<DT, ODT, 64, 128, 32, 64>(a, is1x1, s);
+        case 5: return launch_cfg<DT, ODT, 128, 64, 64, 32>(a, is1x1, s);
+        default: set_error("ymi_conv2d: unknown tile id %d", tile); return YMI_EINVAL;
+    }
+}
+
+int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
+    YMI_REQUIRE(d != nullptr, "ymi_conv2d: null descriptor");
+    YMI_REQUIRE(d->x && d->w && d->bias && d->y, "ymi_conv2d: null buffer");
+    YMI_REQUIRE(d->cin % 8 == 0 && d->x_cstride % 8 == 0, "ymi_conv2d: cin (%d) and x_cstride (%d) must be multiples of 8", d->cin, d->x_cstride);
+    YMI_REQUIRE(d->cout_pad % 32 == 0 && d->k_pad % 32 == 0, "ymi_conv2d: cout_pad (%d) / k_pad (%d) must be multiples of 32", d->cout_pad, d->k_pad);
+    YMI_REQUIRE(d->k_pad >= d->kh * d->kw * d->cin, "ymi_conv2d: k_pad %d < K %d", d->k_pad, d->kh * d->kw * d->cin);
+    YMI_REQUIRE(d->y_cstride % 4 == 0 && (d->res == nullptr || d->res_cstride % 4 == 0), "ymi_conv2d: y/res cstride must be multiples of 4");
+    YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16, "ymi_conv2d: dtype must be F16 or BF16");
+    YMI_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == YMI_F32, "ymi_conv2d: out_dtype must equal dtype or be F32");
+    YMI_REQUIRE(d->ho == (d->h + 2 * d->ph - d->kh) / d->sh + 1 && d->wo == (d->w_in + 2 * d->pw - d->kw) / d->sw + 1,
+                "ymi_conv2d: output size %dx%d inconsistent with input %dx%d k%dx%d s%dx%d p%dx%d", d->ho, d->wo, d->h, d->w_in, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
+    const bool is1x1 = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0;
+    YMI_REQUIRE(is1x1 || d->ktab != nullptr, "ymi_conv2d: ktab required for non-1x1 convolutions");
+    if ((int64_t)d->n * d->ho * d->wo >= (int64_t)1 << 31) {
+        set_error("ymi_conv2d: too many output pixels");
+        return YMI_EINVAL;
+    }
+    ConvArgs a;
+    a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = d->bias; a.ktab = (const int2*)d->ktab;
+    a.y = d->y; a.res = (const uint16_t*)d->res;
+    a.n = d->n; a.h = d->h; a.w_in = d->w_in; a.cin = d->cin; a.x_cs = d->x_cstride;
+    a.ho = d->ho; a.wo = d->wo; a.cout = d->cout; a.cout_pad = d->cout_pad; a.y_cs = d->y_cstride; a.res_cs = d->res_cstride;
+    a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw; a.k_pad = d->k_pad; a.act = d->act;
+    a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
+    if (a.M == 0) return YMI_OK;
+    if (d->dtype == YMI_F16) {
+        if (d->out_dtype == YMI_F32) return launch_dtype<YMI_F16, YMI_F32>(a, is1x1, d->tile, s);
+        return launch_dtype<YMI_F16, YMI_F16>(a, is1x1, d->tile, s);
+    } else {
+        if (d->out_dtype == YMI_F32) return launch_dtype<YMI_BF16, YMI_F32>(a, is1x1, d->tile, s);
+        return launch_dtype<YMI_BF16, YMI_BF16>(a, is1x1, d->tile, s);
+    }
+}
+
+}  // namespace ymi
+
+extern "C" int ymi_conv2d(const ymi_conv_desc* d, void* stream) { return ymi::conv2d_launch(d, (hipStream_t)stream); }
+
+extern "C" int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_pad, int32_t* t) {
+    if (cin % 8 != 0 || k_pad % 32 != 0 || t == nullptr) {
+        ymi::set_error("ymi_conv_build_ktab: cin %% 8 and k_pad %% 32 must be 0");
+        return YMI_EINVAL;
+    }
+    const int K = kh * kw * cin;
+    for (int q = 0; q < k_pad / 8; ++q) {
+        const int k0 = q * 8;
+        if (k0 >= K) {
+            t[2 * q] = 0;
+            t[2 * q + 1] = -1;
+            continue;
+        }
+        const int tap = k0 / cin, c = k0 - tap * cin;
+        const int dy = tap / kw, dx = tap - dy * kw;
+        t[2 * q] = (dy * w_in + dx) * x_cstride + c;
+        t[2 * q + 1] = (dy << 16) | dx;
+    }
+    return YMI_OK;
+}

@@ -1,0 +1,667 @@
+// Detection post-process for gfx950: anchor decode + sigmoid + multi-label threshold compaction,
+// stable radix sort, class-aware greedy NMS with wave64 ballot/shuffle, top-k + box rescale.
+// Integer/index work is bit-exact w.r.t. the oracle contract; float
+// arithmetic uses explicitly un-fused fp32 ops so that it follows torch's per-op rounding.
+//
+// Replaces: yolort/models/box_head.py:328-360 (_concat_pred_logits/_decode_pred_logits),
+//           :414-427 (per-image threshold / batched_nms / top-k loop), yolort/models/_utils.py:59-60,
+//           yolort/models/anchor_utils.py:19-60 (grids/shifts in closed form),
+//           yolort/models/transform.py:354-367 (scale_coords).
+//
+// Record format (96 bits): hi = img << 32 | ~score_bits (u64), lo = cand = anchor << L | label (u32)
+// with L = label bits.  Sorting records ascending by (hi, lo) gives, per image, score descending
+// with ties in candidate order (anchor asc, class asc) == a stable descending sort of the
+// reference's torch.where order (box_head.py:418).
+#include "common.hpp"
+
+namespace ymi {
+
+// status words (device int32[4])
+enum { ST_NCAND = 0, ST_OVERFLOW = 1, ST_NSEG = 2, ST_RSV = 3 };
+
+struct Workspace {
+    // all device pointers, carved from the caller's `ws`
+    float* boxes_all;     // (n, A, 4) decoded xyxy boxes of every anchor
+    uint64_t* hi[2];      // ping-pong record arrays (cand_cap each)
+    uint32_t* lo[2];
+    uint32_t* hist;       // (max_blocks, 256) per-block digit counts / offsets
+    uint32_t* seg_start;  // (cand_cap) segment start positions (unordered)
+    float* kept_box;      // (cand_cap, 4) per-segment kept boxes
+    uint8_t* keep;        // (cand_cap) keep flag indexed by global rank r
+    int64_t total;
+};
+
+constexpr int SORT_ITEMS = 2048;  // records per block per radix pass (256 threads x 8)
+
+static int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+static Workspace carve(void* ws, int n, int total_anchors, int cand_cap) {
+    Workspace w;
+    char* p = (char*)ws;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { char* q = p ? p + off : nullptr; off += align_up(bytes); return q; };
+    const int max_blocks = cdiv(cand_cap, SORT_ITEMS);
+    w.boxes_all = (float*)take((int64_t)n * total_anchors * 16);
+    w.hi[0] = (uint64_t*)take((int64_t)cand_cap * 8);
+    w.hi[1] = (uint64_t*)take((int64_t)cand_cap * 8);
+    w.lo[0] = (uint32_t*)take((int64_t)cand_cap * 4);
+    w.lo[1] = (uint32_t*)take((int64_t)cand_cap * 4);
+    w.hist = (uint32_t*)take((int64_t)max_blocks * 256 * 4 + 1024);
+    w.seg_start = (uint32_t*)take((int64_t)cand_cap * 4);
+    w.kept_box = (float*)take((int64_t)cand_cap * 16);
+    w.keep = (uint8_t*)take((int64_t)cand_cap);
+    w.total = off;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// 1. decode + threshold.  One wave per feature-map pixel: its 3 x K logits are contiguous in the
+//    NHWC fp32 head output, so the wave reads them with coalesced float4 loads (lane l holds
+//    channels 4l..4l+3).  Objectness is broadcast with wave shuffles; since cls < 1,
+//    score = cls*obj > thr requires obj > thr, so pixels whose three anchors all fail that test
+//    skip the class work (the common case).
+// ------------------------------------------------------------------------------------------
+struct DecodeArgs {
+    const float* logits;
+    int h, w, cs;          // level geometry, channel stride
+    float stride;
+    float anc[6];
+    int n, K;              // images, outputs per anchor (num_classes + 5)
+    int level_off;         // index of this level's first anchor within an image
+    int total_anchors;     // anchors per image over all levels
+    int label_bits;
+    float thr;
+    float* boxes_all;
+    uint64_t* hi;
+    uint32_t* lo;
+    int* status;
+    int cap;
+};
+
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t npix = (int64_t)a.n * a.h * a.w;
+    if (pix >= npix) return;
+    const int hw = a.h * a.w;
+    const int img = (int)(pix / hw);
+    const int rem = (int)(pix - (int64_t)img * hw);
+    const int y = rem / a.w, x = rem - y * a.w;
+    const int nch = 3 * a.K;
+    const float* row = a.logits + pix * a.cs;
+    // channels handled by this lane in pass p: c = (p*64 + lane)*4 + e
+    const int npass = cdiv(nch, 256);
+    // objectness + box logits of the three anchors (uniform loads, L1 hits)
+    float obj[3];
+    bool any_obj = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        obj[k] = sigmoid_acc(row[k * a.K + 4]);
+        any_obj |= obj[k] > a.thr;
+    }
+    // decoded boxes: lanes 0..2 own anchor `lane`
+    if (lane < 3) {
+        const float* r = row + lane * a.K;
+        const float sx = sigmoid_acc(r[0]), sy = sigmoid_acc(r[1]), sw = sigmoid_acc(r[2]), sh = sigmoid_acc(r[3]);
+        // _utils.py:59-60: xy = (s*2 - 0.5 + grid) * stride ; wh = (s*2)**2 * anchor   (each op rounded)
+        const float cx = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sx, 2.0f), 0.5f), (float)x), a.stride);
+        const float cy = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sy, 2.0f), 0.5f), (float)y), a.stride);
+        const float w2 = __fmul_rn(sw, 2.0f), h2 = __fmul_rn(sh, 2.0f);
+        const float bw = __fmul_rn(__fmul_rn(w2, w2), a.anc[2 * lane]);
+        const float bh = __fmul_rn(__fmul_rn(h2, h2), a.anc[2 * lane + 1]);
+        // box_convert cxcywh -> xyxy (box_head.py:358)
+        const float hw_ = __fmul_rn(0.5f, bw), hh_ = __fmul_rn(0.5f, bh);
+        f32x4 b = {__fsub_rn(cx, hw_), __fsub_rn(cy, hh_), __fadd_rn(cx, hw_), __fadd_rn(cy, hh_)};
+        const int anchor = a.level_off + (lane * a.h + y) * a.w + x;
+        *reinterpret_cast<f32x4*>(a.boxes_all + ((int64_t)img * a.total_anchors + anchor) * 4) = b;
+    }
+    if (!any_obj) return;
+    for (int p = 0; p < npass; ++p) {
+        const int c0 = (p * 64 + lane) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + 3 < nch) v = *reinterpret_cast<const f32x4*>(row + c0);
+        else
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < nch) v[e] = row[c0 + e];
+        float sc[4];
+        unsigned cand[4];
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            const int k = c / a.K, cls = c - k * a.K - 5;
+            bool ok = (c < nch) && (cls >= 0);
+            float s = 0.f;
+            if (ok) {
+                const float o = k == 0 ? obj[0] : (k == 1 ? obj[1] : obj[2]);
+                s = __fmul_rn(sigmoid_acc(v[e]), o);  // box_head.py:357 scores = cls * obj
+                ok = s > a.thr;                        // box_head.py:418 strict >
+            }
+            sc[e] = s;
+            const int anchor = a.level_off + (k * a.h + y) * a.w + x;
+            cand[e] = ((unsigned)anchor << a.label_bits) | (unsigned)(cls < 0 ? 0 : cls);
+            if (!ok) cand[e] = 0xffffffffu;
+            cnt += ok ? 1 : 0;
+        }
+        // wave-level ordered allocation: inclusive scan of cnt over lanes
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&a.status[ST_NCAND], total);
+        base = __shfl(base, 0, 64);
+        int pos = base + incl - cnt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (cand[e] != 0xffffffffu) {
+                if (pos < a.cap) {
+                    a.hi[pos] = ((uint64_t)(unsigned)img << 32) | (uint64_t)(~__float_as_uint(sc[e]));
+                    a.lo[pos] = cand[e];
+                }
+                ++pos;
+            }
+        }
+    }
+}
+
+__global__ void finalize_count_kernel(int* status, int cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (status[ST_NCAND] > cap) status[ST_OVERFLOW] = 1;
+    }
+}
+
+__device__ __forceinline__ int ncand(const int* status, int cap) {
+    const int n = status[ST_NCAND];
+    return n < cap ? n : cap;
+}
+
+// ------------------------------------------------------------------------------------------
+// 2. LSD radix sort, 8 bits per pass, stable.  Three kernels per pass (histogram / scan / scatter).
+//    The record count lives on the device (no host sync): blocks past the end exit at once.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned digit_of(uint64_t hi, uint32_t lo, int shift) {
+    return shift < 32 ? (lo >> shift) & 0xffu : (unsigned)(hi >> (shift - 32)) & 0xffu;
+}
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* hi, const uint32_t* lo, const int* status, int cap, int shift, uint32_t* hist) {
+    __shared__ unsigned cnt[256];
+    const int n = ncand(status, cap);
+    const int base = blockIdx.x * SORT_ITEMS;
+    if (base >= n) return;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int end = min(n, base + SORT_ITEMS);
+    for (int i = base + threadIdx.x; i < end; i += 256) atomicAdd(&cnt[digit_of(hi[i], lo[i], shift)], 1u);
+    __syncthreads();
+    hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// single block, 256 threads: thread d owns digit d.  hist[b][d] -> exclusive global offset.
+__global__ __launch_bounds__(256) void radix_scan_kernel(const int* status, int cap, uint32_t* hist) {
+    __shared__ unsigned tot[256];
+    const int n = ncand(status, cap);
+    const int nblk = cdiv(n, SORT_ITEMS);
+    const int d = threadIdx.x;
+    unsigned run = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const unsigned c = hist[(int64_t)b * 256 + d];
+        hist[(int64_t)b * 256 + d] = run;
+        run += c;
+    }
+    tot[d] = run;
+    __syncthreads();
+    // exclusive scan over digits (256 values): simple Hillis-Steele in LDS
+    for (int s = 1; s < 256; s <<= 1) {
+        unsigned v = d >= s ? tot[d - s] : 0;
+        __syncthreads();
+        tot[d] += v;
+        __syncthreads();
+    }
+    const unsigned dbase = tot[d] - run;
+    for (int b = 0; b < nblk; ++b) hist[(int64_t)b * 256 + d] += dbase;
+}
+
+// scatter: wave w of the block owns the contiguous records [base + w*512, +512), 8 rounds of 64.
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* hi_in, const uint32_t* lo_in, uint64_t* hi_out, uint32_t* lo_out,
+                                                            const int* status, int cap, int shift, const uint32_t* hist) {
+    __shared__ unsigned wave_hist[4][256];
+    __shared__ unsigned wave_base[4][256];
+    const int n = ncand(status, cap);
+    const int base = blockIdx.x * SORT_ITEMS;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 1024; i += 256) (&wave_hist[0][0])[i] = 0;
+    __syncthreads();
+    uint64_t rhi[8];
+    uint32_t rlo[8];
+    unsigned dig[8];
+    uint64_t peers[8];
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = base + wave * 512 + r * 64 + lane;
+        const bool valid = i < n;
+        rhi[r] = valid ? hi_in[i] : 0;
+        rlo[r] = valid ? lo_in[i] : 0;
+        const unsigned dg = valid ? digit_of(rhi[r], rlo[r], shift) : 0x100u;  // 0x100 = invalid marker
+        dig[r] = dg;
+        // peer mask: lanes of this round with the same digit
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bm = __ballot((dg >> b) & 1u);
+            m &= ((dg >> b) & 1u) ? bm : ~bm;
+        }
+        peers[r] = valid ? m : 0ull;
+        if (valid && (m & lt) == 0) wave_hist[wave][dg] += __popcll(m);  // leader lane of the peer group
+        // (distinct digits -> distinct LDS addresses; rounds are sequential within the wave)
+    }
+    __syncthreads();
+    {
+        const int d = threadIdx.x;
+        unsigned run = hist[(int64_t)blockIdx.x * 256 + d];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            wave_base[w][d] = run;
+            run += wave_hist[w][d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (dig[r] != 0x100u) {
+            const unsigned rank = __popcll(peers[r] & lt);
+            const unsigned dst = wave_base[wave][dig[r]] + rank;
+            hi_out[dst] = rhi[r];
+            lo_out[dst] = rlo[r];
+        }
+        // make every lane's read of wave_base[..] precede the leaders' update for this round
+        __builtin_amdgcn_wave_barrier();
+        if (dig[r] != 0x100u && (peers[r] & lt) == 0) wave_base[wave][dig[r]] += __popcll(peers[r]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 3. class-aware NMS.  After the global sort G, records are re-keyed as
+//      hi' = img << 16 | label,  lo' = r (rank in G)
+//    and stably sorted by label, so each (label, img) segment lists its candidates in score order.
+//    One wave per segment runs the exact greedy algorithm: 64 candidates per step are tested against
+//    the kept boxes so far (uniform loads), then resolved among themselves with ballots/shuffles.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void make_label_records_kernel(const uint64_t* ghi, const uint32_t* glo, uint64_t* phi, uint32_t* plo,
+                                                                 const int* status, int cap, int label_bits, uint8_t* keep) {
+    const int n = ncand(status, cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned label = glo[i] & ((1u << label_bits) - 1u);
+    const unsigned img = (unsigned)(ghi[i] >> 32);
+    phi[i] = ((uint64_t)img << 16) | label;
+    plo[i] = (uint32_t)i;
+    keep[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void find_segments_kernel(const uint64_t* phi, int* status, int cap, uint32_t* seg_start) {
+    const int n = ncand(status, cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || phi[i] != phi[i - 1]) seg_start[atomicAdd(&status[ST_NSEG], 1)] = (uint32_t)i;
+}
+
+__device__ __forceinline__ bool iou_gt(const f32x4 bi, float area_i, const f32x4 bj, float area_j, float thr) {
+    // torchvision nms: inter / (iarea + jarea - inter) > thr, fp32, no fused ops
+    const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+    const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+    const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+    const float inter = __fmul_rn(w, h);
+    const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));
+    return iou > thr;
+}
+
+__global__ __launch_bounds__(256) void nms_segments_kernel(const uint64_t* phi, const uint32_t* plo, const uint64_t* ghi, const uint32_t* glo,
+                                                           const float* boxes_all, int total_anchors, int label_bits, const int* status, int cap,
+                                                           const uint32_t* seg_start, float* kept_box, uint8_t* keep, float thr) {
+    const int n = ncand(status, cap);
+    const int nseg = status[ST_NSEG];
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * 256) >> 6;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int s = wave_global; s < nseg; s += nwaves) {
+        const int start = (int)seg_start[s];
+        const uint64_t key = phi[start];
+        int kept_cnt = 0;
+        f32x4* kb = reinterpret_cast<f32x4*>(kept_box) + start;
+        for (int c = start;; c += 64) {
+            const int p = c + lane;
+            const bool valid = p < n && phi[p] == key;
+            const uint64_t vmask = __ballot(valid);
+            if (vmask == 0) break;
+            f32x4 box = {0.f, 0.f, 0.f, 0.f};
+            unsigned r = 0;
+            if (valid) {
+                r = plo[p];
+                const unsigned img = (unsigned)(ghi[r] >> 32);
+                const unsigned anchor = glo[r] >> label_bits;
+                box = *reinterpret_cast<const f32x4*>(boxes_all + ((int64_t)img * total_anchors + anchor) * 4);
+            }
+            const float area = __fmul_rn(__fsub_rn(box[2], box[0]), __fsub_rn(box[3], box[1]));
+            bool alive = valid;
+            // against boxes already kept in this segment (higher score)
+            for (int j = 0; j < kept_cnt; ++j) {
+                const f32x4 k = kb[j];
+                const float ka = __fmul_rn(__fsub_rn(k[2], k[0]), __fsub_rn(k[3], k[1]));
+                if (alive && iou_gt(k, ka, box, area, thr)) alive = false;
+            }
+            // among the 64 candidates of this step, in order
+            uint64_t mask = __ballot(alive);
+            uint64_t todo = mask;
+            while (todo) {
+                const int i = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                f32x4 bi;
+                bi[0] = __shfl(box[0], i, 64);
+                bi[1] = __shfl(box[1], i, 64);
+                bi[2] = __shfl(box[2], i, 64);
+                bi[3] = __shfl(box[3], i, 64);
+                const float ai = __shfl(area, i, 64);
+                if (alive && lane > i && iou_gt(bi, ai, box, area, thr)) alive = false;
+                mask = __ballot(alive);
+                todo &= mask;
+            }
+            if (alive) {
+                kb[kept_cnt + __popcll(mask & lt)] = box;
+                keep[r] = 1;
+            }
+            kept_cnt += __popcll(mask);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // kept boxes visible to this wave's later loads
+            if (vmask != ~0ull) break;  // last (partial) step of the segment
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4. top-k + rescale.  One block per image: binary-search the image's range in G, then an ordered
+//    compaction of the keep flags in rank order; first K kept are written to the fixed slab.
+// ------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const uint64_t* ghi;
+    const uint32_t* glo;
+    const uint8_t* keep;
+    const float* boxes_all;
+    const float* rescale;
+    const int* status;
+    int cap, total_anchors, label_bits, K;
+    float* out_boxes;
+    float* out_scores;
+    int64_t* out_labels;
+    int* out_count;
+};
+
+__device__ int lower_bound_img(const uint64_t* ghi, int n, unsigned img) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned)(ghi[mid] >> 32) < img) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void gather_topk_kernel(const GatherArgs a) {
+    __shared__ int wave_cnt[4];
+    __shared__ int s_taken;
+    const int n = ncand(a.status, a.cap);
+    const unsigned img = blockIdx.x;
+    const int begin = lower_bound_img(a.ghi, n, img), end = lower_bound_img(a.ghi, n, img + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (threadIdx.x == 0) s_taken = 0;
+    __syncthreads();
+    float gain = 0.f, padx = 0.f, pady = 0.f;
+    if (a.rescale) { gain = a.rescale[img * 3]; padx = a.rescale[img * 3 + 1]; pady = a.rescale[img * 3 + 2]; }
+    for (int c = begin; c < end; c += 256) {
+        const int taken = s_taken;
+        if (taken >= a.K) break;
+        const int r = c + threadIdx.x;
+        const bool k = r < end && a.keep[r] != 0;
+        const uint64_t m = __ballot(k);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = taken;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        const int rank = off + __popcll(m & lt);
+        if (k && rank < a.K) {
+            const uint64_t hi = a.ghi[r];
+            const uint32_t lo = a.glo[r];
+            const unsigned anchor = lo >> a.label_bits;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.boxes_all + ((int64_t)img * a.total_anchors + anchor) * 4);
+            f32x4 o = b;
+            if (gain > 0.f) {  // transform.py:362-365
+                o[0] = __fdiv_rn(__fsub_rn(b[0], padx), gain);
+                o[2] = __fdiv_rn(__fsub_rn(b[2], padx), gain);
+                o[1] = __fdiv_rn(__fsub_rn(b[1], pady), gain);
+                o[3] = __fdiv_rn(__fsub_rn(b[3], pady), gain);
+            }
+            const int64_t slot = (int64_t)img * a.K + rank;
+            *reinterpret_cast<f32x4*>(a.out_boxes + slot * 4) = o;
+            a.out_scores[slot] = __uint_as_float(~(uint32_t)hi);
+            a.out_labels[slot] = (int64_t)(lo & ((1u << a.label_bits) - 1u));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_taken = taken + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.out_count[img] = s_taken < a.K ? s_taken : a.K;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side orchestration
+// ------------------------------------------------------------------------------------------
+static int bits_for(int64_t v) {  // number of bits needed to represent values in [0, v)
+    int b = 0;
+    while (((int64_t)1 << b) < v) ++b;
+    return b;
+}
+
+struct SortState {
+    int cur;  // index of the array pair holding the current order
+};
+
+static int radix_pass(const Workspace& w, SortState& st, int* status, int cap, int shift, hipStream_t s) {
+    const int nblk = cdiv(cap, SORT_ITEMS);
+    const int src = st.cur, dst = st.cur ^ 1;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, s, w.hi[src], w.lo[src], status, cap, shift, w.hist);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(256), 0, s, status, cap, w.hist);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, s, w.hi[src], w.lo[src], w.hi[dst], w.lo[dst], status, cap, shift, w.hist);
+    st.cur = dst;
+    return check_launch("radix pass");
+}
+
+// sorts records in w.hi/lo[st.cur] by (img, score desc, cand asc), then runs NMS + gather.
+static int sort_nms_gather(const Workspace& w, SortState st, int* status, int cap, int n_img, int lo_bits, int label_bits, int total_anchors,
+                           float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count,
+                           hipStream_t s) {
+    int rc;
+    for (int sh = 0; sh < lo_bits; sh += 8) if ((rc = radix_pass(w, st, status, cap, sh, s)) != YMI_OK) return rc;
+    for (int sh = 32; sh < 64; sh += 8) if ((rc = radix_pass(w, st, status, cap, sh, s)) != YMI_OK) return rc;
+    const int img_bits = bits_for(n_img);
+    for (int sh = 64; sh < 64 + img_bits; sh += 8) if ((rc = radix_pass(w, st, status, cap, sh, s)) != YMI_OK) return rc;
+    // G = current arrays; P = the other pair, re-keyed by label
+    const int g = st.cur, p = st.cur ^ 1;
+    const int nthr_blocks = cdiv(cap, 256);
+    hipLaunchKernelGGL(make_label_records_kernel, dim3(nthr_blocks), dim3(256), 0, s, w.hi[g], w.lo[g], w.hi[p], w.lo[p], status, cap, label_bits, w.keep);
+    // The label passes ping-pong between P and a scratch pair; G must stay intact, so P's partner
+    // arrays are carved from seg_start/kept_box which are not live yet.
+    Workspace wl = w;
+    wl.hi[0] = w.hi[p];
+    wl.lo[0] = w.lo[p];
+    wl.hi[1] = reinterpret_cast<uint64_t*>(w.kept_box);        // cap * 16 bytes >= cap * 8
+    wl.lo[1] = w.seg_start;                                   // cap * 4 bytes
+    SortState sl{0};
+    int label_passes = 0;
+    for (int sh = 32; sh < 32 + label_bits; sh += 8) {
+        if ((rc = radix_pass(wl, sl, status, cap, sh, s)) != YMI_OK) return rc;
+        ++label_passes;
+    }
+    const uint64_t* phi = wl.hi[sl.cur];
+    const uint32_t* plo = wl.lo[sl.cur];
+    uint32_t* seg_start = w.seg_start;
+    float* kept_box = w.kept_box;
+    if (sl.cur == 1) {
+        // sorted P currently lives in the scratch (kept_box/seg_start): move it back to P's own arrays
+        YMI_CHECK_HIP(hipMemcpyAsync(w.hi[p], wl.hi[1], (size_t)cap * 8, hipMemcpyDeviceToDevice, s));
+        YMI_CHECK_HIP(hipMemcpyAsync(w.lo[p], wl.lo[1], (size_t)cap * 4, hipMemcpyDeviceToDevice, s));
+        phi = w.hi[p];
+        plo = w.lo[p];
+    }
+    (void)label_passes;
+    hipLaunchKernelGGL(find_segments_kernel, dim3(nthr_blocks), dim3(256), 0, s, phi, status, cap, seg_start);
+    hipLaunchKernelGGL(nms_segments_kernel, dim3(1024), dim3(256), 0, s, phi, plo, w.hi[g], w.lo[g], w.boxes_all, total_anchors, label_bits, status, cap,
+                       seg_start, kept_box, w.keep, nms_thresh);
+    GatherArgs ga;
+    ga.ghi = w.hi[g]; ga.glo = w.lo[g]; ga.keep = w.keep; ga.boxes_all = w.boxes_all; ga.rescale = rescale; ga.status = status;
+    ga.cap = cap; ga.total_anchors = total_anchors; ga.label_bits = label_bits; ga.K = K;
+    ga.out_boxes = out_boxes; ga.out_scores = out_scores; ga.out_labels = out_labels; ga.out_count = out_count;
+    hipLaunchKernelGGL(gather_topk_kernel, dim3(n_img), dim3(256), 0, s, ga);
+    return check_launch("nms/gather");
+}
+
+int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
+    YMI_REQUIRE(d != nullptr, "ymi_postprocess: null descriptor");
+    YMI_REQUIRE(d->num_levels >= 1 && d->num_levels <= YMI_MAX_LEVELS, "ymi_postprocess: num_levels %d out of range", d->num_levels);
+    YMI_REQUIRE(d->n >= 1 && d->n <= 65535, "ymi_postprocess: batch size %d out of range", d->n);
+    YMI_REQUIRE(d->num_classes >= 1 && d->num_classes <= 4096, "ymi_postprocess: num_classes %d out of range", d->num_classes);
+    YMI_REQUIRE(d->out_boxes && d->out_scores && d->out_labels && d->out_count && d->status && d->ws, "ymi_postprocess: null buffer");
+    YMI_REQUIRE(d->detections_per_img >= 1 && d->cand_cap >= 1, "ymi_postprocess: detections_per_img and cand_cap must be positive");
+    int total_anchors = 0;
+    for (int l = 0; l < d->num_levels; ++l) {
+        YMI_REQUIRE(d->logits[l] != nullptr, "ymi_postprocess: logits[%d] is null", l);
+        YMI_REQUIRE(d->lcstride[l] >= 3 * (d->num_classes + 5) && d->lcstride[l] % 4 == 0, "ymi_postprocess: lcstride[%d]=%d too small / not a multiple of 4", l, d->lcstride[l]);
+        total_anchors += 3 * d->lh[l] * d->lw[l];
+    }
+    const int label_bits = bits_for(d->num_classes) < 1 ? 1 : bits_for(d->num_classes);
+    const int anchor_bits = bits_for(total_anchors);
+    YMI_REQUIRE(label_bits + anchor_bits <= 32, "ymi_postprocess: %d anchors x %d classes exceed the 32-bit candidate index", total_anchors, d->num_classes);
+    const Workspace w = carve(d->ws, d->n, total_anchors, d->cand_cap);
+    YMI_REQUIRE(d->ws_bytes >= w.total, "ymi_postprocess: workspace too small (%lld < %lld)", (long long)d->ws_bytes, (long long)w.total);
+    YMI_CHECK_HIP(hipMemsetAsync(d->status, 0, 4 * sizeof(int), s));
+    YMI_CHECK_HIP(hipMemsetAsync(d->out_count, 0, (size_t)d->n * sizeof(int), s));
+    int level_off = 0;
+    for (int l = 0; l < d->num_levels; ++l) {
+        DecodeArgs a;
+        a.logits = d->logits[l]; a.h = d->lh[l]; a.w = d->lw[l]; a.cs = d->lcstride[l]; a.stride = d->stride[l];
+        for (int k = 0; k < 6; ++k) a.anc[k] = d->anchors[l][k];
+        a.n = d->n; a.K = d->num_classes + 5; a.level_off = level_off; a.total_anchors = total_anchors; a.label_bits = label_bits;
+        a.thr = d->score_thresh; a.boxes_all = w.boxes_all; a.hi = w.hi[0]; a.lo = w.lo[0]; a.status = d->status; a.cap = d->cand_cap;
+        const int64_t npix = (int64_t)d->n * a.h * a.w;
+        hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, a);
+        level_off += 3 * a.h * a.w;
+    }
+    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(64), 0, s, d->status, d->cand_cap);
+    int rc = check_launch("decode");
+    if (rc != YMI_OK) return rc;
+    return sort_nms_gather(w, SortState{0}, d->status, d->cand_cap, d->n, label_bits + anchor_bits, label_bits, total_anchors, d->nms_thresh,
+                           d->detections_per_img, d->rescale, d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);
+}
+
+// ---- stand-alone batched NMS (one image) -------------------------------------------------
+constexpr int NMS_LABEL_BITS = 12;
+
+__global__ __launch_bounds__(256) void nms_make_records_kernel(const float* boxes, const float* scores, const int* labels, int n, float* boxes_all,
+                                                               uint64_t* hi, uint32_t* lo, int* status) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { status[ST_NCAND] = n; status[ST_OVERFLOW] = 0; status[ST_NSEG] = 0; status[ST_RSV] = 0; }
+    if (i >= n) return;
+    *reinterpret_cast<f32x4*>(boxes_all + (int64_t)i * 4) = *reinterpret_cast<const f32x4*>(boxes + (int64_t)i * 4);
+    hi[i] = (uint64_t)(~__float_as_uint(scores[i]));
+    lo[i] = ((unsigned)i << NMS_LABEL_BITS) | ((unsigned)labels[i] & ((1u << NMS_LABEL_BITS) - 1u));
+}
+
+__global__ __launch_bounds__(256) void nms_emit_keep_kernel(const uint32_t* glo, const uint8_t* keep, int n, int* keep_out, int* count_out) {
+    // single block: ordered compaction of kept ranks -> original indices
+    __shared__ int wave_cnt[4];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c = 0; c < n; c += 256) {
+        const int r = c + threadIdx.x;
+        const bool k = r < n && keep[r] != 0;
+        const uint64_t m = __ballot(k);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (k) keep_out[off + __popcll(m & lt)] = (int)(glo[r] >> NMS_LABEL_BITS);
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = s_base;
+}
+
+}  // namespace ymi
+
+using namespace ymi;
+
+extern "C" int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_cap) {
+    if (n <= 0 || total_anchors <= 0 || cand_cap <= 0) return 0;
+    return carve(nullptr, n, total_anchors, cand_cap).total;
+}
+
+extern "C" int ymi_postprocess(const ymi_post_desc* d, void* stream) { return postprocess_launch(d, (hipStream_t)stream); }
+
+extern "C" int64_t ymi_nms_ws_bytes(int n) {
+    if (n <= 0) n = 1;
+    return carve(nullptr, 1, n, n).total + 256 /* status */ + 2 * 256;
+}
+
+extern "C" int ymi_batched_nms(const float* boxes, const float* scores, const int32_t* labels, int n, float nms_thresh, int32_t* keep_out,
+                               int32_t* count_out, void* ws, int64_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    YMI_REQUIRE(count_out && ws, "ymi_batched_nms: null buffer");
+    if (n == 0) {
+        YMI_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int), s));
+        return YMI_OK;
+    }
+    YMI_REQUIRE(boxes && scores && labels && keep_out, "ymi_batched_nms: null buffer");
+    YMI_REQUIRE(n > 0 && n < (1 << (32 - NMS_LABEL_BITS)), "ymi_batched_nms: n=%d out of range (max %d)", n, (1 << (32 - NMS_LABEL_BITS)) - 1);
+    YMI_REQUIRE(ws_bytes >= ymi_nms_ws_bytes(n), "ymi_batched_nms: workspace too small");
+    int* status = (int*)ws;
+    const Workspace w = carve((char*)ws + 256, 1, n, n);
+    hipLaunchKernelGGL(nms_make_records_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, boxes, scores, labels, n, w.boxes_all, w.hi[0], w.lo[0], status);
+    // dummy slab outputs for the shared pipeline: carve them after the workspace proper is not possible
+    // without more memory, so the stand-alone path skips gather and emits kept indices itself.
+    int rc;
+    SortState st{0};
+    const int lo_bits = NMS_LABEL_BITS + bits_for(n);
+    for (int sh = 0; sh < lo_bits; sh += 8) if ((rc = radix_pass(w, st, status, n, sh, s)) != YMI_OK) return rc;
+    for (int sh = 32; sh < 64; sh += 8) if ((rc = radix_pass(w, st, status, n, sh, s)) != YMI_OK) return rc;
+    const int g = st.cur, p = st.cur ^ 1;
+    hipLaunchKernelGGL(make_label_records_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w.hi[g], w.lo[g], w.hi[p], w.lo[p], status, n, NMS_LABEL_BITS, w.keep);
+    Workspace wl = w;
+    wl.hi[0] = w.hi[p]; wl.lo[0] = w.lo[p];
+    wl.hi[1] = reinterpret_cast<uint64_t*>(w.kept_box); wl.lo[1] = w.seg_start;
+    SortState sl{0};
+    for (int sh = 32; sh < 32 + NMS_LABEL_BITS; sh += 8) if ((rc = radix_pass(wl, sl, status, n, sh, s)) != YMI_OK) return rc;
+    const uint64_t* phi = wl.hi[sl.cur];
+    const uint32_t* plo = wl.lo[sl.cur];
+    if (sl.cur == 1) {
+        YMI_CHECK_HIP(hipMemcpyAsync(w.hi[p], wl.hi[1], (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        YMI_CHECK_HIP(hipMemcpyAsync(w.lo[p], wl.lo[1], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        phi = w.hi[p]; plo = w.lo[p];
+    }
+    hipLaunchKernelGGL(find_segments_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, phi, status, n, w.seg_start);
+    hipLaunchKernelGGL(nms_segments_kernel, dim3(256), dim3(256), 0, s, phi, plo, w.hi[g], w.lo[g], w.boxes_all, n, NMS_LABEL_BITS, status, n, w.seg_start,
+                       w.kept_box, w.keep, nms_thresh);
+    hipLaunchKernelGGL(nms_emit_keep_kernel, dim3(1), dim3(256), 0, s, w.lo[g], w.keep, n, keep_out, count_out);
+    return check_launch("ymi_batched_nms");
+}

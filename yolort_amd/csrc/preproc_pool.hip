@@ -1,0 +1,312 @@
+// HBM-bound helper kernels of the conv stack edges: letterbox, layout changes, SPP max-pool
+// pyramid, nearest x2 upsample and channel-slice copy.  All move 16 bytes per lane where the
+// layout allows (cdna_hip_programming.md G13) and are launched with >> 256 workgroups.
+#include "common.hpp"
+
+namespace ymi {
+
+// ---------------------------------------------------------------------------------------------
+// Letterbox.  Replaces yolort/models/transform.py:53-97 (bilinear resize; ATen
+// upsample_bilinear2d semantics: align_corners=False, scale recomputed as in/out, src clamped at
+// 0, x1 = min(x0+1, in-1), fp32 lerp) and transform.py:297-330 (fill + centred copy).
+// One thread per output pixel; up to LB_MAX images per launch (descriptors travel as kernargs so
+// there is no device-side pointer table to allocate).
+// ---------------------------------------------------------------------------------------------
+constexpr int LB_MAX = 32;
+struct LetterboxArgs {
+    const void* img[LB_MAX];
+    int geom[LB_MAX][6];  // h_in, w_in, h_res, w_res, pad_top, pad_left
+    void* out;
+    int n, hb, wb, c_out;
+    float fill;
+};
+
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void letterbox_kernel(const LetterboxArgs a) {
+    const int64_t npix = (int64_t)a.hb * a.wb;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix * a.n) return;
+    const int img = (int)(gid / npix);
+    const int rem = (int)(gid - (int64_t)img * npix);
+    const int y = rem / a.wb, x = rem - y * a.wb;
+    const int hin = a.geom[img][0], win = a.geom[img][1], hr = a.geom[img][2], wr = a.geom[img][3];
+    const int yy = y - a.geom[img][4], xx = x - a.geom[img][5];
+    float v[3] = {a.fill, a.fill, a.fill};
+    if ((unsigned)yy < (unsigned)hr && (unsigned)xx < (unsigned)wr) {
+        const float sy = (float)hin / (float)hr, sx = (float)win / (float)wr;
+        float fy = __fsub_rn(__fmul_rn(sy, (float)yy + 0.5f), 0.5f);
+        float fx = __fsub_rn(__fmul_rn(sx, (float)xx + 0.5f), 0.5f);
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = y0 > hin - 1 ? hin - 1 : y0;
+        x0 = x0 > win - 1 ? win - 1 : x0;
+        const int y1 = y0 + 1 > hin - 1 ? hin - 1 : y0 + 1;
+        const int x1 = x0 + 1 > win - 1 ? win - 1 : x0 + 1;
+        float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+        ly1 = ly1 < 0.f ? 0.f : (ly1 > 1.f ? 1.f : ly1);
+        lx1 = lx1 < 0.f ? 0.f : (lx1 > 1.f ? 1.f : lx1);
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const int64_t plane = (int64_t)hin * win;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t b = c * plane;
+            const float p00 = load_elem<IDT>(a.img[img], b + (int64_t)y0 * win + x0);
+            const float p01 = load_elem<IDT>(a.img[img], b + (int64_t)y0 * win + x1);
+            const float p10 = load_elem<IDT>(a.img[img], b + (int64_t)y1 * win + x0);
+            const float p11 = load_elem<IDT>(a.img[img], b + (int64_t)y1 * win + x1);
+            const float top = __fadd_rn(__fmul_rn(p00, lx0), __fmul_rn(p01, lx1));
+            const float bot = __fadd_rn(__fmul_rn(p10, lx0), __fmul_rn(p11, lx1));
+            v[c] = __fadd_rn(__fmul_rn(top, ly0), __fmul_rn(bot, ly1));
+        }
+    }
+    if constexpr (ODT == YMI_F32) {
+        float* o = (float*)a.out + gid * a.c_out;
+        for (int c = 0; c < a.c_out; ++c) o[c] = c < 3 ? v[c] : 0.f;
+    } else {
+        uint16_t* o = (uint16_t*)a.out + gid * a.c_out;
+        u32x2 w01;
+        w01[0] = (uint32_t)to16<ODT>(v[0]) | ((uint32_t)to16<ODT>(v[1]) << 16);
+        w01[1] = (uint32_t)to16<ODT>(v[2]);
+        if (a.c_out == 4) {
+            *reinterpret_cast<u32x2*>(o) = w01;
+        } else if (a.c_out == 8) {
+            u32x4 w = {w01[0], w01[1], 0u, 0u};
+            *reinterpret_cast<u32x4*>(o) = w;
+        } else {
+            for (int c = 0; c < a.c_out; ++c) o[c] = c < 3 ? to16<ODT>(v[c]) : (uint16_t)0;
+        }
+    }
+}
+
+template <int IDT>
+static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t s) {
+    const int64_t total = (int64_t)a.n * a.hb * a.wb;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (out_dtype) {
+        case YMI_F16: hipLaunchKernelGGL((letterbox_kernel<IDT, YMI_F16>), grid, block, 0, s, a); break;
+        case YMI_BF16: hipLaunchKernelGGL((letterbox_kernel<IDT, YMI_BF16>), grid, block, 0, s, a); break;
+        case YMI_F32: hipLaunchKernelGGL((letterbox_kernel<IDT, YMI_F32>), grid, block, 0, s, a); break;
+        default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
+    }
+    return check_launch("letterbox_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW <-> NHWC (module-level API edges only)
+// ---------------------------------------------------------------------------------------------
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const void* x, int n, int c, int h, int w, void* y, int y_cs, int c_pad) {
+    const int64_t npix = (int64_t)n * h * w;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix) return;
+    const int64_t hw = (int64_t)h * w;
+    const int img = (int)(gid / hw);
+    const int64_t p = gid - img * hw;
+    for (int ch = 0; ch < c_pad; ++ch) {
+        const float v = ch < c ? load_elem<IDT>(x, ((int64_t)img * c + ch) * hw + p) : 0.f;
+        if constexpr (ODT == YMI_F32) ((float*)y)[gid * y_cs + ch] = v;
+        else ((uint16_t*)y)[gid * y_cs + ch] = to16<ODT>(v);
+    }
+}
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* x, int x_cs, int n, int c, int h, int w, void* y) {
+    const int64_t total = (int64_t)n * c * h * w;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int64_t hw = (int64_t)h * w;
+    const int64_t p = gid % hw;
+    const int64_t t = gid / hw;
+    const int ch = (int)(t % c);
+    const int img = (int)(t / c);
+    const float v = load_elem<IDT>(x, ((int64_t)img * hw + p) * x_cs + ch);
+    if constexpr (ODT == YMI_F32) ((float*)y)[gid] = v;
+    else ((uint16_t*)y)[gid] = to16<ODT>(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SPP pyramid: pool5/9/13 (stride 1, same, -inf pad) of channels [0,c) -> slices 1..3.
+// max is exact, so one pass over the 13x13 window carrying three running maxima equals the
+// reference's three MaxPool2d calls (common.py:183) bit for bit.  8 channels (16 B) per thread.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void spp_pool_kernel(uint16_t* buf, int n, int h, int w, int c, int cs) {
+    const int c8 = c / 8;
+    const int64_t total = (int64_t)n * h * w * c8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cc = (int)(gid % c8) * 8;
+    const int64_t pix = gid / c8;
+    const int x = (int)(pix % w);
+    const int y = (int)((pix / w) % h);
+    const int img = (int)(pix / ((int64_t)w * h));
+    float m5[8], m9[8], m13[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m5[e] = m9[e] = m13[e] = -INFINITY;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)h) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)w) continue;
+            const int adx = dx < 0 ? -dx : dx;
+            const int r = ady > adx ? ady : adx;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(buf + ((int64_t)(img * h + yy) * w + xx) * cs + cc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = from16<DT>((uint16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+                m13[e] = fmaxf(m13[e], f);
+                if (r <= 4) m9[e] = fmaxf(m9[e], f);
+                if (r <= 2) m5[e] = fmaxf(m5[e], f);
+            }
+        }
+    }
+    uint16_t* o = buf + pix * cs + cc;
+    u32x4 o5, o9, o13;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o5[e] = (uint32_t)to16<DT>(m5[2 * e]) | ((uint32_t)to16<DT>(m5[2 * e + 1]) << 16);
+        o9[e] = (uint32_t)to16<DT>(m9[2 * e]) | ((uint32_t)to16<DT>(m9[2 * e + 1]) << 16);
+        o13[e] = (uint32_t)to16<DT>(m13[2 * e]) | ((uint32_t)to16<DT>(m13[2 * e + 1]) << 16);
+    }
+    *reinterpret_cast<u32x4*>(o + c) = o5;
+    *reinterpret_cast<u32x4*>(o + 2 * c) = o9;
+    *reinterpret_cast<u32x4*>(o + 3 * c) = o13;
+}
+
+// nearest x2 upsample: one thread per (input pixel, 8 channels) -> 4 output pixels
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* x, int x_cs, int n, int h, int w, int c, uint16_t* y, int y_cs) {
+    const int c8 = c / 8;
+    const int64_t total = (int64_t)n * h * w * c8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cc = (int)(gid % c8) * 8;
+    const int64_t pix = gid / c8;
+    const int xx = (int)(pix % w);
+    const int yy = (int)((pix / w) % h);
+    const int img = (int)(pix / ((int64_t)w * h));
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + pix * x_cs + cc);
+    const int w2 = 2 * w;
+    uint16_t* o = y + ((int64_t)(img * 2 * h + 2 * yy) * w2 + 2 * xx) * y_cs + cc;
+    *reinterpret_cast<u32x4*>(o) = v;
+    *reinterpret_cast<u32x4*>(o + y_cs) = v;
+    *reinterpret_cast<u32x4*>(o + (int64_t)w2 * y_cs) = v;
+    *reinterpret_cast<u32x4*>(o + (int64_t)w2 * y_cs + y_cs) = v;
+}
+
+__global__ __launch_bounds__(256) void copy_view_kernel(const uint16_t* x, int x_cs, int64_t npix, int c, uint16_t* y, int y_cs) {
+    const int c8 = c / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix * c8) return;
+    const int cc = (int)(gid % c8) * 8;
+    const int64_t pix = gid / c8;
+    *reinterpret_cast<u32x4*>(y + pix * y_cs + cc) = *reinterpret_cast<const u32x4*>(x + pix * x_cs + cc);
+}
+
+}  // namespace ymi
+
+using namespace ymi;
+
+extern "C" int ymi_letterbox(const void* const* imgs, const int32_t* geom, int n, int in_dtype, void* out, int hb, int wb,
+                             int c_out, int out_dtype, float fill, void* stream) {
+    YMI_REQUIRE(imgs && geom && out && n >= 0, "ymi_letterbox: null argument");
+    YMI_REQUIRE(c_out >= 3, "ymi_letterbox: c_out must be >= 3");
+    const size_t esz = out_dtype == YMI_F32 ? 4 : 2;
+    for (int base = 0; base < n; base += LB_MAX) {
+        LetterboxArgs a;
+        a.n = (n - base) < LB_MAX ? (n - base) : LB_MAX;
+        for (int i = 0; i < a.n; ++i) {
+            a.img[i] = imgs[base + i];
+            for (int k = 0; k < 6; ++k) a.geom[i][k] = geom[(base + i) * 6 + k];
+            YMI_REQUIRE(a.geom[i][2] + a.geom[i][4] <= hb && a.geom[i][3] + a.geom[i][5] <= wb && a.geom[i][4] >= 0 && a.geom[i][5] >= 0,
+                        "ymi_letterbox: image %d (%dx%d at %d,%d) does not fit the %dx%d canvas", base + i, a.geom[i][2], a.geom[i][3], a.geom[i][4], a.geom[i][5], hb, wb);
+        }
+        a.out = (char*)out + (size_t)base * hb * wb * c_out * esz;
+        a.hb = hb; a.wb = wb; a.c_out = c_out; a.fill = fill;
+        int rc;
+        switch (in_dtype) {
+            case YMI_F32: rc = letterbox_dispatch<YMI_F32>(a, out_dtype, (hipStream_t)stream); break;
+            case YMI_F16: rc = letterbox_dispatch<YMI_F16>(a, out_dtype, (hipStream_t)stream); break;
+            case YMI_BF16: rc = letterbox_dispatch<YMI_BF16>(a, out_dtype, (hipStream_t)stream); break;
+            case YMI_U8: rc = letterbox_dispatch<YMI_U8>(a, out_dtype, (hipStream_t)stream); break;
+            default: set_error("ymi_letterbox: bad in_dtype %d", in_dtype); return YMI_EINVAL;
+        }
+        if (rc != YMI_OK) return rc;
+    }
+    return YMI_OK;
+}
+
+#define YMI_DISPATCH_IO(KERNEL, IDT_V, ODT_V, ...)                                                          \
+    do {                                                                                                    \
+        bool _done = false;                                                                                 \
+        auto _try = [&](auto idt, auto odt) {                                                               \
+            if (!_done && IDT_V == decltype(idt)::value && ODT_V == decltype(odt)::value) {                 \
+                hipLaunchKernelGGL((KERNEL<decltype(idt)::value, decltype(odt)::value>), grid, block, 0, s, __VA_ARGS__); \
+                _done = true;                                                                               \
+            }                                                                                               \
+        };                                                                                                  \
+        _try(std::integral_constant<int, YMI_F32>{}, std::integral_constant<int, YMI_F16>{});               \
+        _try(std::integral_constant<int, YMI_F32>{}, std::integral_constant<int, YMI_BF16>{});              \
+        _try(std::integral_constant<int, YMI_F32>{}, std::integral_constant<int, YMI_F32>{});               \
+        _try(std::integral_constant<int, YMI_F16>{}, std::integral_constant<int, YMI_F16>{});               \
+        _try(std::integral_constant<int, YMI_F16>{}, std::integral_constant<int, YMI_F32>{});               \
+        _try(std::integral_constant<int, YMI_BF16>{}, std::integral_constant<int, YMI_BF16>{});             \
+        _try(std::integral_constant<int, YMI_BF16>{}, std::integral_constant<int, YMI_F32>{});              \
+        if (!_done) { set_error("unsupported dtype pair %d -> %d", IDT_V, ODT_V); return YMI_EINVAL; }      \
+    } while (0)
+
+#include <type_traits>
+
+extern "C" int ymi_nchw_to_nhwc(const void* x, int n, int c, int h, int w, int in_dtype, void* y, int y_cstride, int c_pad,
+                                int out_dtype, void* stream) {
+    YMI_REQUIRE(x && y && c_pad >= c && y_cstride >= c_pad, "ymi_nchw_to_nhwc: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t npix = (int64_t)n * h * w;
+    if (npix == 0) return YMI_OK;
+    dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+    YMI_DISPATCH_IO(nchw_to_nhwc_kernel, in_dtype, out_dtype, x, n, c, h, w, y, y_cstride, c_pad);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int ymi_nhwc_to_nchw(const void* x, int x_cstride, int n, int c, int h, int w, int in_dtype, void* y, int out_dtype,
+                                void* stream) {
+    YMI_REQUIRE(x && y && x_cstride >= c, "ymi_nhwc_to_nchw: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)n * c * h * w;
+    if (total == 0) return YMI_OK;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    YMI_DISPATCH_IO(nhwc_to_nchw_kernel, in_dtype, out_dtype, x, x_cstride, n, c, h, w, y);
+    return check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, int dtype, void* stream) {
+    YMI_REQUIRE(buf && c % 8 == 0 && cstride >= 4 * c && cstride % 8 == 0, "ymi_spp_pool: c %% 8 == 0 and cstride >= 4c required");
+    const int64_t total = (int64_t)n * h * w * (c / 8);
+    if (total == 0) return YMI_OK;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dtype == YMI_F16) hipLaunchKernelGGL((spp_pool_kernel<YMI_F16>), grid, block, 0, (hipStream_t)stream, (uint16_t*)buf, n, h, w, c, cstride);
+    else if (dtype == YMI_BF16) hipLaunchKernelGGL((spp_pool_kernel<YMI_BF16>), grid, block, 0, (hipStream_t)stream, (uint16_t*)buf, n, h, w, c, cstride);
+    else { set_error("ymi_spp_pool: dtype must be F16/BF16"); return YMI_EINVAL; }
+    return check_launch("spp_pool_kernel");
+}
+
+extern "C" int ymi_upsample2x(const void* x, int x_cstride, int n, int h, int w, int c, void* y, int y_cstride, int dtype, void* stream) {
+    YMI_REQUIRE(x && y && c % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0, "ymi_upsample2x: channels/strides must be multiples of 8");
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_upsample2x: dtype must be F16/BF16");
+    const int64_t total = (int64_t)n * h * w * (c / 8);
+    if (total == 0) return YMI_OK;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipLaunchKernelGGL(upsample2x_kernel, grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, x_cstride, n, h, w, c, (uint16_t*)y, y_cstride);
+    return check_launch("upsample2x_kernel");
+}
+
+extern "C" int ymi_copy_view(const void* x, int x_cstride, int npix, int c, void* y, int y_cstride, int dtype, void* stream) {
+    YMI_REQUIRE(x && y && c % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0, "ymi_copy_view: channels/strides must be multiples of 8");
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_copy_view: dtype must be F16/BF16");
+    const int64_t total = (int64_t)npix * (c / 8);
+    if (total == 0) return YMI_OK;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipLaunchKernelGGL(copy_view_kernel, grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, x_cstride, (int64_t)npix, c, (uint16_t*)y, y_cstride);
+    return check_launch("copy_view_kernel");
+}

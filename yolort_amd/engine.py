@@ -1,0 +1,273 @@
+"""Plan builder / executor: turns a module tree into a recorded sequence of HIP launches.
+
+The reference dispatches one ATen op per Python call (yolort/models/yolo.py:159-175 walks
+backbone -> head -> anchor_generator -> post_process module by module).  Here every module only
+*emits* its launches once into a C-side plan (`ymi_plan`, include/yolort_amd.h) for a given
+(shape, dtype); a forward is then a single `ymi_plan_run`, optionally a hipGraph replay.
+
+Activations are NHWC views into plan-owned torch buffers; a view may be a channel slice of a wider
+buffer (`cstride > c`), which is how every `torch.cat` of the reference (common.py:173,187,
+path_aggregation_network.py:224,235) disappears: producers write straight into their slot.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_SILU, ConvDesc, PostDesc, YmiError, check, dtype_code
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class View:
+    """NHWC activation view inside a flat torch buffer."""
+
+    base: Tensor  # flat storage tensor (kept alive by the plan)
+    off: int      # element offset of channel 0 of pixel 0
+    n: int
+    h: int
+    w: int
+    c: int
+    cs: int       # pixel stride in elements (>= c)
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.base.dtype
+
+    @property
+    def ptr(self) -> int:
+        return self.base.data_ptr() + self.off * self.base.element_size()
+
+    def slice_c(self, c0: int, c: int) -> "View":
+        assert 0 <= c0 and c0 + c <= self.c
+        return View(self.base, self.off + c0, self.n, self.h, self.w, c, self.cs)
+
+    def as_tensor(self) -> Tensor:
+        """(n,h,w,c) strided torch view of the data (debug / tests / API edges)."""
+        return torch.as_strided(self.base, (self.n, self.h, self.w, self.c), (self.h * self.w * self.cs, self.w * self.cs, self.cs, 1), self.off)
+
+
+class PackedConv:
+    """Weights of one convolution, BatchNorm folded, packed [cout_pad][k_pad] K-major for the
+    implicit-GEMM kernel (k = (ky*kw + kx)*cin + c), plus fp32 bias.
+
+    BN folding follows yolort/v5/utils/torch_utils.py:238-245: w' = w * g/sqrt(var+eps),
+    b' = beta - mean * g/sqrt(var+eps)  (eps = 1e-3, darknetv6.py:110-112).
+    """
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor], bn: Optional[Tuple[Tensor, Tensor, Tensor, Tensor, float]],
+                 dtype: torch.dtype, device: torch.device, cin_pad: Optional[int] = None, stem_superpixel: bool = False):
+        w = weight.detach().to(device=device, dtype=torch.float32)
+        cout, cin, kh, kw = w.shape
+        b = torch.zeros(cout, device=device, dtype=torch.float32) if bias is None else bias.detach().to(device=device, dtype=torch.float32)
+        if bn is not None:
+            g, beta, mean, var, eps = bn
+            scale = g.detach().to(device=device, dtype=torch.float32) / torch.sqrt(var.detach().to(device=device, dtype=torch.float32) + eps)
+            w = w * scale.view(-1, 1, 1, 1)
+            b = beta.detach().to(device=device, dtype=torch.float32) + (b - mean.detach().to(device=device, dtype=torch.float32)) * scale
+        self.stem_superpixel = stem_superpixel
+        if stem_superpixel:
+            # 6x6 s2 p2 conv over an NHWC4 image == 6x3 s(2,1) p(2,1) conv over (W/2) "super-pixels"
+            # of 8 channels (2 pixels x RGB0): tap kx of pixel 2*ox-2+kx -> super-pixel kx//2, parity kx%2.
+            assert cin == 3 and kw % 2 == 0
+            w4 = torch.zeros(cout, kh, kw // 2, 2, 4, device=device, dtype=torch.float32)
+            w4[..., :3] = w.permute(0, 2, 3, 1).reshape(cout, kh, kw // 2, 2, 3)
+            wk = w4.reshape(cout, kh * (kw // 2) * 8)
+            self.kh, self.kw, self.cin = kh, kw // 2, 8
+        else:
+            cp = cin if cin_pad is None else cin_pad
+            if cp % 8 != 0 or cp < cin:
+                raise YmiError(f"conv input channels {cin} (view {cp}) must be padded to a multiple of 8")
+            wp = torch.zeros(cout, kh, kw, cp, device=device, dtype=torch.float32)
+            wp[..., :cin] = w.permute(0, 2, 3, 1)
+            wk = wp.reshape(cout, kh * kw * cp)
+            self.kh, self.kw, self.cin = kh, kw, cp
+        self.cout = cout
+        self.k_real = cin * kh * kw  # algorithmic K (roofline accounting ignores zero padding)
+        self.cout_pad = _round_up(cout, 32)
+        self.k = wk.shape[1]
+        self.k_pad = _round_up(self.k, 32)
+        packed = torch.zeros(self.cout_pad, self.k_pad, device=device, dtype=torch.float32)
+        packed[:cout, : self.k] = wk
+        self.w = packed.to(dtype).contiguous()
+        self.bias = torch.zeros(self.cout_pad, device=device, dtype=torch.float32)
+        self.bias[:cout] = b
+        self.dtype = dtype
+        self._ktabs: Dict[Tuple[int, int], Tensor] = {}
+
+    def ktab(self, w_in: int, x_cs: int) -> Tensor:
+        key = (w_in, x_cs)
+        t = self._ktabs.get(key)
+        if t is None:
+            lib = _lib.load()
+            host = (C.c_int32 * (self.k_pad // 8 * 2))()
+            check(lib.ymi_conv_build_ktab(self.cin, self.kh, self.kw, w_in, x_cs, self.k_pad, host), "ymi_conv_build_ktab")
+            t = torch.tensor(list(host), dtype=torch.int32).to(self.w.device)
+            self._ktabs[key] = t
+        return t
+
+
+def conv_out_hw(h: int, w: int, k: Tuple[int, int], s: Tuple[int, int], p: Tuple[int, int]) -> Tuple[int, int]:
+    return (h + 2 * p[0] - k[0]) // s[0] + 1, (w + 2 * p[1] - k[1]) // s[1] + 1
+
+
+class Plan:
+    """Owns the C plan, the activation buffers and everything the recorded pointers refer to."""
+
+    def __init__(self, device: torch.device, dtype: torch.dtype):
+        self.lib = _lib.load(require_gpu=True)
+        if device.type != "cuda":
+            raise YmiError(f"yolort_amd plans run on an MI355X only (got device {device}); there is no CPU fallback")
+        self.device, self.dtype = device, dtype
+        self.handle = C.c_void_p(self.lib.ymi_plan_create())
+        if not self.handle:
+            raise YmiError("ymi_plan_create failed")
+        self.keep: List[object] = []      # tensors / descriptors referenced by the C plan
+        self.names: List[str] = []
+        self.meta: List[dict] = []        # per-op algorithmic flops/bytes for roofline accounting
+        self.bytes_allocated = 0
+        self.stream: Optional[torch.cuda.Stream] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ymi_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- buffers ----
+    def alloc(self, n: int, h: int, w: int, c: int, dtype: Optional[torch.dtype] = None, zero: bool = False) -> View:
+        dt = dtype or self.dtype
+        numel = n * h * w * c
+        t = (torch.zeros if zero else torch.empty)(max(numel, 1), device=self.device, dtype=dt)
+        self.keep.append(t)
+        self.bytes_allocated += t.numel() * t.element_size()
+        return View(t, 0, n, h, w, c, c)
+
+    def _record(self, idx: int, name: str, **meta) -> None:
+        check(idx, name)
+        self.names.append(name)
+        self.meta.append(meta)
+
+    # ---- ops ----
+    def conv_desc(self, x: View, pc: PackedConv, stride: Tuple[int, int], pad: Tuple[int, int], act: int, y: View, res: Optional[View], tile: int = 0) -> ConvDesc:
+        d = ConvDesc()
+        d.x, d.w, d.bias = x.ptr, pc.w.data_ptr(), pc.bias.data_ptr()
+        is1x1 = pc.kh == 1 and pc.kw == 1 and stride == (1, 1) and pad == (0, 0)
+        kt = None if is1x1 else pc.ktab(x.w, x.cs)
+        d.ktab = None if kt is None else kt.data_ptr()
+        d.y = y.ptr
+        d.res = None if res is None else res.ptr
+        d.n, d.h, d.w_in, d.cin, d.x_cstride = x.n, x.h, x.w, pc.cin, x.cs
+        d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = y.h, y.w, pc.cout, pc.cout_pad, y.cs
+        d.res_cstride = 0 if res is None else res.cs
+        d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = pc.kh, pc.kw, stride[0], stride[1], pad[0], pad[1], pc.k_pad
+        d.act, d.dtype, d.out_dtype, d.tile = act, dtype_code(pc.dtype), dtype_code(y.dtype), tile
+        self.keep.extend([pc, kt, d])
+        return d
+
+    def conv(self, x: View, pc: PackedConv, stride: int | Tuple[int, int] = 1, pad: int | Tuple[int, int] = 0, act: int = ACT_SILU,
+             out: Optional[View] = None, res: Optional[View] = None, out_dtype: Optional[torch.dtype] = None, name: str = "conv", tile: int = 0) -> View:
+        s = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        p = (pad, pad) if isinstance(pad, int) else tuple(pad)
+        if pc.stem_superpixel:
+            if x.c != 4 or x.cs != 4 or x.w % 2:
+                raise YmiError("stem super-pixel conv needs a dense NHWC4 input with even width")
+            x = View(x.base, x.off, x.n, x.h, x.w // 2, 8, 8)
+            s, p = (s[0], 1), (p[0], 1)
+        if x.c != pc.cin:
+            raise YmiError(f"{name}: input view has {x.c} channels, packed weights expect {pc.cin}")
+        ho, wo = conv_out_hw(x.h, x.w, (pc.kh, pc.kw), s, p)
+        if out is None:
+            cpad = _round_up(pc.cout, 8)
+            out = self.alloc(x.n, ho, wo, cpad, out_dtype, zero=cpad != pc.cout).slice_c(0, pc.cout) if cpad != pc.cout else self.alloc(x.n, ho, wo, pc.cout, out_dtype)
+        if (out.n, out.h, out.w, out.c) != (x.n, ho, wo, pc.cout):
+            raise YmiError(f"{name}: output view {(out.n, out.h, out.w, out.c)} != expected {(x.n, ho, wo, pc.cout)}")
+        d = self.conv_desc(x, pc, s, p, act, out, res, tile)
+        esz = 2
+        flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
+        self._record(self.lib.ymi_plan_add_conv(self.handle, C.byref(d)), name, kind="conv",
+                     flops=flops, bytes=float(x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz),
+                     shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
+        return out
+
+    def spp_pool(self, buf: View, c: int, name: str = "spp_pool") -> None:
+        assert buf.c == 4 * c
+        self._record(self.lib.ymi_plan_add_spp_pool(self.handle, buf.ptr, buf.n, buf.h, buf.w, c, buf.cs, dtype_code(buf.dtype)), name,
+                     kind="pool", flops=0.0, bytes=float(buf.n * buf.h * buf.w * c * 2 * 4), shape=f"c{c} {buf.h}x{buf.w}")
+
+    def upsample2x(self, x: View, out: View, name: str = "upsample2x") -> View:
+        assert (out.n, out.h, out.w, out.c) == (x.n, 2 * x.h, 2 * x.w, x.c)
+        self._record(self.lib.ymi_plan_add_upsample2x(self.handle, x.ptr, x.cs, x.n, x.h, x.w, x.c, out.ptr, out.cs, dtype_code(x.dtype)), name,
+                     kind="upsample", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * 2 * 5), shape=f"c{x.c} {x.h}x{x.w}")
+        return out
+
+    def copy(self, x: View, out: View, name: str = "copy") -> View:
+        assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, x.c)
+        self._record(self.lib.ymi_plan_add_copy_view(self.handle, x.ptr, x.cs, x.n * x.h * x.w, x.c, out.ptr, out.cs, dtype_code(x.dtype)), name,
+                     kind="copy", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * 2 * 2), shape=f"c{x.c} {x.h}x{x.w}")
+        return out
+
+    def postprocess(self, logits: Sequence[View], strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
+                    score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None) -> "PostBuffers":
+        n = logits[0].n
+        total_anchors = sum(3 * v.h * v.w for v in logits)
+        pb = PostBuffers(self, n, detections_per_img, total_anchors, cand_cap, rescale)
+        d = PostDesc()
+        for i, v in enumerate(logits):
+            if v.dtype != torch.float32:
+                raise YmiError("post-process expects fp32 head logits")
+            d.logits[i] = v.ptr
+            d.lh[i], d.lw[i], d.lcstride[i] = v.h, v.w, v.cs
+            d.stride[i] = float(strides[i])
+            for k in range(6):
+                d.anchors[i][k] = float(anchors[i][k])
+        d.num_levels, d.n, d.num_classes = len(logits), n, num_classes
+        d.score_thresh, d.nms_thresh, d.detections_per_img = score_thresh, nms_thresh, detections_per_img
+        d.rescale = None if pb.rescale is None else pb.rescale.data_ptr()
+        d.out_boxes, d.out_scores, d.out_labels, d.out_count = pb.boxes.data_ptr(), pb.scores.data_ptr(), pb.labels.data_ptr(), pb.count.data_ptr()
+        d.status = pb.status.data_ptr()
+        d.ws, d.ws_bytes, d.cand_cap = pb.ws.data_ptr(), pb.ws.numel(), cand_cap
+        self.keep.extend([pb, d])
+        self._record(self.lib.ymi_plan_add_postprocess(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0,
+                     bytes=float(sum(v.n * v.h * v.w * 3 * (num_classes + 5) * 4 for v in logits)), shape=f"A={total_anchors}")
+        return pb
+
+    # ---- execution ----
+    @property
+    def num_ops(self) -> int:
+        return self.lib.ymi_plan_num_ops(self.handle)
+
+    def run(self, first: int = 0, last: int = -1, graph: bool = False, stream: Optional[torch.cuda.Stream] = None) -> None:
+        check(self.lib.ymi_plan_run(self.handle, first, last, 1 if graph else 0, _lib.stream_ptr(stream)), "ymi_plan_run")
+
+    def profile(self, iters: int = 5) -> List[Tuple[str, float, dict]]:
+        ms = (C.c_float * self.num_ops)()
+        check(self.lib.ymi_plan_profile(self.handle, iters, ms, _lib.stream_ptr()), "ymi_plan_profile")
+        return [(self.names[i], float(ms[i]), self.meta[i]) for i in range(self.num_ops)]
+
+
+class PostBuffers:
+    """Fixed-shape detection slab + workspace of one post-process op."""
+
+    def __init__(self, plan: Plan, n: int, k: int, total_anchors: int, cand_cap: int, rescale: Optional[Tensor]):
+        dev = plan.device
+        self.n, self.k, self.cand_cap = n, k, cand_cap
+        self.boxes = torch.zeros(n, k, 4, device=dev, dtype=torch.float32)
+        self.scores = torch.zeros(n, k, device=dev, dtype=torch.float32)
+        self.labels = torch.zeros(n, k, device=dev, dtype=torch.int64)
+        self.count = torch.zeros(n, device=dev, dtype=torch.int32)
+        self.status = torch.zeros(4, device=dev, dtype=torch.int32)
+        self.rescale = rescale
+        nbytes = plan.lib.ymi_postprocess_ws_bytes(n, total_anchors, cand_cap)
+        self.ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        plan.bytes_allocated += nbytes

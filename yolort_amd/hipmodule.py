@@ -1,0 +1,108 @@
+"""Base class of every graph piece: parameters live in ordinary torch containers (so state_dict
+keys match the reference's checkpoints), compute is emitted into a HIP plan (engine.Plan).
+
+`forward` of any such module accepts the reference's NCHW tensors, converts at the edge, runs the
+module's own plan on the MI355X and converts back -- that is how the reference's per-block shape
+tests (test/test_v5_common.py, test/test_models.py:188-274) run against this package.  There is no
+eager/CPU implementation: off-GPU `forward` raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from ._lib import YmiError, check, dtype_code
+from .engine import Plan, View
+
+
+def compute_dtype_of(module: nn.Module) -> torch.dtype:
+    """fp16/bf16 models compute in their own dtype; fp32-parameter models compute in
+    `module.compute_dtype` (default fp16) with fp32 accumulation -- the engine has no fp32 MFMA path."""
+    p = next(module.parameters(), None)
+    if p is not None and p.dtype in (torch.float16, torch.bfloat16):
+        return p.dtype
+    return getattr(module, "compute_dtype", torch.float16)
+
+
+def weights_signature(module: nn.Module) -> Tuple:
+    sig = 0
+    ptr = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        sig += t._version
+        ptr ^= t.data_ptr()
+    return (sig, ptr)
+
+
+def nchw_to_view(plan_or_none: Optional[Plan], x: Tensor, c_pad: int, out: Optional[View] = None, dtype: Optional[torch.dtype] = None) -> View:
+    lib = _lib.load(require_gpu=True)
+    n, c, h, w = x.shape
+    x = x.contiguous()
+    if out is None:
+        t = torch.zeros(n * h * w * c_pad, device=x.device, dtype=dtype or x.dtype)
+        out = View(t, 0, n, h, w, c_pad, c_pad)
+    check(lib.ymi_nchw_to_nhwc(x.data_ptr(), n, c, h, w, dtype_code(x.dtype), out.ptr, out.cs, c_pad, dtype_code(out.dtype), _lib.stream_ptr()), "ymi_nchw_to_nhwc")
+    return out
+
+
+def view_to_nchw(v: View, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    lib = _lib.load(require_gpu=True)
+    y = torch.empty(v.n, v.c, v.h, v.w, device=v.base.device, dtype=out_dtype or v.dtype)
+    check(lib.ymi_nhwc_to_nchw(v.ptr, v.cs, v.n, v.c, v.h, v.w, dtype_code(v.dtype), y.data_ptr(), dtype_code(y.dtype), _lib.stream_ptr()), "ymi_nhwc_to_nchw")
+    return y
+
+
+class HipModule(nn.Module):
+    """nn.Module whose forward is a cached HIP plan of its own `emit`."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._plans: Dict[Tuple, Tuple] = {}
+
+    def _input_cpad(self, c: int) -> int:
+        """channel padding of the NHWC input view built at the NCHW API edge"""
+        return (c + 7) // 8 * 8
+
+    # subclasses implement: emit(plan, x: View | List[View], out=None) -> View | List[View]
+    def emit(self, plan: Plan, x, out=None):  # pragma: no cover
+        raise NotImplementedError
+
+    def _inputs_as_list(self, x) -> Tuple[List[Tensor], bool]:
+        if isinstance(x, Tensor):
+            return [x], False
+        if isinstance(x, dict):
+            return list(x.values()), True
+        return list(x), True
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("yolort_amd implements the inference path only; call .eval() (training is out of scope)")
+        xs, is_list = self._inputs_as_list(x)
+        for t in xs:
+            if not t.is_cuda:
+                raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
+            if t.dim() != 4:
+                raise ValueError(f"expected NCHW tensors, got shape {tuple(t.shape)}")
+        cdt = compute_dtype_of(self)
+        key = (tuple(tuple(t.shape) for t in xs), cdt, xs[0].device.index, weights_signature(self))
+        entry = self._plans.get(key)
+        if entry is None:
+            self._plans.clear()
+            plan = Plan(xs[0].device, cdt)
+            ins = []
+            for t in xs:
+                c_pad = self._input_cpad(t.shape[1])
+                ins.append(plan.alloc(t.shape[0], t.shape[2], t.shape[3], c_pad, zero=True))
+            outs = self.emit(plan, ins if is_list else ins[0])
+            entry = (plan, ins, outs)
+            self._plans[key] = entry
+        plan, ins, outs = entry
+        for t, v in zip(xs, ins):
+            nchw_to_view(plan, t, v.c, out=v)
+        plan.run()
+        odt = xs[0].dtype if xs[0].dtype.is_floating_point else torch.float32
+        if isinstance(outs, View):
+            return view_to_nchw(outs, odt)
+        return [view_to_nchw(o, odt) for o in outs]

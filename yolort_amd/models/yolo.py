@@ -1,0 +1,206 @@
+"""YOLO core model and the architecture table (reference yolort/models/yolo.py).
+
+`YOLO.forward` has the reference's signature and return type (List[Dict] with keys scores / labels
+/ boxes, yolo.py:141-183) but executes as one recorded HIP plan:
+  NHWC4 batch -> CSPDarknet + PAN (fused conv kernels) -> head (fp32 logits) -> decode + NMS slab.
+Constructor injection points (yolo.py:65-81) are honoured: custom `head`, `anchor_generator` or
+`post_process` modules are called with the reference's tensor conventions on top of the HIP backbone.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .._lib import YmiError
+from ..engine import Plan, View
+from ..hipmodule import compute_dtype_of, nchw_to_view, view_to_nchw, weights_signature
+from ..ops import slab_to_list
+from .anchor_utils import AnchorGenerator
+from .backbone_utils import darknet_pan_backbone
+from .box_head import PostProcess, YOLOHead
+
+__all__ = [
+    "YOLO",
+    "yolov5_darknet_pan_n_r60", "yolov5_darknet_pan_n6_r60", "yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_s6_r60",
+    "yolov5_darknet_pan_m_r60", "yolov5_darknet_pan_m6_r60", "yolov5_darknet_pan_l_r60", "yolov5_darknet_pan_l6_r60",
+    "yolov5_darknet_pan_x_r60", "yolov5_darknet_pan_x6_r60",
+    "yolov5_darknet_pan_s_r31", "yolov5_darknet_pan_m_r31", "yolov5_darknet_pan_l_r31",
+    "yolov5_darknet_pan_s_r40", "yolov5_darknet_pan_m_r40", "yolov5_darknet_pan_l_r40", "yolov5_darknet_tan_s_r40",
+]
+
+DEFAULT_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # yolo.py:94-99
+P6_ANCHORS = [[19, 27, 44, 40, 38, 94], [96, 68, 86, 152, 180, 137], [140, 301, 303, 264, 238, 542], [436, 615, 739, 380, 925, 792]]  # yolo.py:642-647
+
+
+class _PlanEntry:
+    def __init__(self, plan: Plan, x: View, feats: List[View], logits: Optional[List[View]], post, rescale: Optional[Tensor], n_backbone_ops: int):
+        self.plan, self.x, self.feats, self.logits, self.post, self.rescale = plan, x, feats, logits, post, rescale
+        self.n_backbone_ops = n_backbone_ops
+
+
+class YOLO(nn.Module):
+    def __init__(
+        self,
+        backbone: nn.Module,
+        num_classes: int,
+        strides: Optional[List[int]] = None,
+        anchor_grids: Optional[List[List[float]]] = None,
+        anchor_generator: Optional[nn.Module] = None,
+        head: Optional[nn.Module] = None,
+        criterion: Optional[Callable[..., Dict[str, Tensor]]] = None,
+        score_thresh: float = 0.005,
+        nms_thresh: float = 0.45,
+        detections_per_img: int = 300,
+        post_process: Optional[nn.Module] = None,
+    ):
+        super().__init__()
+        if not hasattr(backbone, "out_channels"):
+            raise ValueError(
+                "backbone should contain an attribute out_channels specifying the number of output channels "
+                "(assumed to be the same for all the levels)"
+            )
+        self.backbone = backbone
+        strides = [8, 16, 32] if strides is None else strides
+        anchor_grids = DEFAULT_ANCHORS if anchor_grids is None else anchor_grids
+        self.anchor_generator = anchor_generator if anchor_generator is not None else AnchorGenerator(strides, anchor_grids)
+        self.compute_loss = criterion  # training criterion is out of scope; kept only if the caller injects one
+        self.num_classes = num_classes
+        self.head = head if head is not None else YOLOHead(backbone.out_channels, self.anchor_generator.num_anchors, self.anchor_generator.strides, num_classes)
+        self.post_process = post_process if post_process is not None else PostProcess(self.anchor_generator.strides, score_thresh, nms_thresh, detections_per_img)
+        self.compute_dtype = torch.float16  # used when parameters are fp32 (see hipmodule.compute_dtype_of)
+        self.use_graph = os.environ.get("YOLORT_AMD_GRAPH", "0") == "1"
+        self.cand_cap_per_image = int(os.environ.get("YOLORT_AMD_CAND_CAP", "16384"))
+        self._entries: Dict[Tuple, _PlanEntry] = {}
+        self._has_warned = False
+
+    # ------------------------------------------------------------------------------------------
+    def fused(self) -> bool:
+        return type(self.head) is YOLOHead and type(self.post_process) is PostProcess and type(self.anchor_generator) is AnchorGenerator and hasattr(self.backbone, "emit")
+
+    def _entry(self, n: int, h: int, w: int, device: torch.device) -> _PlanEntry:
+        cdt = compute_dtype_of(self)
+        pp = self.post_process
+        post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
+        key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image)
+        e = self._entries.get(key)
+        if e is not None:
+            return e
+        self._entries.clear()  # one live shape at a time keeps HBM use bounded
+        if not hasattr(self.backbone, "emit"):
+            raise YmiError("the backbone must be a yolort_amd HIP module (custom torch backbones have no MI355X path)")
+        plan = Plan(device, cdt)
+        x = plan.alloc(n, h, w, 4, zero=True)
+        feats = self.backbone.emit(plan, x)
+        n_backbone = plan.num_ops
+        logits = post = rescale = None
+        if self.fused():
+            logits = self.head.emit(plan, feats)
+            rescale = torch.zeros(n, 3, device=device, dtype=torch.float32)
+            ag = self.anchor_generator
+            post = plan.postprocess(logits, [float(s) for s in ag.strides], ag.anchor_grids, self.num_classes, float(pp.score_thresh), float(pp.nms_thresh),
+                                    int(pp.detections_per_img), self.cand_cap_per_image * n, rescale=rescale)
+        e = _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
+        self._entries[key] = e
+        return e
+
+    def _run_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> List[Dict[str, Tensor]]:
+        """input view already filled; runs the plan and converts the slab to the reference's List[Dict]"""
+        if e.post is None:  # custom hooks: HIP backbone, then the injected modules on torch tensors
+            e.plan.run(graph=self.use_graph)
+            feats = [view_to_nchw(v) for v in e.feats]
+            head_outputs = self.head(feats)
+            grids, shifts = self.anchor_generator(feats)
+            return self.post_process(head_outputs, grids, shifts)
+        if rescale_rows is None:
+            e.rescale.zero_()
+        else:
+            e.rescale.copy_(torch.tensor(rescale_rows, dtype=torch.float32), non_blocking=False)
+        while True:
+            e.plan.run(graph=self.use_graph)
+            host = torch.cat([e.post.status, e.post.count]).cpu().tolist()
+            if host[1] == 0:
+                break
+            # candidate capacity exceeded: nothing was truncated; grow and rebuild (rare)
+            self.cand_cap_per_image = int(host[0] * 1.25 / e.x.n) + 1024
+            x_old = e.x
+            e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
+            e2.x.base.copy_(x_old.base)
+            if rescale_rows is not None:
+                e2.rescale.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
+            e = e2
+        counts = host[4:]
+        p = e.post
+        return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), counts)
+
+    def forward(self, samples: Tensor, targets: Optional[Tensor] = None):
+        """samples: batched images (N,3,H,W) in 0-1 range (reference yolo.py:141-183)."""
+        if self.training:
+            raise NotImplementedError("yolort_amd implements the inference path only; call .eval() (training / SetCriterion are out of scope)")
+        if not isinstance(samples, Tensor) or samples.dim() != 4:
+            raise ValueError("samples is expected to be a batched tensor of shape [N, 3, H, W]")
+        if not samples.is_cuda:
+            raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
+        n, c, h, w = samples.shape
+        e = self._entry(n, h, w, samples.device)
+        nchw_to_view(e.plan, samples, 4, out=e.x)
+        return self._run_entry(e, None)
+
+    @classmethod
+    def load_from_yolov5(cls, checkpoint_path: str, score_thresh: float = 0.25, nms_thresh: float = 0.45, version: str = "r6.0",
+                         post_process: Optional[nn.Module] = None):
+        raise NotImplementedError(
+            "loading pickled ultralytics checkpoints (reference yolo.py:185-223, _checkpoint.py) is the next row of the "
+            "scope table (SURVEY.md 8f-1); load a yolort-format state_dict with model.load_state_dict instead"
+        )
+
+
+def build_model(backbone_name: str, depth_multiple: float, width_multiple: float, version: str, weights_name: Optional[str] = None,
+                pretrained: bool = False, progress: bool = True, num_classes: int = 80, use_p6: bool = False, **kwargs: Any) -> YOLO:
+    """Reference yolo.py:226-265.  There is no network here, so `pretrained=True` raises instead of downloading."""
+    backbone = darknet_pan_backbone(backbone_name, depth_multiple, width_multiple, version=version, use_p6=use_p6)
+    model = YOLO(backbone, num_classes, **kwargs)
+    if pretrained:
+        raise ValueError(f"No checkpoint is available for model {weights_name} (offline build: load a state_dict explicitly)")
+    return model
+
+
+def _r60(size: str, depth: float, width: float, p6: bool):
+    def factory(pretrained: bool = False, progress: bool = True, num_classes: int = 80, **kwargs: Any) -> YOLO:
+        extra = dict(use_p6=True, strides=[8, 16, 32, 64], anchor_grids=P6_ANCHORS) if p6 else {}
+        name = f"{size}6" if p6 else size
+        return build_model(f"darknet_{size}_r6_0", depth, width, "r6.0", f"yolov5_darknet_pan_{name}_r60_coco", pretrained=pretrained,
+                           progress=progress, num_classes=num_classes, **extra, **kwargs)
+
+    factory.__doc__ = f"yolov5 {size}{'6' if p6 else ''} release 6.0 (depth {depth}, width {width}); reference yolo.py:472-834"
+    return factory
+
+
+yolov5_darknet_pan_n_r60 = _r60("n", 0.33, 0.25, False)
+yolov5_darknet_pan_s_r60 = _r60("s", 0.33, 0.5, False)
+yolov5_darknet_pan_m_r60 = _r60("m", 0.67, 0.75, False)
+yolov5_darknet_pan_l_r60 = _r60("l", 1.0, 1.0, False)
+yolov5_darknet_pan_x_r60 = _r60("x", 1.33, 1.25, False)
+yolov5_darknet_pan_n6_r60 = _r60("n", 0.33, 0.25, True)
+yolov5_darknet_pan_s6_r60 = _r60("s", 0.33, 0.5, True)
+yolov5_darknet_pan_m6_r60 = _r60("m", 0.67, 0.75, True)
+yolov5_darknet_pan_l6_r60 = _r60("l", 1.0, 1.0, True)
+yolov5_darknet_pan_x6_r60 = _r60("x", 1.33, 1.25, True)
+
+
+def _legacy(name: str):
+    def factory(*args: Any, **kwargs: Any):
+        raise NotImplementedError(f"{name}: legacy r3.1/r4.0 (Focus stem / BottleneckCSP / TAN) architectures are out of the MI355X hot-path scope")
+
+    return factory
+
+
+yolov5_darknet_pan_s_r31 = _legacy("yolov5_darknet_pan_s_r31")
+yolov5_darknet_pan_m_r31 = _legacy("yolov5_darknet_pan_m_r31")
+yolov5_darknet_pan_l_r31 = _legacy("yolov5_darknet_pan_l_r31")
+yolov5_darknet_pan_s_r40 = _legacy("yolov5_darknet_pan_s_r40")
+yolov5_darknet_pan_m_r40 = _legacy("yolov5_darknet_pan_m_r40")
+yolov5_darknet_pan_l_r40 = _legacy("yolov5_darknet_pan_l_r40")
+yolov5_darknet_tan_s_r40 = _legacy("yolov5_darknet_tan_s_r40")

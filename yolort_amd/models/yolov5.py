@@ -1,0 +1,110 @@
+"""`YOLOv5`: letterbox + YOLO + box rescale behind the reference's predict API
+(reference yolort/models/yolov5.py:19-297)."""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .._lib import YmiError
+from ..utils import contains_any_tensor
+from . import yolo
+from .transform import YOLOTransform, rescale_params
+from .yolo import YOLO
+
+__all__ = ["YOLOv5"]
+
+
+class YOLOv5(nn.Module):
+    def __init__(
+        self,
+        arch: Optional[str] = None,
+        model: Optional[nn.Module] = None,
+        num_classes: int = 80,
+        pretrained: bool = False,
+        progress: bool = True,
+        size: Tuple[int, int] = (640, 640),
+        size_divisible: int = 32,
+        fixed_shape: Optional[Tuple[int, int]] = None,
+        fill_color: int = 114,
+        **kwargs: Any,
+    ) -> None:
+        super().__init__()
+        self.arch = arch
+        self.num_classes = num_classes
+        if model is None:
+            model = yolo.__dict__[arch](pretrained=pretrained, progress=progress, num_classes=num_classes, **kwargs)
+        self.model = model
+        self.transform = YOLOTransform(size[0], size[1], size_divisible=size_divisible, fixed_shape=fixed_shape, fill_color=fill_color)
+        self._has_warned = False
+
+    def forward(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
+        """inputs: iterable of (3,H,W) tensors in 0-1 range (or uint8 0-255), possibly of different sizes
+        (reference yolov5.py:135-189).  Returns List[Dict] with boxes in ORIGINAL image coordinates."""
+        if self.training:
+            raise NotImplementedError("yolort_amd implements the inference path only; call .eval() (training is out of scope)")
+        if targets is not None:
+            raise NotImplementedError("targets belong to the training path (out of scope)")
+        images = [inputs[i] for i in range(len(inputs))]
+        for im in images:
+            if im.dim() != 3:  # reference transform.py:185-189
+                raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], but got '{im.shape}'.")
+            if not im.is_cuda:
+                raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
+        original = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        (hb, wb), sizes, pads = self.transform.geometry(original)
+        model = self.model
+        if not isinstance(model, YOLO):
+            raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
+        e = model._entry(len(images), hb, wb, images[0].device)
+        self.transform.letterbox_into(images, e.x, sizes, pads)
+        rows = [rescale_params((hb, wb), o) for o in original]
+        if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
+            dets = model._run_entry(e, None)
+            return self.transform.postprocess(dets, (hb, wb), original)
+        return model._run_entry(e, rows)
+
+    @torch.no_grad()
+    def predict(self, x: Any, image_loader: Optional[Callable] = None) -> List[Dict[str, Tensor]]:
+        """Reference yolov5.py:202-216."""
+        image_loader = image_loader or self.default_loader
+        images = self.collate_images(x, image_loader)
+        return self.forward(images)
+
+    def default_loader(self, img_path: str) -> Tensor:
+        """RGB uint8 CHW tensor; the /255 of the reference (yolov5.py:228) is fused into the letterbox
+        kernel's uint8 path (decode stays on the host, PIL)."""
+        import numpy as np
+        from PIL import Image
+
+        arr = np.asarray(Image.open(img_path).convert("RGB"))
+        return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous()
+
+    def collate_images(self, samples: Any, image_loader: Callable) -> List[Tensor]:
+        """Reference yolov5.py:230-262: everything moves to the model's device; floating inputs take the
+        model dtype, uint8 images stay uint8 (the kernel normalises them)."""
+        p = next(self.parameters())
+
+        def prep(t: Tensor) -> Tensor:
+            t = t.to(p.device)
+            return t if t.dtype == torch.uint8 else t.type_as(p)
+
+        if isinstance(samples, Tensor):
+            return [prep(samples)]
+        if contains_any_tensor(samples):
+            return [prep(s) for s in samples]
+        if isinstance(samples, str):
+            samples = [samples]
+        if isinstance(samples, (list, tuple)) and all(isinstance(s, str) for s in samples):
+            return [prep(image_loader(s)) for s in samples]
+        raise NotImplementedError(
+            f"The type of the sample is {type(samples)}, we currently don't support it now, the "
+            "samples should be either a tensor, list of tensors, a image path or list of image paths."
+        )
+
+    @classmethod
+    def load_from_yolov5(cls, checkpoint_path: str, *, size: Tuple[int, int] = (640, 640), size_divisible: int = 32,
+                         fixed_shape: Optional[Tuple[int, int]] = None, fill_color: int = 114, **kwargs: Any):
+        model = YOLO.load_from_yolov5(checkpoint_path, **kwargs)
+        return cls(model=model, size=size, size_divisible=size_divisible, fixed_shape=fixed_shape, fill_color=fill_color)

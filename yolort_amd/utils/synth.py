@@ -1,0 +1,101 @@
+"""Seeded synthetic "trained-like" weights (data generation only; no compute path).
+
+There are no pretrained checkpoints offline and the reference's default init makes every score
+vanish, so benchmarks and parity tests use a seeded recipe:
+
+  * conv weights        ~ N(0, 1/fan_in), rounded to fp16-representable values
+  * BatchNorm affine    weight = 0.75 + 0.5 U, bias = 0.2 N
+  * BatchNorm statistics loaded from a committed calibration file
+    ``yolort_amd/data/synth_bn_<arch>_s<seed>.npz`` (produced once, on CPU, by
+    ``oracle/make_synth_bn.py`` -- batch statistics of a seeded calibration batch)
+  * head convs          weight ~ N(0, (g/sqrt(Cin))^2), bias box 0 / obj `obj_bias` / cls `cls_bias`
+
+The same state_dict is loaded into the reference (oracle) and into this package, exactly like a
+real yolort checkpoint would be (reference loader: yolort/models/yolo.py:259-263).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+def _fp16_round(a: np.ndarray) -> np.ndarray:
+    return a.astype(np.float16).astype(np.float32)
+
+
+def synth_state_dict(
+    template: Dict[str, torch.Tensor],
+    seed: int = 0,
+    head_gain: float = 1.0,
+    obj_bias: float = -4.0,
+    cls_bias: float = -1.0,
+    num_outputs: int = 85,
+) -> Dict[str, torch.Tensor]:
+    """Fill a state_dict (keys/shapes taken from `template`) with the seeded recipe.
+
+    BatchNorm running statistics are left at (0, 1); see `load_synth_bn`.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out: Dict[str, torch.Tensor] = {}
+    for key, t in template.items():
+        shape = tuple(t.shape)
+        if key.endswith("num_batches_tracked"):
+            v = np.zeros(shape, np.int64)
+            out[key] = torch.from_numpy(v)
+            continue
+        if key.endswith(".conv.weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = _fp16_round(rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in))
+        elif key.endswith(".bn.weight"):
+            v = (0.75 + 0.5 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+        elif key.endswith(".bn.bias"):
+            v = (0.2 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        elif key.endswith(".bn.running_mean"):
+            v = np.zeros(shape, np.float32)
+        elif key.endswith(".bn.running_var"):
+            v = np.ones(shape, np.float32)
+        elif ".head." in key and key.endswith(".weight"):
+            v = _fp16_round(rng.standard_normal(shape, dtype=np.float32) * (head_gain / np.sqrt(shape[1])))
+        elif ".head." in key and key.endswith(".bias"):
+            b = np.zeros((shape[0] // num_outputs, num_outputs), np.float32)
+            b[:, 4] = obj_bias
+            b[:, 5:] = cls_bias
+            v = b.reshape(shape)
+        else:
+            raise KeyError(f"synth recipe does not know key {key}")
+        out[key] = torch.from_numpy(np.ascontiguousarray(v))
+    return out
+
+
+def synth_bn_path(arch: str, seed: int) -> str:
+    return os.path.join(_DATA, f"synth_bn_{arch}_s{seed}.npz")
+
+
+def load_synth_bn(sd: Dict[str, torch.Tensor], arch: str, seed: int = 0, path: Optional[str] = None) -> Dict[str, torch.Tensor]:
+    """Overwrite the BatchNorm running statistics of `sd` with the committed calibration."""
+    path = path or synth_bn_path(arch, seed)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"no committed BN calibration for arch={arch} seed={seed}: {path} (run oracle/make_synth_bn.py)")
+    z = np.load(path)
+    prefix = "model." if any(k.startswith("model.") for k in sd) else ""
+    for k in z.files:
+        kk = prefix + k
+        if kk not in sd:
+            raise KeyError(f"calibration key {kk} not in state_dict")
+        sd[kk] = torch.from_numpy(z[k].astype(np.float32))
+    return sd
+
+
+def synth_weights(template: Dict[str, torch.Tensor], arch: str, seed: int = 0, **kw) -> Dict[str, torch.Tensor]:
+    return load_synth_bn(synth_state_dict(template, seed=seed, **kw), arch, seed)
+
+
+def synth_images(n: int, h: int = 640, w: int = 640, seed: int = 1) -> torch.Tensor:
+    """Seeded U[0,1) images (N,3,H,W) fp32."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(rng.random((n, 3, h, w), dtype=np.float32))

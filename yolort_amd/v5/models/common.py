@@ -1,0 +1,138 @@
+"""YOLOv5 building blocks (r4.0/r6.0 forms) as HIP plan emitters.
+
+Same constructor signatures, attribute names and state_dict keys as the reference's blocks
+(yolort/v5/models/common.py: Conv :42, Bottleneck :94, C3 :149, SPP :176, SPPF :190) so that its
+checkpoints load unchanged; the arithmetic is the fused implicit-GEMM kernel (csrc/conv_igemm.hip)
+instead of conv2d -> BatchNorm2d -> SiLU -> cat.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from ..._lib import ACT_NONE, ACT_SILU, YmiError
+from ...engine import PackedConv, Plan, View
+from ...hipmodule import HipModule
+
+__all__ = ["Conv", "Bottleneck", "C3", "SPP", "SPPF", "autopad"]
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03  # set after construction by the reference (darknetv6.py:110-112)
+
+
+def autopad(k, p=None):
+    """'same' padding (reference common.py:35-39)."""
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+class Conv(HipModule):
+    """conv2d (no bias) + BatchNorm2d + SiLU, fused (reference common.py:42-73)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True, version="r4.0"):
+        super().__init__()
+        if g != 1:
+            raise NotImplementedError("grouped convolutions are not on the YOLOv5 r6.0 hot path")
+        if version != "r4.0":
+            raise NotImplementedError(f"Currently doesn't support version {version}.")
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2, eps=BN_EPS, momentum=BN_MOMENTUM)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+        if not isinstance(self.act, (nn.SiLU, nn.Identity)):
+            raise NotImplementedError("only SiLU / identity activations are fused")
+        self._packed: Dict[Tuple, Tuple] = {}
+
+    def _is_stem(self) -> bool:
+        return self.conv.in_channels == 3 and self.conv.kernel_size == (6, 6) and self.conv.stride == (2, 2) and self.conv.padding == (2, 2)
+
+    def _input_cpad(self, c: int) -> int:
+        return 4 if self._is_stem() else (c + 7) // 8 * 8
+
+    def packed(self, dtype: torch.dtype, device: torch.device, cin_view: int) -> PackedConv:
+        sig = tuple(t._version for t in (self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)) + (self.conv.weight.data_ptr(),)
+        stem = cin_view == 4 and self._is_stem()
+        key = (dtype, device, cin_view, stem)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, float(self.bn.eps))
+        pc = PackedConv(self.conv.weight, None, bn, dtype, device, cin_pad=None if stem else cin_view, stem_superpixel=stem)
+        self._packed[key] = (sig, pc)
+        return pc
+
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, res: Optional[View] = None, name: str = "conv") -> View:
+        pc = self.packed(plan.dtype, plan.device, x.c)
+        act = ACT_SILU if isinstance(self.act, nn.SiLU) else ACT_NONE
+        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act, out=out, res=res, name=name)
+
+
+class Bottleneck(HipModule):
+    """x + cv2(cv1(x)) (1x1 then 3x3); the residual add rides in cv2's epilogue (reference :94-116)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5, version="r4.0"):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1, version=version)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g, version=version)
+        self.add = shortcut and c1 == c2
+
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck") -> View:
+        y = self.cv1.emit(plan, x, name=name + ".cv1")
+        return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + ".cv2")
+
+
+class C3(HipModule):
+    """cv3(cat(m(cv1(x)), cv2(x))) (reference :149-173).  The concat buffer is allocated first; the
+    last bottleneck and cv2 write straight into its two halves, so no cat kernel exists."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5, version="r4.0"):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1, version=version)
+        self.cv2 = Conv(c1, c_, 1, 1, version=version)
+        self.cv3 = Conv(2 * c_, c2, 1, version=version)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, version=version) for _ in range(n)])
+
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "c3") -> View:
+        c_ = self.cv1.conv.out_channels
+        cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
+        nb = len(self.m)
+        y = self.cv1.emit(plan, x, out=cat.slice_c(0, c_) if nb == 0 else None, name=name + ".cv1")
+        for j, b in enumerate(self.m):
+            y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}")
+        self.cv2.emit(plan, x, out=cat.slice_c(c_, c_), name=name + ".cv2")
+        return self.cv3.emit(plan, cat, out=out, name=name + ".cv3")
+
+
+class SPP(HipModule):
+    """cv2(cat(x, mp5(x), mp9(x), mp13(x))) after cv1 (reference :176-187)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13), version="r4.0"):
+        super().__init__()
+        if tuple(k) != (5, 9, 13):
+            raise NotImplementedError("the fused pool pyramid implements k=(5, 9, 13)")
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1, version=version)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1, version=version)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "spp") -> View:
+        c_ = self.cv1.conv.out_channels
+        if c_ % 8:
+            raise YmiError("SPP hidden width must be a multiple of 8")
+        cat = plan.alloc(x.n, x.h, x.w, 4 * c_)
+        self.cv1.emit(plan, x, out=cat.slice_c(0, c_), name=name + ".cv1")
+        plan.spp_pool(cat, c_, name=name + ".pool")
+        return self.cv2.emit(plan, cat, out=out, name=name + ".cv2")
+
+
+class SPPF(SPP):
+    """SPPF(k=5) == SPP(k=(5,9,13)) (reference :190-207, equivalence note :196); same parameters."""
+
+    def __init__(self, c1, c2, k=5, version="r4.0"):
+        if k != 5:
+            raise NotImplementedError("the fused pool pyramid implements SPPF(k=5)")
+        super().__init__(c1, c2, (5, 9, 13), version=version)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
