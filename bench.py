@@ -1,0 +1,222 @@
+"""Throughput benchmark of the MI355X YOLOv5 inference hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path over one batch of 32 synthetic 640x640 images per GPU:
+letterbox -> CSPDarknet+PAN -> head -> decode + class-aware NMS + top-k + rescale -> List[Dict], with
+the images already resident in HBM (fp16, 0-1 range).  With N > 1 every rank runs its own shard
+(weak scaling: 32 images per GPU) and the fixed-shape detection slabs are all-gathered over RCCL.
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric plus
+  "roofline"     : conv stack (the dominant kernel family, conv_igemm_kernel) -- algorithmic bytes of
+                   all conv launches of one step / time of those launches, measured with HIP events on
+                   the plan's stream inside the timed region, against the 8 TB/s HBM peak; the
+                   per-layer max(flops/2.5PF, bytes/8TB/s) bound of SURVEY.md 8d is reported too.
+  "cpu_baseline" : the oracle (CPU fp32 restatement of the reference) timed on this box's host cores
+                   on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
+MFMA_PEAK = 2.5e15  # FLOP/s dense fp16/bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="yolov5_darknet_pan_s_r60")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--score-thresh", type=float, default=0.25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", default="", help="write a per-op profile (json) to this path after the timed run")
+    return ap.parse_args()
+
+
+def cpu_baseline(arch, sd, images_cpu, score_thresh, budget_s=25.0):
+    """oracle (port of the reference's algorithm) on the host cores, bounded sample"""
+    from oracle import yolov5_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    imgs = [im.float() for im in images_cpu]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.yolov5_forward(imgs[:4], sd, score_thresh=score_thresh)  # warm-up on 4 images
+        warm = time.perf_counter() - t0
+        n_sample = max(4, min(len(imgs), int(4 * (budget_s * 0.45) / max(warm, 1e-3)) // 4 * 4))
+        t0 = time.perf_counter()
+        passes = 0
+        while True:
+            O.yolov5_forward(imgs[:n_sample], sd, score_thresh=score_thresh)
+            passes += 1
+            dt = time.perf_counter() - t0
+            if passes >= 2 or dt > budget_s * 0.5:
+                break
+    return {"value": round(passes * n_sample / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} pass(es) of {n_sample} images 640x640 through oracle/yolov5_oracle.py (fp32, torch CPU, {cores} threads), incl. letterbox+NMS"}
+
+
+def parity_sample(model, images_gpu, images_cpu, sd, score_thresh, k=2):
+    """'mAP vs ref' proxy on a bounded sample: HIP detections scored against the oracle's."""
+    import numpy as np
+
+    from oracle import yolov5_oracle as O
+
+    with torch.no_grad():
+        ref = O.yolov5_forward([im.float() for im in images_cpu[:k]], sd, score_thresh=score_thresh)
+    got = model.forward(images_gpu[:k])
+    ious, matched, total = [], 0, 0
+    for r, d in zip(ref, got):
+        rb, rl = r["boxes"].numpy(), r["labels"].numpy()
+        gb, gl = d["boxes"].float().cpu().numpy(), d["labels"].cpu().numpy()
+        total += len(rl)
+        for i in range(len(rl)):
+            c = np.where(gl == rl[i])[0]
+            if len(c) == 0:
+                continue
+            x1, y1 = np.maximum(rb[i, 0], gb[c, 0]), np.maximum(rb[i, 1], gb[c, 1])
+            x2, y2 = np.minimum(rb[i, 2], gb[c, 2]), np.minimum(rb[i, 3], gb[c, 3])
+            inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+            iou = inter / ((rb[i, 2] - rb[i, 0]) * (rb[i, 3] - rb[i, 1]) + (gb[c, 2] - gb[c, 0]) * (gb[c, 3] - gb[c, 1]) - inter + 1e-12)
+            best = float(iou.max())
+            if best >= 0.5:
+                matched += 1
+                ious.append(best)
+    return {"images": k, "ref_dets": total, "matched_iou50": round(matched / max(total, 1), 4),
+            "median_iou": round(float(np.median(ious)), 4) if ious else None}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from yolort_amd import dist as ydist
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    model = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300)
+    sd = synth_weights(model.state_dict(), args.arch, seed=0, head_gain=1.0)
+    model.load_state_dict(sd)
+    model = model.to(dev).to(dtype).eval()
+
+    # each rank's shard of the (weak-scaled) global batch: seeds differ per rank
+    images_cpu = list(synth_images(args.batch, args.size, args.size, seed=1 + rank))
+    images_gpu = [im.to(dev).to(dtype) for im in images_cpu]
+
+    yolo = model.model
+    stream = torch.cuda.current_stream()
+
+    def step():
+        dets = model.forward(images_gpu)
+        if world > 1:
+            e = next(iter(yolo._entries.values()))
+            ydist.all_gather_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count)
+        return dets
+
+    for _ in range(args.warmup):
+        dets = step()
+    torch.cuda.synchronize()
+    e = next(iter(yolo._entries.values()))
+    n_conv_ops = sum(1 for m in e.plan.meta if m["kind"] != "post")
+    # conv-stack bracket events (recorded on the plan's stream inside the timed region)
+    yolo.bracket = (n_conv_ops, [], [])
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dets = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    starts, ends = yolo.bracket[1], yolo.bracket[2]
+    conv_ms = sum(s.elapsed_time(t) for s, t in zip(starts, ends)) / max(len(starts), 1)
+    yolo.bracket = None
+
+    if rank == 0:
+        conv_meta = [m for m in e.plan.meta if m["kind"] == "conv"]
+        n_conv = len(conv_meta)
+        bytes_step = sum(m["bytes"] for m in conv_meta)
+        flops_step = sum(m["flops"] for m in conv_meta)
+        bound_s = sum(max(m["flops"] / MFMA_PEAK, m["bytes"] / HBM_PEAK) for m in conv_meta)
+        conv_s = conv_ms * 1e-3
+        achieved = bytes_step / conv_s / 1e9 if conv_s > 0 else 0.0
+        ips = world * args.batch * args.steps / elapsed
+        out = {
+            "metric": "images/sec at 640x640 (bs=32) yolov5s",
+            "value": round(ips, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{args.arch} {args.dtype} bs={args.batch}/GPU {args.size}x{args.size}, full letterbox+backbone+head+decode+NMS HIP path (BASELINE configs[1])",
+                       "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
+                       "weights": "seeded synthetic (yolort_amd/utils/synth.py)", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
+                       "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
+                       "candidates_per_step_rank0": int(e.post.status[0].item())},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
+                         "traffic": None, "kernel": "conv_igemm_kernel (all conv launches of one step)", "launches_per_step": n_conv,
+                         "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2), "conv_ms_per_step": round(conv_ms, 4),
+                         "algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_step": flops_step,
+                         "tflops": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0,
+                         "per_layer_bound_ms": round(bound_s * 1e3, 4), "frac_of_per_layer_bound": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd_cpu = {k: v.float().cpu() for k, v in model.state_dict().items()}
+            out["parity"] = parity_sample(model, images_gpu, images_cpu, sd_cpu, args.score_thresh)
+            out["cpu_baseline"] = cpu_baseline(args.arch, sd_cpu, images_cpu, args.score_thresh)
+        if args.per_op:
+            prof = e.plan.profile(iters=5)
+            with open(args.per_op, "w") as f:
+                json.dump([{"name": n, "ms": ms, **meta} for n, ms, meta in prof], f, indent=1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

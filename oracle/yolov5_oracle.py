@@ -152,10 +152,32 @@ class _Calib:
 CALIB = _Calib()
 
 
+class _Emulate:
+    """Optional low-precision emulation of the HIP engine's storage format: when `dtype` is
+    torch.float16 / torch.bfloat16 the oracle folds BatchNorm into the conv weights, rounds the folded
+    weights and every activation to that dtype (accumulation stays fp32), i.e. it restates exactly
+    what the MI355X path stores in HBM.  Used to separate "inherent fp16/bf16 rounding" from bugs."""
+
+    def __init__(self) -> None:
+        self.dtype = None
+
+
+EMULATE = _Emulate()
+
+
+def _q(x: Tensor) -> Tensor:
+    return x.to(EMULATE.dtype).to(torch.float32) if EMULATE.dtype is not None else x
+
+
 def conv_bn_silu(x: Tensor, sd: Dict[str, Tensor], p: str, stride: int = 1, pad: Optional[int] = None) -> Tensor:
     """common.py:42-70 `Conv`: SiLU(BN(conv2d(x))), bias-free conv, pad=k//2 (autopad :35-39)."""
     w = sd[p + ".conv.weight"]
     k = w.shape[-1]
+    if EMULATE.dtype is not None:  # folded-BN, low-precision storage emulation (see _Emulate)
+        scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + BN_EPS)
+        bias = sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale
+        y = F.conv2d(_q(x), _q(w * scale.view(-1, 1, 1, 1)), bias, stride, k // 2 if pad is None else pad)
+        return F.silu(y)
     y = F.conv2d(x, w, None, stride, k // 2 if pad is None else pad)
     if CALIB.active:
         sd[p + ".bn.running_mean"] = y.mean(dim=(0, 2, 3))
@@ -176,7 +198,7 @@ def c3(x: Tensor, sd: Dict[str, Tensor], p: str, shortcut: bool) -> Tensor:
     y = conv_bn_silu(x, sd, p + ".cv1")
     for j in range(_count(sd, p + ".m")):
         z = conv_bn_silu(conv_bn_silu(y, sd, f"{p}.m.{j}.cv1"), sd, f"{p}.m.{j}.cv2")
-        y = y + z if shortcut else z
+        y = _q(_q(y) + z) if (shortcut and EMULATE.dtype is not None) else (y + z if shortcut else z)
     return conv_bn_silu(torch.cat((y, conv_bn_silu(x, sd, p + ".cv2")), dim=1), sd, p + ".cv3")
 
 
@@ -230,7 +252,7 @@ def head(features: List[Tensor], sd: Dict[str, Tensor], p: str = "head", num_anc
     """YOLOHead.forward (box_head.py:68-82): biased 1x1 conv, view (N,A,K,H,W) -> (N,A,H,W,K)."""
     outs = []
     for i, f in enumerate(features):
-        y = F.conv2d(f, sd[f"{p}.head.{i}.weight"], sd[f"{p}.head.{i}.bias"])
+        y = F.conv2d(_q(f), _q(sd[f"{p}.head.{i}.weight"]), sd[f"{p}.head.{i}.bias"])
         n, _, h, w = y.shape
         outs.append(y.view(n, num_anchors, -1, h, w).permute(0, 1, 3, 4, 2).contiguous())
     return outs

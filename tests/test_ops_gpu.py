@@ -38,8 +38,9 @@ def _run_conv(dev, dtype, n, cin, cout, h, w, k, s, p, act=True, residual=False,
     xv.as_tensor().copy_(_nhwc(xq).to(dev, dtype))
     pc = engine.PackedConv(wq, bias, None, dtype, dev)
     ho, wo = engine.conv_out_hw(h, w, (k, k), (s, s), (p, p))
-    yb = plan.alloc(n, ho, wo, cout + y_cs_extra, zero=True)
-    yv = yb.slice_c(y_cs_extra // 2 if y_cs_extra else 0, cout) if y_cs_extra else yb
+    cpad = (cout + 7) // 8 * 8
+    yb = plan.alloc(n, ho, wo, cpad + y_cs_extra, zero=True)
+    yv = yb.slice_c(y_cs_extra // 2 if y_cs_extra else 0, cout)
     rv = None
     if residual:
         r = torch.randn(n, cout, ho, wo, generator=g).to(dtype).float()

@@ -75,6 +75,8 @@ class YOLO(nn.Module):
         self.cand_cap_per_image = int(os.environ.get("YOLORT_AMD_CAND_CAP", "16384"))
         self._entries: Dict[Tuple, _PlanEntry] = {}
         self._has_warned = False
+        # measurement hook (bench.py): (n_ops, starts, ends) -> HIP events around ops [0, n_ops) of every run
+        self.bracket = None
 
     # ------------------------------------------------------------------------------------------
     def fused(self) -> bool:
@@ -119,7 +121,17 @@ class YOLO(nn.Module):
         else:
             e.rescale.copy_(torch.tensor(rescale_rows, dtype=torch.float32), non_blocking=False)
         while True:
-            e.plan.run(graph=self.use_graph)
+            if self.bracket is not None:
+                n_ops, starts, ends = self.bracket
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                e.plan.run(0, n_ops)
+                ev1.record()
+                e.plan.run(n_ops, -1)
+                starts.append(ev0)
+                ends.append(ev1)
+            else:
+                e.plan.run(graph=self.use_graph)
             host = torch.cat([e.post.status, e.post.count]).cpu().tolist()
             if host[1] == 0:
                 break

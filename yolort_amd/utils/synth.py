@@ -8,7 +8,9 @@ vanish, so benchmarks and parity tests use a s
   * BatchNorm statistics loaded from a committed calibration file
     ``yolort_amd/data/synth_bn_<arch>_s<seed>.npz`` (produced once, on CPU, by
     ``oracle/make_synth_bn.py`` -- batch statistics of a seeded calibration batch)
-  * head convs          weight ~ N(0, (g/sqrt(Cin))^2), bias box 0 / obj `obj_bias` / cls `cls_bias`
+  * head convs          weight ~ N(0, (g/sqrt(Cin))^2) for the obj/cls outputs and a quarter of that for
+                        the 4 box outputs (keeps boxes anchor-sized instead of degenerate),
+                        bias box 0 / obj `obj_bias` / cls `cls_bias`
 
 The same state_dict is loaded into the reference (oracle) and into this package, exactly like a
 real yolort checkpoint would be (reference loader: yolort/models/yolo.py:259-263).
@@ -60,7 +62,10 @@ def synth_state_dict(
         elif key.endswith(".bn.running_var"):
             v = np.ones(shape, np.float32)
         elif ".head." in key and key.endswith(".weight"):
-            v = _fp16_round(rng.standard_normal(shape, dtype=np.float32) * (head_gain / np.sqrt(shape[1])))
+            v = rng.standard_normal(shape, dtype=np.float32) * (head_gain / np.sqrt(shape[1]))
+            v = v.reshape(shape[0] // num_outputs, num_outputs, *shape[1:])
+            v[:, :4] *= 0.25  # box regressors: small logits -> sigmoid near 0.5 -> anchor-sized boxes
+            v = _fp16_round(v.reshape(shape))
         elif ".head." in key and key.endswith(".bias"):
             b = np.zeros((shape[0] // num_outputs, num_outputs), np.float32)
             b[:, 4] = obj_bias
