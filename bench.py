@@ -53,7 +53,7 @@ def cpu_baseline(arch, sd, images_cpu, score_thresh, budget_s=25.0):
     """oracle (port of the reference's algorithm) on the host cores, bounded sample"""
     from oracle import yolov5_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # torch CPU convs stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     imgs = [im.float() for im in images_cpu]
     with torch.no_grad():
@@ -125,7 +125,7 @@ def main():
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     model = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300)
-    sd = synth_weights(model.state_dict(), args.arch, seed=0, head_gain=1.0)
+    sd = synth_weights(model.state_dict(), args.arch, seed=0)
     model.load_state_dict(sd)
     model = model.to(dev).to(dtype).eval()
 

@@ -80,7 +80,7 @@ def anchors_decode_golden():
              rnd_ho0=ho3[0].numpy(), rnd_ho1=ho3[1].numpy(), rnd_pred=pred3.numpy())
 
 
-def e2e_golden(arch="yolov5_darknet_pan_n_r60", tag="n", sizes=((160, 120), (96, 160), (128, 128)), S=160, head_gain=2.0, thr=0.2):
+def e2e_golden(arch="yolov5_darknet_pan_n_r60", tag="n", sizes=((160, 120), (96, 160), (128, 128)), S=160, head_gain=1.0, thr=0.1):
     model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr, nms_thresh=0.45)
     sd = synth_weights(model.state_dict(), arch, seed=0, head_gain=head_gain)
     model.load_state_dict(sd)

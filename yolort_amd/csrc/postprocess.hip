@@ -203,41 +203,63 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* hi, con
     hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// single block, 256 threads: thread d owns digit d.  hist[b][d] -> exclusive global offset.
-__global__ __launch_bounds__(256) void radix_scan_kernel(const int* status, int cap, uint32_t* hist) {
-    __shared__ unsigned tot[256];
+// One block per digit d (256 blocks): exclusive scan of hist[b][d] over the blocks b of the pass,
+// 256 entries per sweep (wave shuffles + LDS), total of the digit left in tot[d].  The scatter
+// kernel turns tot[] into digit bases itself (a 256-value LDS scan), so the serial chain of the
+// classic single-block scan is gone.
+__global__ __launch_bounds__(256) void radix_scan_kernel(const int* status, int cap, uint32_t* hist, uint32_t* tot) {
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned carry_s;
     const int n = ncand(status, cap);
     const int nblk = cdiv(n, SORT_ITEMS);
-    const int d = threadIdx.x;
-    unsigned run = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const unsigned c = hist[(int64_t)b * 256 + d];
-        hist[(int64_t)b * 256 + d] = run;
-        run += c;
-    }
-    tot[d] = run;
+    const int d = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry_s = 0;
     __syncthreads();
-    // exclusive scan over digits (256 values): simple Hillis-Steele in LDS
-    for (int s = 1; s < 256; s <<= 1) {
-        unsigned v = d >= s ? tot[d - s] : 0;
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+        const int b = b0 + t;
+        const unsigned c = b < nblk ? hist[(int64_t)b * 256 + d] : 0u;
+        unsigned incl = c;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const unsigned v = __shfl_up(incl, s, 64);
+            if (lane >= s) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        tot[d] += v;
+        unsigned off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (b < nblk) hist[(int64_t)b * 256 + d] = off + incl - c;
+        __syncthreads();
+        if (t == 255) carry_s = off + incl;
         __syncthreads();
     }
-    const unsigned dbase = tot[d] - run;
-    for (int b = 0; b < nblk; ++b) hist[(int64_t)b * 256 + d] += dbase;
+    if (t == 0) tot[d] = carry_s;
 }
 
 // scatter: wave w of the block owns the contiguous records [base + w*512, +512), 8 rounds of 64.
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* hi_in, const uint32_t* lo_in, uint64_t* hi_out, uint32_t* lo_out,
-                                                            const int* status, int cap, int shift, const uint32_t* hist) {
+                                                            const int* status, int cap, int shift, const uint32_t* hist, const uint32_t* tot) {
     __shared__ unsigned wave_hist[4][256];
     __shared__ unsigned wave_base[4][256];
+    __shared__ unsigned dsum[256];
     const int n = ncand(status, cap);
     const int base = blockIdx.x * SORT_ITEMS;
     if (base >= n) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 1024; i += 256) (&wave_hist[0][0])[i] = 0;
+    {   // digit bases: inclusive scan of the 256 digit totals (Hillis-Steele in LDS)
+        const int d = threadIdx.x;
+        const unsigned mine = tot[d];
+        dsum[d] = mine;
+        __syncthreads();
+        for (int st = 1; st < 256; st <<= 1) {
+            const unsigned v = d >= st ? dsum[d - st] : 0u;
+            __syncthreads();
+            dsum[d] += v;
+            __syncthreads();
+        }
+        dsum[d] -= mine;  // exclusive
+    }
     __syncthreads();
     uint64_t rhi[8];
     uint32_t rlo[8];
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* hi_i
     __syncthreads();
     {
         const int d = threadIdx.x;
-        unsigned run = hist[(int64_t)blockIdx.x * 256 + d];
+        unsigned run = hist[(int64_t)blockIdx.x * 256 + d] + dsum[d];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             wave_base[w][d] = run;
@@ -478,8 +500,9 @@ static int radix_pass(const Workspace& w, SortState& st, int* status, int cap, i
     const int nblk = cdiv(cap, SORT_ITEMS);
     const int src = st.cur, dst = st.cur ^ 1;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, s, w.hi[src], w.lo[src], status, cap, shift, w.hist);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(256), 0, s, status, cap, w.hist);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, s, w.hi[src], w.lo[src], w.hi[dst], w.lo[dst], status, cap, shift, w.hist);
+    uint32_t* tot = w.hist + (int64_t)nblk * 256;  // 256 words after the per-block table
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, s, status, cap, w.hist, tot);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, s, w.hi[src], w.lo[src], w.hi[dst], w.lo[dst], status, cap, shift, w.hist, tot);
     st.cur = dst;
     return check_launch("radix pass");
 }

@@ -175,6 +175,66 @@ __global__ __launch_bounds__(256) void spp_pool_kernel(uint16_t* buf, int n, int
     *reinterpret_cast<u32x4*>(o + 3 * c) = o13;
 }
 
+// LDS cascade form of the same pyramid: one block per (image, 8-channel chunk).  The h x w plane of
+// those 8 channels is staged in LDS as fp32 and three 5x5 max stages are applied back to back, each
+// separable (row pass then column pass): mp9 = mp5(mp5(x)), mp13 = mp5(mp9) -- the SPPF identity of
+// the reference (common.py:196), exact because max is exact.  10 taps per stage instead of a
+// 169-tap window, and the plane is read from HBM once.
+template <int DT>
+__global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h, int w, int c, int cs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hw = h * w;
+    float* A = sm;
+    float* B = sm + (size_t)hw * 8;
+    float* Cb = sm + (size_t)hw * 16;
+    const int c8 = c / 8;
+    const int img = blockIdx.x / c8, cc = (blockIdx.x % c8) * 8;
+    uint16_t* base = buf + (int64_t)img * hw * cs + cc;
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)p * cs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) A[p * 8 + e] = from16<DT>((uint16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+    }
+    __syncthreads();
+    float* src = A;
+    float* dst = Cb;
+    for (int stage = 0; stage < 3; ++stage) {
+        for (int p = threadIdx.x; p < hw; p += 256) {  // row pass: src -> B
+            const int y = p / w, x = p - y * w;
+            const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 > w - 1 ? w - 1 : x + 2;
+            float m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+            for (int xx = x0; xx <= x1; ++xx)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], src[(y * w + xx) * 8 + e]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) B[p * 8 + e] = m[e];
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < hw; p += 256) {  // column pass: B -> dst, and out to HBM
+            const int y = p / w, x = p - y * w;
+            const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 > h - 1 ? h - 1 : y + 2;
+            float m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+            for (int yy = y0; yy <= y1; ++yy)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], B[(yy * w + x) * 8 + e]);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (uint32_t)to16<DT>(m[2 * e]) | ((uint32_t)to16<DT>(m[2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>(base + (int64_t)p * cs + (stage + 1) * c) = o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[p * 8 + e] = m[e];
+        }
+        __syncthreads();
+        float* t = src;  // ping-pong A <-> Cb (B is the row-pass scratch)
+        src = dst;
+        dst = t;
+    }
+}
+
 // nearest x2 upsample: one thread per (input pixel, 8 channels) -> 4 output pixels
 __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* x, int x_cs, int n, int h, int w, int c, uint16_t* y, int y_cs) {
     const int c8 = c / 8;
@@ -284,6 +344,19 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
     YMI_REQUIRE(buf && c % 8 == 0 && cstride >= 4 * c && cstride % 8 == 0, "ymi_spp_pool: c %% 8 == 0 and cstride >= 4c required");
     const int64_t total = (int64_t)n * h * w * (c / 8);
     if (total == 0) return YMI_OK;
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_spp_pool: dtype must be F16/BF16");
+    const size_t lds = (size_t)h * w * 8 * 4 * 3;
+    if (lds <= 160 * 1024 - 512) {  // whole plane of 8 channels fits the 160 KB LDS three times
+        dim3 g((unsigned)(n * (c / 8))), b(256);
+        if (dtype == YMI_F16) {
+            if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)spp_pool_lds_kernel<YMI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((spp_pool_lds_kernel<YMI_F16>), g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
+        } else {
+            if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)spp_pool_lds_kernel<YMI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((spp_pool_lds_kernel<YMI_BF16>), g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
+        }
+        return check_launch("spp_pool_lds_kernel");
+    }
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (dtype == YMI_F16) hipLaunchKernelGGL((spp_pool_kernel<YMI_F16>), grid, block, 0, (hipStream_t)stream, (uint16_t*)buf, n, h, w, c, cstride);
     else if (dtype == YMI_BF16) hipLaunchKernelGGL((spp_pool_kernel<YMI_BF16>), grid, block, 0, (hipStream_t)stream, (uint16_t*)buf, n, h, w, c, cstride);

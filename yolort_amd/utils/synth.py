@@ -33,7 +33,7 @@ def _fp16_round(a: np.ndarray) -> np.ndarray:
 def synth_state_dict(
     template: Dict[str, torch.Tensor],
     seed: int = 0,
-    head_gain: float = 1.0,
+    head_gain: float = 0.5,
     obj_bias: float = -4.0,
     cls_bias: float = -1.0,
     num_outputs: int = 85,
