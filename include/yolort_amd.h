@@ -84,6 +84,7 @@ int ymi_nhwc_to_nchw(const void* x, int x_cstride, int n, int c, int h, int w, i
  *            for every 8-channel chunk (built by ymi_conv_build_ktab); entries past K are {0,-1}
  *   y        NHWC view (n,ho,wo,cout) with pixel stride y_cstride, dtype out_dtype (dtype or F32)
  *   res      optional residual view, same shape as y, dtype `dtype` (NULL = none); added AFTER act
+ *            (not combinable with y2)
  * ---------------------------------------------------------------------------------------- */
 typedef struct ymi_conv_desc {
     const void* x;
@@ -97,6 +98,15 @@ typedef struct ymi_conv_desc {
     int32_t kh, kw, sh, sw, ph, pw, k_pad;
     int32_t act, dtype, out_dtype;
     int32_t tile; /* 0 = auto, else forces a tile configuration (tuning / tests) */
+    /* optional second output: output channels [cout_split, cout) go to view y2 (channel 0 of y2 =
+     * channel cout_split); lets one launch serve two consumers of the same input (C3.cv1 + C3.cv2,
+     * reference common.py:172-173).  cout_split == 0 disables; must be a multiple of 8. */
+    void* y2;
+    int32_t y2_cstride, cout_split;
+    /* >= 256 readable zero bytes in device memory: source of out-of-image / out-of-range operand
+     * chunks for the direct-to-LDS loads of the pipelined kernel (NULL selects the register-staged
+     * kernel, which needs none) */
+    const void* zeros;
 } ymi_conv_desc;
 
 int ymi_conv2d(const ymi_conv_desc* d, void* stream);

@@ -97,8 +97,9 @@ def test_conv_parity(dev, dtype, cfg):
     _run_conv(dev, dtype, **cfg)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, -1, -2, -3, -4, -5])
 def test_conv_tiles(dev, tile):
+    """positive ids: LDS-DMA pipelined kernel (v2) tile configurations; negative: register-staged (v1)"""
     _run_conv(dev, torch.float16, n=2, cin=64, cout=128, h=37, w=29, k=3, s=1, p=1, tile=tile)
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=37, w=29, k=1, s=1, p=0, tile=tile, residual=True)
 
@@ -106,6 +107,35 @@ def test_conv_tiles(dev, tile):
 def test_conv_views_and_residual(dev):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=20, w=20, k=3, s=1, p=1, residual=True, x_cs_extra=64, y_cs_extra=128)
     _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)
+
+
+def test_conv_second_output(dev):
+    """one launch, two destinations: couts [0,32) -> y, [32,64) -> channel slice of another buffer (C3 cv1+cv2)"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 64, 24, 20, generator=g).half().float()
+    wt = (torch.randn(64, 64, 1, 1, generator=g) / 8).half().float()
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x, wt, b))
+    plan = engine.Plan(dev, torch.float16)
+    xv = plan.alloc(2, 24, 20, 64)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+    y = plan.alloc(2, 24, 20, 32)
+    cat = plan.alloc(2, 24, 20, 64, zero=True)
+    plan.conv(xv, engine.PackedConv(wt, b, None, torch.float16, dev), 1, 0, out=y, out2=cat.slice_c(32, 32), split=32)
+    plan.run()
+    got1 = y.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    got2 = cat.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    assert (got1 - ref[:, :32]).abs().max().item() < 2e-2
+    assert (got2[:, 32:] - ref[:, 32:]).abs().max().item() < 2e-2
+    assert got2[:, :32].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("k,s,p,cin,cout,hw", [(1, 1, 0, 64, 32, 160), (3, 1, 1, 32, 32, 96), (3, 2, 1, 32, 64, 128), (3, 1, 1, 128, 128, 40), (1, 1, 0, 512, 256, 20)])
+def test_conv_v1_v2_agree_at_scale(dev, k, s, p, cin, cout, hw):
+    """larger, multi-block problems: pipelined (v2) and register-staged (v1) kernels against torch fp32"""
+    for tile in (0, -100):
+        _run_conv(dev, torch.float16, n=2, cin=cin, cout=cout, h=hw, w=hw, k=k, s=s, p=p, tile=tile, seed=k + cin)
 
 
 def test_conv_head_fp32_out(dev):

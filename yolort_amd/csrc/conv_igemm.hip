@@ -55,6 +55,9 @@ struct ConvArgs {
     int act;
     int M;         // n*ho*wo
     int nblk_m, nblk_n;
+    void* y2;      // second output view for couts >= split (0 = off)
+    int y2_cs, split;
+    const uint16_t* zeros;
 };
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
@@ -246,6 +249,298 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+
+// =============================================================================================
+// v2: LDS-DMA pipelined variant.  Same tiling and MFMA mapping as above, but operand tiles travel
+// HBM -> LDS with `global_load_lds_dwordx4` (no VGPR round trip) into a STAGES-deep ring, so
+// STAGES-1 k-steps of loads are in flight behind the MFMAs and there is ONE barrier per k-step
+// (cdna_hip_programming.md section 5: counted vmcnt + raw s_barrier; all LDS in one array).
+//   * a wave-instruction moves 64 lanes x 16 B = 1 KiB to LDS base + lane*16: 16 tile rows x 64 B.
+//     LDS rows are therefore dense (64 B), and bank conflicts of the fragment reads are removed by
+//     an XOR swizzle applied on the SOURCE side: lane (row, pos) fetches k-chunk pos ^ ((row>>2)&3),
+//     the reader of chunk c looks at position c ^ ((row>>2)&3) (rule 21: linear dest, permuted
+//     source, same involution on the read).
+//   * out-of-image taps, rows past M / cout_pad and K padding read from a zero page instead of
+//     branching, so every lane always issues its load (LDS slots must be overwritten each round).
+//   * the im2col table lives in LDS (ds_read, lgkmcnt) so that no ordinary VMEM load sits in the
+//     main loop -- hipcc would otherwise drain the DMA queue with vmcnt(0) at its first use.
+// Epilogue: bias + SiLU (+ residual) in fp32, then lanes l / l+32 exchange halves with
+// v_permlane32_swap so that each lane stores 8 consecutive output channels (16 B) per store.
+// =============================================================================================
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void glds16(const uint16_t* g, uint16_t* lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1>
+__global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert(BM % 64 == 0, "activation pieces are dealt 1:1 to the 4 waves");
+    constexpr int PA = BM / 64;                  // activation pieces (1 KiB = 16 rows) per wave per stage
+    constexpr int W_PIECES = BN / 16;            // weight pieces per stage (all waves together)
+    constexpr int PW = (W_PIECES + 3) / 4;       // weight pieces per wave per stage
+    constexpr int P = PA + PW;                   // DMA instructions per wave per stage (same for every wave)
+    constexpr int STAGE_HALFS = (BM + BN) * 32;  // uint16 elements per stage
+    typedef typename Mfma<DT>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // the ONLY LDS object
+    int2* ktab_lds = reinterpret_cast<int2*>(smem + STAGES * STAGE_HALFS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = (wave / WAVES_N) * WM, wave_n = (wave % WAVES_N) * WN;
+
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int bm = lb / a.nblk_n, bn = lb % a.nblk_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nsteps = a.k_pad / BK;
+
+    if constexpr (!IS1X1) {
+        for (int i = tid; i < a.k_pad / 8; i += 256) ktab_lds[i] = a.ktab[i];
+    }
+
+    // ---- per-lane DMA geometry.  Wave w moves activation pieces w*PA .. w*PA+PA-1 (16 rows each) and
+    //      weight pieces w*PW .. (clamped: surplus waves re-send the last piece, identical bytes). ----
+    const int sub_row = lane >> 2;                         // row within the piece
+    const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // k-chunk fetched = pos ^ ((row>>2)&3)
+    const int64_t zdelta_x = a.zeros - a.x;                // element distance to the zero page
+    const int64_t zdelta_w = a.zeros - a.w;
+    int a_off[PA], a_iyx[PA];     // element offset of (img, iy0, ix0, 0); packed (iy0+16384)<<16 | (ix0+16384), <0 = row past M
+    int a_slot[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int pi = wave * PA + j;
+        a_slot[j] = pi * 512;
+        const int m = m0 + pi * 16 + sub_row;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int img = mm / (a.ho * a.wo);
+        const int rem = mm - img * (a.ho * a.wo);
+        const int oy = rem / a.wo, ox = rem - oy * a.wo;
+        const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+        a_off[j] = ((img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
+        a_iyx[j] = ok ? (((iy0 + 16384) << 16) | ((ix0 + 16384) & 0xffff)) : -1;
+    }
+    int64_t w_off[PW];            // element offset of (row, chunk*8) in the packed weights, or the zero page
+    int w_slot[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        int pi = wave * PW + j;
+        pi = pi < W_PIECES ? pi : W_PIECES - 1;
+        w_slot[j] = (BM / 16 + pi) * 512;
+        const int r = n0 + pi * 16 + sub_row;
+        w_off[j] = (int64_t)r * a.k_pad + chunk * 8;
+    }
+    bool w_valid[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        int pi = wave * PW + j;
+        pi = pi < W_PIECES ? pi : W_PIECES - 1;
+        w_valid[j] = (n0 + pi * 16 + sub_row) < a.cout_pad;
+    }
+
+    auto issue = [&](int step) {
+        uint16_t* stage = smem + (step % STAGES) * STAGE_HALFS;
+        int koff, dy = 0, dx = 0;
+        bool tap_ok;
+        if constexpr (IS1X1) {
+            koff = (step * 4 + chunk) * 8;
+            tap_ok = koff < a.cin;
+        } else {
+            const int2 t = ktab_lds[step * 4 + chunk];
+            koff = t.x;
+            tap_ok = t.y >= 0;
+            dy = t.y >> 16;
+            dx = t.y & 0xffff;
+        }
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            bool ok = tap_ok & (a_iyx[j] >= 0);
+            if constexpr (!IS1X1) {
+                const int iy = (a_iyx[j] >> 16) - 16384 + dy, ix = (a_iyx[j] & 0xffff) - 16384 + dx;
+                ok = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w_in);
+            }
+            const int64_t d = ok ? (int64_t)(a_off[j] + koff) : zdelta_x;   // v_cndmask, no branch
+            glds16(a.x + d, stage + a_slot[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int64_t d = w_valid[j] ? w_off[j] + step * BK : zdelta_w;
+            glds16(a.w + d, stage + w_slot[j]);
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if constexpr (!IS1X1) __syncthreads();   // ktab visible (no DMA in flight yet: plain barrier is fine)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nsteps) issue(s);
+
+    const int frow = lane & 31;
+    const int swz = (lane >> 2) & 3;
+    int pos[2];
+    pos[0] = ((0 + (lane >> 5)) ^ swz) * 8;   // element offset of this lane's k-chunk, ks = 0
+    pos[1] = ((2 + (lane >> 5)) ^ swz) * 8;   // ks = 1
+
+    for (int step = 0; step < nsteps; ++step) {
+        // this wave's pieces of stage `step` have landed once at most `ahead` later stages are pending
+        const int issued = (step + STAGES - 1 < nsteps) ? step + STAGES - 1 : nsteps;
+        const int ahead = issued - (step + 1);
+        if (ahead >= 2) wait_vmcnt<2 * P>();
+        else if (ahead == 1) wait_vmcnt<P>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();          // every wave's pieces landed; everyone is done with stage step-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (step + STAGES - 1 < nsteps) issue(step + STAGES - 1);   // refill the slot freed by step-1
+        const uint16_t* as = smem + (step % STAGES) * STAGE_HALFS + wave_m * 32;
+        const uint16_t* ws = smem + (step % STAGES) * STAGE_HALFS + (BM + wave_n) * 32;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag af[TM], wf[TN];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const frag*>(as + (j * 32 + frow) * 32 + pos[ks]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(ws + (i * 32 + frow) * 32 + pos[ks]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(wf[i], af[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue ----
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wave_m + j * 32 + frow;
+        const bool m_ok = m < a.M;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int cbase = n0 + wave_n + i * 32;   // wave-uniform
+            if (cbase >= a.cout) continue;
+            float v[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cbase + g * 8 + hi * 4;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (co < a.cout) b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][g * 4 + e] + b[e];
+                    if (a.act == YMI_ACT_SILU) t = silu(t);
+                    v[g][e] = t;
+                }
+                if (a.res != nullptr && m_ok && co < a.cout) {
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (int64_t)m * a.res_cs + co);
+                    v[g][0] += from16<DT>((uint16_t)(rv[0] & 0xffff));
+                    v[g][1] += from16<DT>((uint16_t)(rv[0] >> 16));
+                    v[g][2] += from16<DT>((uint16_t)(rv[1] & 0xffff));
+                    v[g][3] += from16<DT>((uint16_t)(rv[1] >> 16));
+                }
+            }
+            if constexpr (ODT == YMI_F32) {
+                if (!m_ok) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cbase + g * 8 + hi * 4;
+                    if (co >= a.cout) continue;
+                    float* yp = reinterpret_cast<float*>(a.y) + (int64_t)m * a.y_cs + co;
+                    if (co + 3 < a.cout) {
+                        f32x4 o = {v[g][0], v[g][1], v[g][2], v[g][3]};
+                        *reinterpret_cast<f32x4*>(yp) = o;
+                    } else {
+                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[g][e];
+                    }
+                }
+            } else {
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
+                    pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
+                }
+                const bool wide = (cbase + 32 <= a.cout) && ((a.split & 7) == 0);   // wave-uniform
+                if (wide) {
+                    // groups (g, g+1): lanes < 32 end with cols [g*8, g*8+8), lanes >= 32 with [(g+1)*8, (g+1)*8+8)
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        uint32_t ax = pk[g][0], ay = pk[g][1], bx = pk[g + 1][0], by = pk[g + 1][1];
+                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                        ax = rx[0]; bx = rx[1];
+                        ay = ry[0]; by = ry[1];
+                        if (m_ok) {
+                            const int co = cbase + (g + hi) * 8;
+                            uint16_t* yp;
+                            if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co - a.split);
+                            else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
+                            u32x4 o = {ax, ay, bx, by};
+                            *reinterpret_cast<u32x4*>(yp) = o;
+                        }
+                    }
+                } else if (m_ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = cbase + g * 8 + hi * 4;
+                        if (co >= a.cout) continue;
+                        uint16_t* yp;
+                        if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co - a.split);
+                        else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
+                        if (co + 3 < a.cout) {
+                            u32x2 o = {pk[g][0], pk[g][1]};
+                            *reinterpret_cast<u32x2*>(yp) = o;
+                        } else {
+                            for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[g][e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
+    ConvArgs a = a0;
+    a.nblk_m = cdiv(a.M, BM);
+    a.nblk_n = cdiv(a.cout_pad, BN);
+    const size_t lds = (size_t)STAGES * (BM + BN) * 64 + (is1x1 ? 0 : (size_t)a.k_pad) + 16;
+    dim3 grid(a.nblk_m * a.nblk_n), block(256);
+    if (is1x1) {
+        auto kfn = conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, true>;
+        if (lds > 64 * 1024) {
+            static bool done = false;
+            if (!done) { YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+        }
+        hipLaunchKernelGGL(kfn, grid, block, lds, s, a);
+    } else {
+        auto kfn = conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false>;
+        if (lds > 64 * 1024) {
+            static bool done = false;
+            if (!done) { YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+        }
+        hipLaunchKernelGGL(kfn, grid, block, lds, s, a);
+    }
+    return check_launch("conv_igemm_v2_kernel");
+}
+
 template <int DT, int ODT, int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     ConvArgs a = a0;
@@ -262,6 +557,8 @@ static int launch_cfg(const ConvArgs& a0, bool is1x1, hipStream_t s) {
 // tile ids: 1 = 128x128, 2 = 256x64, 3 = 256x32, 4 = 64x128, 5 = 128x64, 6 = 64x64... keep small
 template <int DT, int ODT>
 static int launch_dtype(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) {
+    const bool force_v1 = tile < 0;
+    if (force_v1) tile = -tile == 100 ? 0 : -tile;   // negative tile ids force the register-staged kernel (-100 = auto)
     if (tile == 0) {
         const int cp = a.cout_pad;
         if (cp <= 32) tile = 3;
@@ -273,7 +570,17 @@ static int launch_dtype(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) 
             if (cp % 128 != 0 && cp % 64 == 0 && cp < 128) tile = 2;
         }
     }
+    if (tile < 10 && a.zeros != nullptr && !force_v1) tile += 10;   // pipelined kernel whenever a zero page is supplied
+    if (tile >= 10 && a.zeros == nullptr) {
+        set_error("ymi_conv2d: tile %d (pipelined kernel) needs desc.zeros", tile);
+        return YMI_EINVAL;
+    }
     switch (tile) {
+        case 11: return launch_v2<DT, ODT, 128, 128, 64, 64, 4>(a, is1x1, s);
+        case 12: return launch_v2<DT, ODT, 256, 64, 64, 64, 3>(a, is1x1, s);
+        case 13: return launch_v2<DT, ODT, 256, 32, 64, 32, 3>(a, is1x1, s);
+        case 14: return launch_v2<DT, ODT, 64, 128, 32, 64, 4>(a, is1x1, s);
+        case 15: return launch_v2<DT, ODT, 128, 64, 64, 32, 4>(a, is1x1, s);
         case 1: return launch_cfg<DT, ODT, 128, 128, 64, 64>(a, is1x1, s);
         case 2: return launch_cfg<DT, ODT, 256, 64, 64, 64>(a, is1x1, s);
         case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(a, is1x1, s);
@@ -307,6 +614,16 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     a.ho = d->ho; a.wo = d->wo; a.cout = d->cout; a.cout_pad = d->cout_pad; a.y_cs = d->y_cstride; a.res_cs = d->res_cstride;
     a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw; a.k_pad = d->k_pad; a.act = d->act;
     a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
+    a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
+    YMI_REQUIRE(a.split == 0 || (d->y2 != nullptr && a.split % 8 == 0 && a.split < d->cout && d->res == nullptr && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0),
+                "ymi_conv2d: invalid second-output configuration");
+    YMI_REQUIRE(a.split == 0 || a.zeros != nullptr, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");
+    if (a.zeros != nullptr) {
+        // 32-bit element offsets inside the pipelined kernel
+        YMI_REQUIRE((int64_t)d->n * d->h * d->w_in * d->x_cstride < ((int64_t)1 << 31) && (int64_t)d->cout_pad * d->k_pad < ((int64_t)1 << 31),
+                    "ymi_conv2d: tensor too large for the pipelined kernel's 32-bit offsets");
+        YMI_REQUIRE(d->y_cstride % 8 == 0 || d->out_dtype == YMI_F32, "ymi_conv2d: y_cstride must be a multiple of 8");
+    }
     if (a.M == 0) return YMI_OK;
     if (d->dtype == YMI_F16) {
         if (d->out_dtype == YMI_F32) return launch_dtype<YMI_F16, YMI_F32>(a, is1x1, d->tile, s);

@@ -12,6 +12,7 @@ path_aggregation_network.py:224,235) disappears: producers write straight into t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -135,6 +136,9 @@ class Plan:
         self.meta: List[dict] = []        # per-op algorithmic flops/bytes for roofline accounting
         self.bytes_allocated = 0
         self.stream: Optional[torch.cuda.Stream] = None
+        # zero page for the pipelined conv kernel's out-of-range operand chunks (see yolort_amd.h)
+        self.zeros = torch.zeros(1024, device=device, dtype=torch.uint8)
+        self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
 
     def __del__(self):
         try:
@@ -159,7 +163,8 @@ class Plan:
         self.meta.append(meta)
 
     # ---- ops ----
-    def conv_desc(self, x: View, pc: PackedConv, stride: Tuple[int, int], pad: Tuple[int, int], act: int, y: View, res: Optional[View], tile: int = 0) -> ConvDesc:
+    def conv_desc(self, x: View, pc: PackedConv, stride: Tuple[int, int], pad: Tuple[int, int], act: int, y: View, res: Optional[View], tile: int = 0,
+                  y2: Optional[View] = None, split: int = 0) -> ConvDesc:
         d = ConvDesc()
         d.x, d.w, d.bias = x.ptr, pc.w.data_ptr(), pc.bias.data_ptr()
         is1x1 = pc.kh == 1 and pc.kw == 1 and stride == (1, 1) and pad == (0, 0)
@@ -172,11 +177,19 @@ class Plan:
         d.res_cstride = 0 if res is None else res.cs
         d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = pc.kh, pc.kw, stride[0], stride[1], pad[0], pad[1], pc.k_pad
         d.act, d.dtype, d.out_dtype, d.tile = act, dtype_code(pc.dtype), dtype_code(y.dtype), tile
+        d.y2 = None if y2 is None else y2.ptr
+        d.y2_cstride, d.cout_split = (0, 0) if y2 is None else (y2.cs, split)
+        d.zeros = None if (self.use_v1 and y2 is None) else self.zeros.data_ptr()
+        if self.use_v1 and y2 is None and tile == 0:
+            d.tile = -100
         self.keep.extend([pc, kt, d])
         return d
 
     def conv(self, x: View, pc: PackedConv, stride: int | Tuple[int, int] = 1, pad: int | Tuple[int, int] = 0, act: int = ACT_SILU,
-             out: Optional[View] = None, res: Optional[View] = None, out_dtype: Optional[torch.dtype] = None, name: str = "conv", tile: int = 0) -> View:
+             out: Optional[View] = None, res: Optional[View] = None, out_dtype: Optional[torch.dtype] = None, name: str = "conv", tile: int = 0,
+             out2: Optional[View] = None, split: int = 0) -> View:
+        """`out2`/`split`: output channels [split, cout) are written to view `out2` instead of `out`
+        (one launch feeding two consumers of the same input, e.g. C3.cv1 + C3.cv2)."""
         s = (stride, stride) if isinstance(stride, int) else tuple(stride)
         p = (pad, pad) if isinstance(pad, int) else tuple(pad)
         if pc.stem_superpixel:
@@ -188,15 +201,23 @@ class Plan:
             raise YmiError(f"{name}: input view has {x.c} channels, packed weights expect {pc.cin}")
         ho, wo = conv_out_hw(x.h, x.w, (pc.kh, pc.kw), s, p)
         if out is None:
+            assert out2 is None
             cpad = _round_up(pc.cout, 8)
             out = self.alloc(x.n, ho, wo, cpad, out_dtype, zero=cpad != pc.cout).slice_c(0, pc.cout) if cpad != pc.cout else self.alloc(x.n, ho, wo, pc.cout, out_dtype)
-        if (out.n, out.h, out.w, out.c) != (x.n, ho, wo, pc.cout):
-            raise YmiError(f"{name}: output view {(out.n, out.h, out.w, out.c)} != expected {(x.n, ho, wo, pc.cout)}")
-        d = self.conv_desc(x, pc, s, p, act, out, res, tile)
+        c_first = split if out2 is not None else pc.cout
+        if (out.n, out.h, out.w, out.c) != (x.n, ho, wo, c_first):
+            raise YmiError(f"{name}: output view {(out.n, out.h, out.w, out.c)} != expected {(x.n, ho, wo, c_first)}")
+        if out2 is not None and (out2.n, out2.h, out2.w, out2.c) != (x.n, ho, wo, pc.cout - split):
+            raise YmiError(f"{name}: second output view has the wrong shape")
+        d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
+        # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
+        # output once; a fused cv1+cv2 launch stands for two reference convs, so its input counts twice.
+        ref_reads = 2 if out2 is not None else 1
         self._record(self.lib.ymi_plan_add_conv(self.handle, C.byref(d)), name, kind="conv",
-                     flops=flops, bytes=float(x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz),
+                     flops=flops, bytes=float(ref_reads * x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz),
+                     ref_convs=ref_reads,
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
 

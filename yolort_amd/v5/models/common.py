@@ -94,15 +94,37 @@ class C3(HipModule):
         self.cv2 = Conv(c1, c_, 1, 1, version=version)
         self.cv3 = Conv(2 * c_, c2, 1, version=version)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, version=version) for _ in range(n)])
+        self._pair: Dict[Tuple, Tuple] = {}
+
+    def packed_pair(self, dtype: torch.dtype, device: torch.device, cin_view: int) -> PackedConv:
+        """cv1 and cv2 read the same input: their folded weights are stacked along cout so ONE launch
+        computes both (the kernel's second-output feature routes cv2's half into the concat buffer)."""
+        mods = (self.cv1, self.cv2)
+        sig = tuple(t._version for m in mods for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)) + (self.cv1.conv.weight.data_ptr(),)
+        key = (dtype, device, cin_view)
+        hit = self._pair.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        cat = lambda f: torch.cat([f(m) for m in mods])  # noqa: E731
+        bn = (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), float(self.cv1.bn.eps))
+        pc = PackedConv(cat(lambda m: m.conv.weight), None, bn, dtype, device, cin_pad=cin_view)
+        self._pair[key] = (sig, pc)
+        return pc
 
     def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "c3") -> View:
         c_ = self.cv1.conv.out_channels
         cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
         nb = len(self.m)
-        y = self.cv1.emit(plan, x, out=cat.slice_c(0, c_) if nb == 0 else None, name=name + ".cv1")
+        fuse = (not plan.use_v1) and c_ % 8 == 0 and nb >= 1 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
+        if fuse:
+            y = plan.alloc(x.n, x.h, x.w, c_)
+            plan.conv(x, self.packed_pair(plan.dtype, plan.device, x.c), 1, 0, ACT_SILU, out=y, out2=cat.slice_c(c_, c_), split=c_, name=name + ".cv1+cv2")
+        else:
+            y = self.cv1.emit(plan, x, out=cat.slice_c(0, c_) if nb == 0 else None, name=name + ".cv1")
         for j, b in enumerate(self.m):
             y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}")
-        self.cv2.emit(plan, x, out=cat.slice_c(c_, c_), name=name + ".cv2")
+        if not fuse:
+            self.cv2.emit(plan, x, out=cat.slice_c(c_, c_), name=name + ".cv2")
         return self.cv3.emit(plan, cat, out=out, name=name + ".cv3")
 
 
