@@ -136,18 +136,29 @@ def main():
     yolo = model.model
     stream = torch.cuda.current_stream()
 
-    def step():
-        dets = model.forward(images_gpu)
+    # serving loop with two batches in flight: submit batch i+1, then collect batch i (its sort/NMS tail
+    # and the host-side result handling overlap the convolutions of batch i+1).  Every submitted batch
+    # is collected inside the timed region.
+    def run_steps(k):
+        pending, dets = None, None
+        for _ in range(k):
+            p = model.forward_async(images_gpu)
+            if pending is not None:
+                dets = collect(pending)
+            pending = p
+        return collect(pending)
+
+    def collect(p):
+        dets = p.result()
         if world > 1:
-            e = next(iter(yolo._entries.values()))
+            e = p.entry
             ydist.all_gather_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count)
         return dets
 
-    for _ in range(args.warmup):
-        dets = step()
+    dets = run_steps(max(args.warmup, 1))
     torch.cuda.synchronize()
     e = next(iter(yolo._entries.values()))
-    n_conv_ops = sum(1 for m in e.plan.meta if m["kind"] != "post")
+    n_conv_ops = e.n_conv_ops
     # conv-stack bracket events (recorded on the plan's stream inside the timed region)
     yolo.bracket = (n_conv_ops, [], [])
 
@@ -157,8 +168,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dets = step()
+    dets = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -103,9 +103,10 @@ typedef struct ymi_conv_desc {
      * reference common.py:172-173).  cout_split == 0 disables; must be a multiple of 8. */
     void* y2;
     int32_t y2_cstride, cout_split;
-    /* >= 256 readable zero bytes in device memory: source of out-of-image / out-of-range operand
-     * chunks for the direct-to-LDS loads of the pipelined kernel (NULL selects the register-staged
-     * kernel, which needs none) */
+    /* >= 256 readable zero bytes in device memory within +-4 GiB of x (e.g. the tail of x's own
+     * buffer): source of out-of-image / out-of-range activation chunks for the direct-to-LDS loads of
+     * the pipelined kernel, which also requires the packed weight ROWS to be zero-padded to a
+     * multiple of 128 (NULL selects the register-staged kernel, which needs neither) */
     const void* zeros;
 } ymi_conv_desc;
 

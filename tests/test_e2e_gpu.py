@@ -105,7 +105,7 @@ def test_yolov5n_against_reference_golden(dev, golden_dir, dtype):
         frac, miou, ds = match_fraction(ref, _np(d), iou_thr=0.5, score_tol=0.15 if loose else 0.05, margin=0.1 if loose else 0.03, thr=thr)
         print(f"image {i}: matched {frac:.3f} median IoU {miou:.4f} max dscore {ds:.4f}")
         assert frac >= (0.6 if loose else 0.93), f"image {i}: only {frac:.3f} of reference detections matched"
-        assert miou >= (0.8 if loose else 0.93)
+        assert miou >= (0.7 if loose else 0.93)
 
 
 def test_postprocess_exact_given_oracle_logits(dev, golden_dir):

@@ -24,6 +24,9 @@ namespace ymi {
 
 constexpr int BK = 32;          // k elements per main-loop step
 constexpr int LDS_PITCH = 40;   // halfs per LDS row (32 + 8 pad) = 80 bytes
+// v2 epilogue flavour: false = direct 16-byte stores from the MFMA layout after a permlane32 swap,
+// true = stage the tile through LDS and write whole pixel rows (measured slower on yolov5s: -4%)
+constexpr bool STAGED_EPILOGUE = false;
 
 template <int DT>
 struct Mfma;
@@ -58,6 +61,9 @@ struct ConvArgs {
     void* y2;      // second output view for couts >= split (0 = off)
     int y2_cs, split;
     const uint16_t* zeros;
+    int x_zero_off;    // (zeros - x) in elements: out-of-range activation chunks read x + x_zero_off
+    int kh, kw;
+    int debug;         // tuning aid: bit0 = skip LDS reads + MFMA, bit1 = skip operand loads (results are garbage)
 };
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
@@ -277,7 +283,8 @@ __device__ __forceinline__ void glds16(const uint16_t* g, uint16_t* lds_wave_uni
                                      (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1>
+// UTAP (uniform tap): cin % 32 == 0 and kh*kw <= 32 -> scalar tap arithmetic + per-row validity bitmask, no im2col table
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP>
 __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
@@ -305,17 +312,20 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
     const int m0 = bm * BM, n0 = bn * BN;
     const int nsteps = a.k_pad / BK;
 
-    if constexpr (!IS1X1) {
+    if constexpr (!IS1X1 && !UTAP) {
         for (int i = tid; i < a.k_pad / 8; i += 256) ktab_lds[i] = a.ktab[i];
     }
 
     // ---- per-lane DMA geometry.  Wave w moves activation pieces w*PA .. w*PA+PA-1 (16 rows each) and
-    //      weight pieces w*PW .. (clamped: surplus waves re-send the last piece, identical bytes). ----
+    //      weight pieces w*PW .. (clamped: surplus waves re-send the last piece, identical bytes).
+    //      Addresses are (uniform 64-bit base) + (per-lane 32-bit element offset); out-of-range
+    //      activation chunks select the offset of a zero page that lives in the tail of x's own
+    //      buffer, weight rows past cout are real zero rows of the packed tensor -> no branches. ----
     const int sub_row = lane >> 2;                         // row within the piece
     const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // k-chunk fetched = pos ^ ((row>>2)&3)
-    const int64_t zdelta_x = a.zeros - a.x;                // element distance to the zero page
-    const int64_t zdelta_w = a.zeros - a.w;
-    int a_off[PA], a_iyx[PA];     // element offset of (img, iy0, ix0, 0); packed (iy0+16384)<<16 | (ix0+16384), <0 = row past M
+    int a_off[PA];       // element offset of (img, iy0, ix0, 0) relative to a.x
+    int a_aux[PA];       // UTAP: bit t set <=> tap t of this row is inside the image (0 for rows past M)
+                         // else: (iy0+16384)<<16 | (ix0+16384), or -1 for rows past M
     int a_slot[PA];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
@@ -329,55 +339,80 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
         const int oy = rem / a.wo, ox = rem - oy * a.wo;
         const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
         a_off[j] = ((img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
-        a_iyx[j] = ok ? (((iy0 + 16384) << 16) | ((ix0 + 16384) & 0xffff)) : -1;
+        if constexpr (UTAP) {
+            unsigned mask = 0;
+            for (int t = 0; t < a.kh * a.kw; ++t) {
+                const int dy = t / a.kw, dx = t - dy * a.kw;
+                const bool in = ((unsigned)(iy0 + dy) < (unsigned)a.h) && ((unsigned)(ix0 + dx) < (unsigned)a.w_in);
+                mask |= (in ? 1u : 0u) << t;
+            }
+            a_aux[j] = ok ? (int)mask : 0;
+        } else {
+            a_aux[j] = ok ? (((iy0 + 16384) << 16) | ((ix0 + 16384) & 0xffff)) : -1;
+        }
     }
-    int64_t w_off[PW];            // element offset of (row, chunk*8) in the packed weights, or the zero page
+    int w_off[PW];       // element offset of (row, chunk*8) in the packed weights (rows are zero-padded to 128)
     int w_slot[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         int pi = wave * PW + j;
         pi = pi < W_PIECES ? pi : W_PIECES - 1;
         w_slot[j] = (BM / 16 + pi) * 512;
-        const int r = n0 + pi * 16 + sub_row;
-        w_off[j] = (int64_t)r * a.k_pad + chunk * 8;
-    }
-    bool w_valid[PW];
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-        int pi = wave * PW + j;
-        pi = pi < W_PIECES ? pi : W_PIECES - 1;
-        w_valid[j] = (n0 + pi * 16 + sub_row) < a.cout_pad;
+        w_off[j] = (n0 + pi * 16 + sub_row) * a.k_pad + chunk * 8;
     }
 
+    // UTAP running state (issue() is called for steps 0,1,2,... in order): all wave-uniform scalars
+    int u_tap = 0, u_c0 = 0, u_dx = 0, u_kbase = 0;
     auto issue = [&](int step) {
         uint16_t* stage = smem + (step % STAGES) * STAGE_HALFS;
-        int koff, dy = 0, dx = 0;
-        bool tap_ok;
-        if constexpr (IS1X1) {
-            koff = (step * 4 + chunk) * 8;
-            tap_ok = koff < a.cin;
-        } else {
-            const int2 t = ktab_lds[step * 4 + chunk];
-            koff = t.x;
-            tap_ok = t.y >= 0;
-            dy = t.y >> 16;
-            dx = t.y & 0xffff;
-        }
+        if constexpr (UTAP) {
+            // cin % 32 == 0: the four chunks of a step share one tap -> tap/channel math is scalar
+            const int koff = u_kbase + chunk * 8;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) {
-            bool ok = tap_ok & (a_iyx[j] >= 0);
-            if constexpr (!IS1X1) {
-                const int iy = (a_iyx[j] >> 16) - 16384 + dy, ix = (a_iyx[j] & 0xffff) - 16384 + dx;
-                ok = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w_in);
+            for (int j = 0; j < PA; ++j) {
+                const bool ok = (a_aux[j] >> u_tap) & 1;
+                const int off = ok ? a_off[j] + koff : a.x_zero_off;
+                glds16(a.x + off, stage + a_slot[j]);
             }
-            const int64_t d = ok ? (int64_t)(a_off[j] + koff) : zdelta_x;   // v_cndmask, no branch
-            glds16(a.x + d, stage + a_slot[j]);
+            // advance to the next 32-channel chunk / tap / kernel row (element offsets relative to (iy0, ix0))
+            u_c0 += BK;
+            u_kbase += BK;
+            if (u_c0 == a.cin) {
+                u_c0 = 0;
+                ++u_tap;
+                ++u_dx;
+                u_kbase += a.x_cs - a.cin;
+                if (u_dx == a.kw) {
+                    u_dx = 0;
+                    u_kbase += (a.w_in - a.kw) * a.x_cs;
+                }
+            }
+        } else {
+            int koff, dy = 0, dx = 0;
+            bool tap_ok;
+            if constexpr (IS1X1) {
+                koff = (step * 4 + chunk) * 8;
+                tap_ok = koff < a.cin;
+            } else {
+                const int2 t = ktab_lds[step * 4 + chunk];
+                koff = t.x;
+                tap_ok = t.y >= 0;
+                dy = t.y >> 16;
+                dx = t.y & 0xffff;
+            }
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                bool ok = tap_ok & (a_aux[j] >= 0);
+                if constexpr (!IS1X1) {
+                    const int iy = (a_aux[j] >> 16) - 16384 + dy, ix = (a_aux[j] & 0xffff) - 16384 + dx;
+                    ok = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w_in);
+                }
+                const int off = ok ? a_off[j] + koff : a.x_zero_off;
+                glds16(a.x + off, stage + a_slot[j]);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < PW; ++j) {
-            const int64_t d = w_valid[j] ? w_off[j] + step * BK : zdelta_w;
-            glds16(a.w + d, stage + w_slot[j]);
-        }
+        for (int j = 0; j < PW; ++j) glds16(a.w + (w_off[j] + step * BK), stage + w_slot[j]);
     };
 
     f32x16 acc[TN][TM];
@@ -388,10 +423,10 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if constexpr (!IS1X1) __syncthreads();   // ktab visible (no DMA in flight yet: plain barrier is fine)
+    if constexpr (!IS1X1 && !UTAP) __syncthreads();   // ktab visible (no DMA in flight yet: plain barrier is fine)
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nsteps) issue(s);
+        if (s < nsteps && !(a.debug & 2)) issue(s);
 
     const int frow = lane & 31;
     const int swz = (lane >> 2) & 3;
@@ -408,7 +443,8 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();          // every wave's pieces landed; everyone is done with stage step-1
         __builtin_amdgcn_sched_barrier(0);
-        if (step + STAGES - 1 < nsteps) issue(step + STAGES - 1);   // refill the slot freed by step-1
+        if (step + STAGES - 1 < nsteps && !(a.debug & 2)) issue(step + STAGES - 1);   // refill the slot freed by step-1
+        if (a.debug & 1) continue;
         const uint16_t* as = smem + (step % STAGES) * STAGE_HALFS + wave_m * 32;
         const uint16_t* ws = smem + (step % STAGES) * STAGE_HALFS + (BM + wave_n) * 32;
 #pragma unroll
@@ -425,6 +461,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
         }
     }
 
+    if constexpr (!STAGED_EPILOGUE) {
     // ---- epilogue ----
     const int hi = lane >> 5;
 #pragma unroll
@@ -514,6 +551,117 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
             }
         }
     }
+    } else {
+    // ---- epilogue ----
+    // 16-bit outputs: bias + SiLU in fp32 -> packed to the output dtype -> staged through LDS as a
+    // [BM][BN] tile (the operand ring is dead by now) -> written back as WHOLE pixel rows, 16 B per
+    // lane with consecutive lanes on consecutive channels.  A direct store from the MFMA layout would
+    // touch 32 cache lines with 32-byte pieces per instruction (measured ~1 TB/s); the staged form
+    // writes full 64..256-byte runs.  The residual (Bottleneck shortcut) is added at this stage from
+    // equally coalesced 16-byte loads.  fp32 outputs (head logits) keep the direct float4 path.
+    const int hi = lane >> 5;
+    if constexpr (ODT == YMI_F32) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wave_m + j * 32 + frow;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = n0 + wave_n + i * 32 + g * 8 + hi * 4;
+                    if (co >= a.cout) continue;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][g * 4 + e] + b[e];
+                        if (a.act == YMI_ACT_SILU) t = silu(t);
+                        v[e] = t;
+                    }
+                    float* yp = reinterpret_cast<float*>(a.y) + (int64_t)m * a.y_cs + co;
+                    if (co + 3 < a.cout) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(yp) = o;
+                    } else {
+                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[e];
+                    }
+                }
+            }
+        }
+    } else {
+        constexpr int OPITCH = BN + 8;   // halfs per staged row (+16 B: spreads ds_write_b64 over banks)
+        static_assert(BM * OPITCH * 2 <= STAGES * (BM + BN) * 64, "output tile must fit in the operand ring");
+        uint16_t* ot = smem;
+        __builtin_amdgcn_s_barrier();    // every wave is done reading the last operand stage
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int row = wave_m + j * 32 + frow;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = wave_n + i * 32 + g * 8 + hi * 4;   // column inside the tile
+                    const int co = n0 + cl;
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (co < a.cout_pad) b = *reinterpret_cast<const f32x4*>(a.bias + co);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][g * 4 + e] + b[e];
+                        if (a.act == YMI_ACT_SILU) t = silu(t);
+                        v[e] = t;
+                    }
+                    u32x2 o;
+                    o[0] = (uint32_t)to16<DT>(v[0]) | ((uint32_t)to16<DT>(v[1]) << 16);
+                    o[1] = (uint32_t)to16<DT>(v[2]) | ((uint32_t)to16<DT>(v[3]) << 16);
+                    *reinterpret_cast<u32x2*>(ot + row * OPITCH + cl) = o;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;              // 16-byte chunks per tile row
+        constexpr int CHUNKS = BM * CPR;
+#pragma unroll 4
+        for (int c = tid; c < CHUNKS; c += 256) {
+            const int row = c / CPR, cl = (c % CPR) * 8;
+            const int m = m0 + row, co = n0 + cl;
+            if (m >= a.M || co >= a.cout) continue;
+            u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OPITCH + cl);
+            if (co + 7 < a.cout) {
+                if (a.res != nullptr) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (int64_t)m * a.res_cs + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = from16<DT>((uint16_t)(v[e] & 0xffff)) + from16<DT>((uint16_t)(r[e] & 0xffff));
+                        const float hi2 = from16<DT>((uint16_t)(v[e] >> 16)) + from16<DT>((uint16_t)(r[e] >> 16));
+                        v[e] = (uint32_t)to16<DT>(lo) | ((uint32_t)to16<DT>(hi2) << 16);
+                    }
+                }
+                uint16_t* yp;
+                if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co - a.split);
+                else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
+                *reinterpret_cast<u32x4*>(yp) = v;
+            } else {   // ragged last chunk (cout % 8 != 0): element-wise
+                for (int e = 0; e < 8 && co + e < a.cout; ++e) {
+                    float t = from16<DT>((uint16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+                    if (a.res != nullptr) t += from16<DT>(a.res[(int64_t)m * a.res_cs + co + e]);
+                    uint16_t* yp;
+                    if (a.split > 0 && co + e >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co + e - a.split);
+                    else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co + e;
+                    *yp = to16<DT>(t);
+                }
+            }
+        }
+    }
+    }
+}
+
+template <typename K>
+static int launch_v2_kernel(K kfn, const ConvArgs& a, size_t lds, dim3 grid, hipStream_t s) {
+    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    return check_launch("conv_igemm_v2_kernel");
 }
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES>
@@ -521,24 +669,12 @@ static int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, BM);
     a.nblk_n = cdiv(a.cout_pad, BN);
-    const size_t lds = (size_t)STAGES * (BM + BN) * 64 + (is1x1 ? 0 : (size_t)a.k_pad) + 16;
-    dim3 grid(a.nblk_m * a.nblk_n), block(256);
-    if (is1x1) {
-        auto kfn = conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, true>;
-        if (lds > 64 * 1024) {
-            static bool done = false;
-            if (!done) { YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
-        }
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, a);
-    } else {
-        auto kfn = conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false>;
-        if (lds > 64 * 1024) {
-            static bool done = false;
-            if (!done) { YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
-        }
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, a);
-    }
-    return check_launch("conv_igemm_v2_kernel");
+    const bool utap = (a.cin % 32 == 0) && (a.kh * a.kw <= 32);
+    const size_t lds = (size_t)STAGES * (BM + BN) * 64 + ((is1x1 || utap) ? 0 : (size_t)a.k_pad) + 16;
+    dim3 grid(a.nblk_m * a.nblk_n);
+    if (utap) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, true>, a, lds, grid, s);
+    if (is1x1) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, true, false>, a, lds, grid, s);
+    return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, false>, a, lds, grid, s);
 }
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN>
@@ -556,7 +692,10 @@ static int launch_cfg(const ConvArgs& a0, bool is1x1, hipStream_t s) {
 
 // tile ids: 1 = 128x128, 2 = 256x64, 3 = 256x32, 4 = 64x128, 5 = 128x64, 6 = 64x64... keep small
 template <int DT, int ODT>
-static int launch_dtype(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) {
+static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s) {
+    ConvArgs a = a0;
+    a.debug = 0;
+    if (tile >= 0x100) { a.debug = tile >> 8; tile &= 0xff; }
     const bool force_v1 = tile < 0;
     if (force_v1) tile = -tile == 100 ? 0 : -tile;   // negative tile ids force the register-staged kernel (-100 = auto)
     if (tile == 0) {
@@ -615,6 +754,13 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw; a.k_pad = d->k_pad; a.act = d->act;
     a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
     a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
+    a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
+    if (d->zeros != nullptr) {
+        const int64_t dz = ((const char*)d->zeros - (const char*)d->x) / 2;
+        YMI_REQUIRE(dz > -((int64_t)1 << 31) && dz < ((int64_t)1 << 31) && ((const char*)d->zeros - (const char*)d->x) % 16 == 0,
+                    "ymi_conv2d: desc.zeros must lie within +-4 GiB of x and be 16-byte aligned relative to it (use the tail of x's buffer)");
+        a.x_zero_off = (int)dz;
+    }
     YMI_REQUIRE(a.split == 0 || (d->y2 != nullptr && a.split % 8 == 0 && a.split < d->cout && d->res == nullptr && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0),
                 "ymi_conv2d: invalid second-output configuration");
     YMI_REQUIRE(a.split == 0 || a.zeros != nullptr, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");

@@ -38,6 +38,7 @@ class View:
     w: int
     c: int
     cs: int       # pixel stride in elements (>= c)
+    tail: int = -1  # element index of the buffer's zero tail (-1: foreign buffer without one)
 
     @property
     def dtype(self) -> torch.dtype:
@@ -49,7 +50,7 @@ class View:
 
     def slice_c(self, c0: int, c: int) -> "View":
         assert 0 <= c0 and c0 + c <= self.c
-        return View(self.base, self.off + c0, self.n, self.h, self.w, c, self.cs)
+        return View(self.base, self.off + c0, self.n, self.h, self.w, c, self.cs, self.tail)
 
     def as_tensor(self) -> Tensor:
         """(n,h,w,c) strided torch view of the data (debug / tests / API edges)."""
@@ -96,7 +97,8 @@ class PackedConv:
         self.cout_pad = _round_up(cout, 32)
         self.k = wk.shape[1]
         self.k_pad = _round_up(self.k, 32)
-        packed = torch.zeros(self.cout_pad, self.k_pad, device=device, dtype=torch.float32)
+        # rows zero-padded to a multiple of 128 (largest cout tile): the pipelined kernel never branches on rows
+        packed = torch.zeros(_round_up(cout, 128), self.k_pad, device=device, dtype=torch.float32)
         packed[:cout, : self.k] = wk
         self.w = packed.to(dtype).contiguous()
         self.bias = torch.zeros(self.cout_pad, device=device, dtype=torch.float32)
@@ -152,10 +154,18 @@ class Plan:
     def alloc(self, n: int, h: int, w: int, c: int, dtype: Optional[torch.dtype] = None, zero: bool = False) -> View:
         dt = dtype or self.dtype
         numel = n * h * w * c
-        t = (torch.zeros if zero else torch.empty)(max(numel, 1), device=self.device, dtype=dt)
+        # every buffer carries a 256-byte zero tail: the pipelined conv kernel reads out-of-image operand
+        # chunks from there (32-bit offset from the view, see ymi_conv_desc.zeros)
+        tail = 256 // torch.empty((), dtype=dt).element_size()
+        numel = _round_up(max(numel, 1), 8)
+        t = (torch.zeros if zero else torch.empty)(numel + tail, device=self.device, dtype=dt)
+        if not zero:
+            t[numel:].zero_()
         self.keep.append(t)
         self.bytes_allocated += t.numel() * t.element_size()
-        return View(t, 0, n, h, w, c, c)
+        v = View(t, 0, n, h, w, c, c)
+        v.tail = numel
+        return v
 
     def _record(self, idx: int, name: str, **meta) -> None:
         check(idx, name)
@@ -179,9 +189,13 @@ class Plan:
         d.act, d.dtype, d.out_dtype, d.tile = act, dtype_code(pc.dtype), dtype_code(y.dtype), tile
         d.y2 = None if y2 is None else y2.ptr
         d.y2_cstride, d.cout_split = (0, 0) if y2 is None else (y2.cs, split)
-        d.zeros = None if (self.use_v1 and y2 is None) else self.zeros.data_ptr()
-        if self.use_v1 and y2 is None and tile == 0:
-            d.tile = -100
+        has_tail = x.tail >= 0
+        if y2 is not None and not has_tail:
+            raise YmiError("second-output convs need a plan-allocated input (zero tail)")
+        v1 = (self.use_v1 and y2 is None) or not has_tail
+        d.zeros = None if v1 else x.base.data_ptr() + x.tail * x.base.element_size()
+        if v1 and tile >= 0:
+            d.tile = -100 if tile == 0 else -tile
         self.keep.extend([pc, kt, d])
         return d
 
@@ -195,7 +209,7 @@ class Plan:
         if pc.stem_superpixel:
             if x.c != 4 or x.cs != 4 or x.w % 2:
                 raise YmiError("stem super-pixel conv needs a dense NHWC4 input with even width")
-            x = View(x.base, x.off, x.n, x.h, x.w // 2, 8, 8)
+            x = View(x.base, x.off, x.n, x.h, x.w // 2, 8, 8, x.tail)
             s, p = (s[0], 1), (p[0], 1)
         if x.c != pc.cin:
             raise YmiError(f"{name}: input view has {x.c} channels, packed weights expect {pc.cin}")

@@ -39,6 +39,33 @@ class _PlanEntry:
     def __init__(self, plan: Plan, x: View, feats: List[View], logits: Optional[List[View]], post, rescale: Optional[Tensor], n_backbone_ops: int):
         self.plan, self.x, self.feats, self.logits, self.post, self.rescale = plan, x, feats, logits, post, rescale
         self.n_backbone_ops = n_backbone_ops
+        self.n_conv_ops = plan.num_ops - (1 if post is not None else 0)
+        n = x.n
+        # pinned staging for the tiny per-batch host<->device traffic (rescale rows in, status+counts out)
+        self.rescale_host = torch.zeros(n, 3, dtype=torch.float32).pin_memory() if post is not None else None
+        self.result_host = torch.zeros(4 + n, dtype=torch.int32).pin_memory() if post is not None else None
+        self.done = None        # event recorded after the post-process + result copy of the last submit
+        self.post_stream = torch.cuda.Stream(device=x.base.device) if post is not None else None
+
+
+class PendingDetections:
+    """Handle of an in-flight batch (YOLO.submit / YOLOv5.forward_async); `.result()` blocks on its
+    completion event only -- later batches keep running on the GPU meanwhile."""
+
+    def __init__(self, owner: "YOLO", entry: _PlanEntry, rows, hook_result=None):
+        self.owner, self.entry, self.rows, self.hook_result = owner, entry, rows, hook_result
+        self.event = entry.done
+
+    def result(self) -> List[Dict[str, Tensor]]:
+        if self.hook_result is not None:
+            return self.hook_result
+        e = self.entry
+        self.event.synchronize()
+        host = e.result_host.tolist()
+        if host[1] != 0:   # candidate capacity exceeded (nothing truncated): grow, rebuild, redo synchronously
+            return self.owner._redo_with_capacity(e, self.rows, host[0])
+        p = e.post
+        return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), host[4:])
 
 
 class YOLO(nn.Module):
@@ -74,6 +101,9 @@ class YOLO(nn.Module):
         self.use_graph = os.environ.get("YOLORT_AMD_GRAPH", "0") == "1"
         self.cand_cap_per_image = int(os.environ.get("YOLORT_AMD_CAND_CAP", "16384"))
         self._entries: Dict[Tuple, _PlanEntry] = {}
+        self._ring: Dict[Tuple, List[_PlanEntry]] = {}
+        self._ring_pos = 0
+        self.pipeline_depth = 2   # plan instances per shape: batch i+1 may run while batch i is post-processed / collected
         self._has_warned = False
         # measurement hook (bench.py): (n_ops, starts, ends) -> HIP events around ops [0, n_ops) of every run
         self.bracket = None
@@ -87,12 +117,23 @@ class YOLO(nn.Module):
         pp = self.post_process
         post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
         key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image)
-        e = self._entries.get(key)
-        if e is not None:
+        ring = self._ring.get(key)
+        if ring is not None:
+            self._ring_pos = (self._ring_pos + 1) % len(ring)
+            e = ring[self._ring_pos]
+            self._entries = {key: e}
             return e
         self._entries.clear()  # one live shape at a time keeps HBM use bounded
+        self._ring.clear()
         if not hasattr(self.backbone, "emit"):
             raise YmiError("the backbone must be a yolort_amd HIP module (custom torch backbones have no MI355X path)")
+        ring = [self._build_entry(n, h, w, device, cdt, pp) for _ in range(max(1, self.pipeline_depth))]
+        self._ring[key] = ring
+        self._ring_pos = 0
+        self._entries[key] = ring[0]
+        return ring[0]
+
+    def _build_entry(self, n: int, h: int, w: int, device: torch.device, cdt, pp) -> _PlanEntry:
         plan = Plan(device, cdt)
         x = plan.alloc(n, h, w, 4, zero=True)
         feats = self.backbone.emit(plan, x)
@@ -104,48 +145,76 @@ class YOLO(nn.Module):
             ag = self.anchor_generator
             post = plan.postprocess(logits, [float(s) for s in ag.strides], ag.anchor_grids, self.num_classes, float(pp.score_thresh), float(pp.nms_thresh),
                                     int(pp.detections_per_img), self.cand_cap_per_image * n, rescale=rescale)
-        e = _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
-        self._entries[key] = e
-        return e
+        return _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
 
-    def _run_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> List[Dict[str, Tensor]]:
-        """input view already filled; runs the plan and converts the slab to the reference's List[Dict]"""
+    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> PendingDetections:
+        """input view already filled on the current stream; enqueues the plan and returns a handle.
+        Conv stack on the current stream, post-process + result copy on the entry's side stream, so
+        the next batch's convolutions overlap this batch's sort/NMS (few, long-running waves)."""
         if e.post is None:  # custom hooks: HIP backbone, then the injected modules on torch tensors
             e.plan.run(graph=self.use_graph)
             feats = [view_to_nchw(v) for v in e.feats]
             head_outputs = self.head(feats)
             grids, shifts = self.anchor_generator(feats)
-            return self.post_process(head_outputs, grids, shifts)
+            return PendingDetections(self, e, None, hook_result=self.post_process(head_outputs, grids, shifts))
+        main = torch.cuda.current_stream()
         if rescale_rows is None:
-            e.rescale.zero_()
+            e.rescale_host.zero_()
         else:
-            e.rescale.copy_(torch.tensor(rescale_rows, dtype=torch.float32), non_blocking=False)
-        while True:
-            if self.bracket is not None:
-                n_ops, starts, ends = self.bracket
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-                e.plan.run(0, n_ops)
-                ev1.record()
-                e.plan.run(n_ops, -1)
-                starts.append(ev0)
-                ends.append(ev1)
-            else:
-                e.plan.run(graph=self.use_graph)
-            host = torch.cat([e.post.status, e.post.count]).cpu().tolist()
-            if host[1] == 0:
-                break
-            # candidate capacity exceeded: nothing was truncated; grow and rebuild (rare)
-            self.cand_cap_per_image = int(host[0] * 1.25 / e.x.n) + 1024
-            x_old = e.x
-            e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
-            e2.x.base.copy_(x_old.base)
-            if rescale_rows is not None:
-                e2.rescale.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
-            e = e2
-        counts = host[4:]
-        p = e.post
-        return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), counts)
+            e.rescale_host.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
+        e.rescale.copy_(e.rescale_host, non_blocking=True)
+        if self.bracket is not None:
+            _, starts, ends = self.bracket
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(main)
+            e.plan.run(0, e.n_conv_ops, stream=main)
+            ev1.record(main)
+            starts.append(ev0)
+            ends.append(ev1)
+        else:
+            e.plan.run(0, e.n_conv_ops, graph=self.use_graph, stream=main)
+        side = e.post_stream
+        side.wait_stream(main)
+        e.plan.run(e.n_conv_ops, -1, stream=side)
+        with torch.cuda.stream(side):
+            e.result_host.copy_(torch.cat([e.post.status, e.post.count]), non_blocking=True)
+        e.done = torch.cuda.Event()
+        e.done.record(side)
+        if self.pipeline_depth <= 1:
+            main.wait_event(e.done)
+        return PendingDetections(self, e, rescale_rows)
+
+    def _acquire(self, n: int, h: int, w: int, device: torch.device) -> _PlanEntry:
+        """next plan instance of the ring for this shape; waits (on the GPU, not the host) until the
+        work previously submitted on it has drained before its buffers are overwritten"""
+        e = self._entry(n, h, w, device)
+        if e.done is not None:
+            torch.cuda.current_stream().wait_event(e.done)
+        return e
+
+    def _redo_with_capacity(self, e: _PlanEntry, rescale_rows, needed: int) -> List[Dict[str, Tensor]]:
+        self.cand_cap_per_image = int(needed * 1.25 / e.x.n) + 1024
+        x_old = e.x
+        torch.cuda.synchronize()
+        e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
+        e2.x.base.copy_(x_old.base)
+        return self._submit_entry(e2, rescale_rows).result()
+
+    def _run_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> List[Dict[str, Tensor]]:
+        return self._submit_entry(e, rescale_rows).result()
+
+    def submit(self, samples: Tensor) -> PendingDetections:
+        """asynchronous form of forward(): enqueue a pre-batched (N,3,H,W) tensor, collect later"""
+        if self.training:
+            raise NotImplementedError("yolort_amd implements the inference path only; call .eval() (training / SetCriterion are out of scope)")
+        if not isinstance(samples, Tensor) or samples.dim() != 4:
+            raise ValueError("samples is expected to be a batched tensor of shape [N, 3, H, W]")
+        if not samples.is_cuda:
+            raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
+        n, c, h, w = samples.shape
+        e = self._acquire(n, h, w, samples.device)
+        nchw_to_view(e.plan, samples, 4, out=e.x)
+        return self._submit_entry(e, None)
 
     def forward(self, samples: Tensor, targets: Optional[Tensor] = None):
         """samples: batched images (N,3,H,W) in 0-1 range (reference yolo.py:141-183)."""
@@ -155,10 +224,7 @@ class YOLO(nn.Module):
             raise ValueError("samples is expected to be a batched tensor of shape [N, 3, H, W]")
         if not samples.is_cuda:
             raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
-        n, c, h, w = samples.shape
-        e = self._entry(n, h, w, samples.device)
-        nchw_to_view(e.plan, samples, 4, out=e.x)
-        return self._run_entry(e, None)
+        return self.submit(samples).result()
 
     @classmethod
     def load_from_yolov5(cls, checkpoint_path: str, score_thresh: float = 0.25, nms_thresh: float = 0.45, version: str = "r6.0",

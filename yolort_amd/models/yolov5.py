@@ -42,6 +42,12 @@ class YOLOv5(nn.Module):
     def forward(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
         """inputs: iterable of (3,H,W) tensors in 0-1 range (or uint8 0-255), possibly of different sizes
         (reference yolov5.py:135-189).  Returns List[Dict] with boxes in ORIGINAL image coordinates."""
+        return self.forward_async(inputs, targets).result()
+
+    def forward_async(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
+        """Enqueues one batch and returns a handle whose `.result()` yields forward()'s List[Dict].
+        Serving loops keep two batches in flight (submit i+1, then collect i): the host work and the
+        sort/NMS tail of batch i then overlap the convolutions of batch i+1."""
         if self.training:
             raise NotImplementedError("yolort_amd implements the inference path only; call .eval() (training is out of scope)")
         if targets is not None:
@@ -57,13 +63,14 @@ class YOLOv5(nn.Module):
         model = self.model
         if not isinstance(model, YOLO):
             raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
-        e = model._entry(len(images), hb, wb, images[0].device)
+        e = model._acquire(len(images), hb, wb, images[0].device)
         self.transform.letterbox_into(images, e.x, sizes, pads)
         rows = [rescale_params((hb, wb), o) for o in original]
         if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
-            dets = model._run_entry(e, None)
-            return self.transform.postprocess(dets, (hb, wb), original)
-        return model._run_entry(e, rows)
+            pend = model._submit_entry(e, None)
+            pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
+            return pend
+        return model._submit_entry(e, rows)
 
     @torch.no_grad()
     def predict(self, x: Any, image_loader: Optional[Callable] = None) -> List[Dict[str, Tensor]]:
