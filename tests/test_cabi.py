@@ -1,0 +1,81 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol that
+include/yolort_amd.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from yolort_amd import _build, _lib
+    _build.build()  # no-op when the .so is current; hipcc cross-compiles gfx950 without a GPU
+    return _lib.load(require_gpu=False)
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "yolort_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ymi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from yolort_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/yolort_amd.h but not exported"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_abi_version_and_error_channel(lib):
+    assert lib.ymi_abi_version() == 1
+    # a host-side argument error must come back as a code + message, never as an exception/abort
+    t = (C.c_int32 * 8)()
+    rc = lib.ymi_conv_build_ktab(7, 3, 3, 10, 8, 32, t)   # cin not a multiple of 8
+    assert rc == -1 and b"ktab" in lib.ymi_last_error()
+
+
+def test_ktab_known_answers(lib):
+    """im2col table of a 3x3 conv over 16 channels, image width 10, pixel stride 24 elements"""
+    k_pad = 160  # K = 144 rounded up to 32
+    t = (C.c_int32 * (k_pad // 8 * 2))()
+    assert lib.ymi_conv_build_ktab(16, 3, 3, 10, 24, k_pad, t) == 0
+    e = [(t[2 * i], t[2 * i + 1]) for i in range(k_pad // 8)]
+    assert e[0] == (0, 0) and e[1] == (8, 0)                 # tap (0,0), channels 0..7 / 8..15
+    assert e[2] == (24, 1) and e[3] == (32, 1)               # tap (0,1): one pixel to the right
+    assert e[6] == (10 * 24, 1 << 16)                        # tap (1,0): one row down
+    assert e[17] == ((2 * 10 + 2) * 24 + 8, (2 << 16) | 2)   # last real chunk
+    assert e[18] == (0, -1) and e[19] == (0, -1)             # K padding
+
+
+def test_workspace_queries(lib):
+    a = lib.ymi_postprocess_ws_bytes(32, 25200, 1 << 19)
+    b = lib.ymi_postprocess_ws_bytes(32, 25200, 1 << 20)
+    assert 0 < a < b
+    assert lib.ymi_postprocess_ws_bytes(0, 25200, 10) == 0
+    assert lib.ymi_nms_ws_bytes(1000) > 1000 * 16
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors of the descriptors must have the C layout (sizes computed from the header with gcc)"""
+    import subprocess, tempfile
+    from yolort_amd import _lib
+    src = '#include <stdio.h>\n#include "yolort_amd.h"\nint main(){printf("%zu %zu\\n", sizeof(ymi_conv_desc), sizeof(ymi_post_desc));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
+        out = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == C.sizeof(_lib.ConvDesc)
+    assert int(out[1]) == C.sizeof(_lib.PostDesc)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from yolort_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.YmiError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,73 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of the N>1 path: contiguous sharding and the
+single fixed-shape slab all-gather that bench.py runs over RCCL on the GPU box."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolort_amd import dist as yd
+        n, k = 6, 5
+        lo, hi = yd.shard_range(n, rank, world)
+        g = torch.Generator().manual_seed(1234)
+        boxes = torch.rand(n, k, 4, generator=g)
+        scores = torch.rand(n, k, generator=g)
+        labels = torch.randint(0, 80, (n, k), generator=g)
+        count = torch.tensor([5, 0, 3, 1, 5, 2], dtype=torch.int32)
+        b, s, l, c = yd.all_gather_slab(boxes[lo:hi], scores[lo:hi], labels[lo:hi], count[lo:hi])
+        ok = torch.equal(b, boxes) and torch.equal(s, scores) and torch.equal(l, labels) and torch.equal(c, count)
+        dets = [{"boxes": boxes[i, : count[i]], "scores": scores[i, : count[i]], "labels": labels[i, : count[i]]} for i in range(lo, hi)]
+        full = yd.gather_detections(dets, k)
+        ok = ok and len(full) == n and all(torch.equal(full[i]["labels"], labels[i, : count[i]]) and torch.equal(full[i]["boxes"], boxes[i, : count[i]]) for i in range(n))
+        q.put((rank, bool(ok), (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from yolort_amd.dist import shard_range
+    for n in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+    assert shard_range(256, 3, 8) == (96, 128)  # BASELINE config 4: bs 256 over 8 GPUs, 32 per rank
+
+
+def test_slab_pack_roundtrip_is_exact():
+    from yolort_amd.dist import pack_slab, unpack_slab
+    b, s = torch.rand(4, 300, 4), torch.rand(4, 300)
+    l = torch.randint(0, 1 << 20, (4, 300))
+    c = torch.tensor([300, 0, 17, 299], dtype=torch.int32)
+    b2, s2, l2, c2 = unpack_slab(pack_slab(b, s, l, c), 300)
+    assert torch.equal(b, b2) and torch.equal(s, s2) and torch.equal(l, l2) and torch.equal(c, c2)
+
+
+@pytest.mark.timeout(120)
+def test_all_gather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert res == [(0, True, (0, 3)), (1, True, (3, 6))]

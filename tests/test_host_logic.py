@@ -1,0 +1,122 @@
+"""Host-side logic of the product (no GPU): letterbox geometry against the reference goldens, API
+surface/contracts of the mirrored modules, and the 'no CPU fallback' behaviour."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_letterbox_geometry_matches_reference(golden_dir):
+    from yolort_amd.models.transform import YOLOTransform, pad_offset, resized_hw
+    g = json.load(open(os.path.join(golden_dir, "letterbox.json")))
+    n = 0
+    for c in g["cases"]:
+        if c.get("mixed"):
+            t = YOLOTransform(640, 640, fixed_shape=tuple(c["fixed"]) if c["fixed"] else None)
+            (hb, wb), sizes, pads = t.geometry([(1080, 810), (480, 640), (720, 1280)])
+            assert [3, 3, hb, wb] == c["canvas"] and [list(s) for s in sizes] == c["image_sizes"]
+            continue
+        t = YOLOTransform(c["S"], c["S"], size_divisible=c["stride"])
+        (hb, wb), sizes, pads = t.geometry([tuple(c["hw"])])
+        assert list(sizes[0]) == c["resized"], c
+        assert [hb, wb] == c["canvas"], c
+        n += 1
+    assert n == 40
+    # SURVEY.md Appendix B rounding traps, spelled out
+    assert resized_hw(1281, 1279, 640.0, 640.0) == (639, 639)
+    assert resized_hw(375, 500, 640.0, 640.0) == (480, 640)
+    assert resized_hw(100, 37, 1280.0, 1280.0) == (1279, 473)
+    assert pad_offset(448, 427) == 10 and pad_offset(640, 427) == 106
+    t = YOLOTransform(640, 640, fixed_shape=(640, 640))
+    (_, _), sizes, pads = t.geometry([(427, 640)])
+    assert pads[0][0] == g["fixed_427"]["first_row"] and pads[0][0] + sizes[0][0] - 1 == g["fixed_427"]["last_row"]
+    assert float(np.float32(t.fill_color)) == g["fill"]
+
+
+def test_rescale_matches_reference_scale_coords(golden_dir):
+    from yolort_amd.models.transform import rescale_params, scale_coords
+    g = json.load(open(os.path.join(golden_dir, "letterbox.json")))
+    b = scale_coords(torch.tensor([[100.0, 100.0, 200.0, 200.0]]), (640, 480), (1080, 810))
+    assert [float(v) for v in b.flatten()] == g["scale_coords"]
+    b = scale_coords(torch.tensor([[10.5, 20.25, 300.75, 333.0]]), (384, 640), (720, 1280))
+    assert [float(v) for v in b.flatten()] == g["scale_coords2"]
+    gain, px, py = rescale_params((640, 480), (1080, 810))
+    assert abs(gain - 0.59259) < 1e-5 and px == 0.0 and py == 0.0
+
+
+def test_make_divisible_reference_values():
+    """values of reference test/test_models_utils.py:16-37"""
+    from yolort_amd.models._utils import _make_divisible
+    assert [_make_divisible(v, 8) for v in (16, 32 * 0.25, 64 * 0.5, 768 * 0.75, 1024 * 1.25, 30)] == [16, 8, 32, 576, 1280, 32]
+    assert _make_divisible(10, 8) == 16 and _make_divisible(3, 8) == 8
+
+
+def test_anchor_generator_known_answers(golden_dir):
+    """reference test/test_models_anchor_utils.py:14-30"""
+    from yolort_amd.models.anchor_utils import AnchorGenerator
+    z = np.load(os.path.join(golden_dir, "anchors_decode.npz"))
+    grids, shifts = AnchorGenerator([4], [[6, 14]])([torch.rand(1, 3, 2, 2)])
+    np.testing.assert_array_equal(grids[0].numpy(), z["grids"])
+    np.testing.assert_array_equal(shifts[0].numpy(), z["shifts"])
+
+
+def test_api_surface_and_kwargs():
+    import yolort_amd.models as M
+    for name in ("YOLO", "YOLOv5", "yolov5n", "yolov5n6", "yolov5s", "yolov5s6", "yolov5m", "yolov5m6", "yolov5l", "yolov5ts"):
+        assert hasattr(M, name)
+    m = M.yolov5s(score_thresh=0.35, nms_thresh=0.5, detections_per_img=100, size=(320, 416), fill_color=0)
+    pp = m.model.post_process
+    assert (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) == (0.35, 0.5, 100)
+    assert (m.transform.min_size, m.transform.max_size, m.transform.fill_color) == (320, 416, 0.0)
+    assert len(m.state_dict()) == 348 and all(k.startswith("model.") for k in m.state_dict())
+    assert M.yolov5n6().transform.size_divisible == 64
+    assert M.yolov5n6().model.anchor_generator.strides == [8, 16, 32, 64]
+    with pytest.raises(NotImplementedError):
+        M.yolov5n(upstream_version="r4.0")
+    with pytest.raises(NotImplementedError):
+        M.yolov5ts()
+    with pytest.raises(ValueError):
+        M.YOLO(torch.nn.Identity(), 80)  # backbone without out_channels (reference yolo.py:83-88)
+    # defaults of the reference (yolo.py:77-79)
+    d = M.YOLOv5(arch="yolov5_darknet_pan_n_r60").model.post_process
+    assert (d.score_thresh, d.nms_thresh, d.detections_per_img) == (0.005, 0.45, 300)
+
+
+def test_no_cpu_fallback_anywhere():
+    from yolort_amd._lib import YmiError
+    from yolort_amd.models import yolov5n
+    from yolort_amd.v5 import C3, Conv
+    m = yolov5n().eval()
+    with pytest.raises(YmiError):
+        m.predict(torch.rand(3, 64, 64))
+    with pytest.raises(YmiError):
+        m.model(torch.rand(1, 3, 64, 64))
+    with pytest.raises(YmiError):
+        Conv(8, 16, 3).eval()(torch.rand(1, 8, 16, 16))
+    with pytest.raises(YmiError):
+        C3(16, 16).eval()(torch.rand(1, 16, 8, 8))
+    with pytest.raises(NotImplementedError):
+        yolov5n().train()(torch.rand(1, 3, 64, 64))
+
+
+def test_collate_images_contract():
+    """reference yolov5.py:230-262 (device/dtype follow the model; unsupported types raise)"""
+    from yolort_amd.models import yolov5n
+    m = yolov5n().half()
+    out = m.collate_images([torch.rand(3, 8, 8), torch.rand(3, 4, 4)], m.default_loader)
+    assert all(t.dtype == torch.float16 for t in out) and len(out) == 2
+    assert m.collate_images(torch.zeros(3, 8, 8, dtype=torch.uint8), m.default_loader)[0].dtype == torch.uint8
+    with pytest.raises(NotImplementedError):
+        m.collate_images(3.14, m.default_loader)
+
+
+def test_synth_weights_are_deterministic():
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    t = YOLOv5(arch=arch).state_dict()
+    a, b = synth_weights(t, arch, seed=0), synth_weights(t, arch, seed=0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert float(a["model.backbone.body.0.bn.running_var"].mean()) != 1.0  # calibrated statistics were loaded
