@@ -63,10 +63,20 @@ struct ConvArgs {
     const uint16_t* zeros;
     int x_zero_off;    // (zeros - x) in elements: out-of-range activation chunks read x + x_zero_off
     int kh, kw;
+    unsigned magic_hw, magic_w;   // ceil(2^32 / (ho*wo)), ceil(2^32 / wo): exact floor-division for m < 2^31 / d ... see fast_div
     int debug;         // tuning aid: bit0 = skip LDS reads + MFMA, bit1 = skip operand loads (results are garbage)
 };
 
-__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU with hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each; the result is rounded to fp16/bf16)
+// floor(n / d) for 0 <= n < 2^31 with magic = floor(2^32 / d) + 1: one mul_hi and a fix-up step
+__device__ __forceinline__ int fast_div(int n, int d, unsigned magic) {
+    int q = (int)__umulhi((unsigned)n, magic);
+    if (q * d > n) --q;                 // magic over-estimates by at most one ...
+    else if ((q + 1) * d <= n) ++q;     // ... and is clamped to 2^32-1 for d == 1 (under-estimates by one)
+    return q;
+}
+
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
 
 // BM x BN block tile, each wave WM x WN; IS1X1: kh=kw=1, stride 1, pad 0 (no bounds checks, no table)
 template <int DT, int ODT, int BM, int BN, int WM, int WN, bool IS1X1>
@@ -334,17 +344,21 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
         const int m = m0 + pi * 16 + sub_row;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
-        const int img = mm / (a.ho * a.wo);
-        const int rem = mm - img * (a.ho * a.wo);
-        const int oy = rem / a.wo, ox = rem - oy * a.wo;
+        const int hw_o = a.ho * a.wo;
+        const int img = fast_div(mm, hw_o, a.magic_hw);
+        const int rem = mm - img * hw_o;
+        const int oy = fast_div(rem, a.wo, a.magic_w), ox = rem - oy * a.wo;
         const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
         a_off[j] = ((img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
         if constexpr (UTAP) {
             unsigned mask = 0;
-            for (int t = 0; t < a.kh * a.kw; ++t) {
-                const int dy = t / a.kw, dx = t - dy * a.kw;
-                const bool in = ((unsigned)(iy0 + dy) < (unsigned)a.h) && ((unsigned)(ix0 + dx) < (unsigned)a.w_in);
-                mask |= (in ? 1u : 0u) << t;
+            int t = 0;
+            for (int dy = 0; dy < a.kh; ++dy) {
+                const bool yin = (unsigned)(iy0 + dy) < (unsigned)a.h;
+                for (int dx = 0; dx < a.kw; ++dx, ++t) {
+                    const bool in = yin && ((unsigned)(ix0 + dx) < (unsigned)a.w_in);
+                    mask |= (in ? 1u : 0u) << t;
+                }
             }
             a_aux[j] = ok ? (int)mask : 0;
         } else {
@@ -755,6 +769,9 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
     a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
     a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
+    auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
+    a.magic_hw = magic(d->ho * d->wo);
+    a.magic_w = magic(d->wo);
     if (d->zeros != nullptr) {
         const int64_t dz = ((const char*)d->zeros - (const char*)d->x) / 2;
         YMI_REQUIRE(dz > -((int64_t)1 << 31) && dz < ((int64_t)1 << 31) && ((const char*)d->zeros - (const char*)d->x) % 16 == 0,

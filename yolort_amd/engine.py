@@ -141,6 +141,9 @@ class Plan:
         # zero page for the pipelined conv kernel's out-of-range operand chunks (see yolort_amd.h)
         self.zeros = torch.zeros(1024, device=device, dtype=torch.uint8)
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
+        # per-shape tile selection by measurement at plan-build time ("measure, don't guess"): each conv is
+        # timed once per candidate tile on its real buffers with HIP events; winners are cached per shape
+        self.autotune = os.environ.get("YOLORT_AMD_AUTOTUNE", "1") == "1"
 
     def __del__(self):
         try:
@@ -224,6 +227,8 @@ class Plan:
         if out2 is not None and (out2.n, out2.h, out2.w, out2.c) != (x.n, ho, wo, pc.cout - split):
             raise YmiError(f"{name}: second output view has the wrong shape")
         d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
+        if self.autotune and tile == 0 and d.zeros:
+            d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split))
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
@@ -234,6 +239,38 @@ class Plan:
                      ref_convs=ref_reads,
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
+
+    _TUNE_CACHE: Dict[Tuple, int] = {}
+
+    def _autotune_tile(self, d: ConvDesc, key: Tuple) -> int:
+        key = key + (self.dtype,)
+        hit = Plan._TUNE_CACHE.get(key)
+        if hit is not None:
+            return hit
+        cands = [11, 12, 13, 14, 15]
+        if d.cout_pad <= 32:
+            cands = [13, 15, 12]
+        elif d.cout_pad <= 64:
+            cands = [12, 15, 13, 11]
+        best, best_ms = 0, float("inf")
+        stream = _lib.stream_ptr()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for t in cands:
+            d.tile = t
+            if self.lib.ymi_conv2d(C.byref(d), stream) < 0:   # configuration not applicable
+                continue
+            torch.cuda.synchronize()
+            reps = 3
+            ev[0].record()
+            for _ in range(reps):
+                self.lib.ymi_conv2d(C.byref(d), stream)
+            ev[1].record()
+            torch.cuda.synchronize()
+            ms = ev[0].elapsed_time(ev[1]) / reps
+            if ms < best_ms:
+                best, best_ms = t, ms
+        Plan._TUNE_CACHE[key] = best
+        return best
 
     def spp_pool(self, buf: View, c: int, name: str = "spp_pool") -> None:
         assert buf.c == 4 * c
