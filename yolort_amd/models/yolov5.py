@@ -64,13 +64,14 @@ class YOLOv5(nn.Module):
         if not isinstance(model, YOLO):
             raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
         e = model._acquire(len(images), hb, wb, images[0].device)
-        self.transform.letterbox_into(images, e.x, sizes, pads)
-        rows = [rescale_params((hb, wb), o) for o in original]
-        if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
-            pend = model._submit_entry(e, None)
-            pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
-            return pend
-        return model._submit_entry(e, rows)
+        with torch.cuda.stream(e.main_stream):
+            self.transform.letterbox_into(images, e.x, sizes, pads)
+            rows = [rescale_params((hb, wb), o) for o in original]
+            if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
+                pend = model._submit_entry(e, None)
+                pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
+                return pend
+            return model._submit_entry(e, rows)
 
     @torch.no_grad()
     def predict(self, x: Any, image_loader: Optional[Callable] = None) -> List[Dict[str, Tensor]]:
