@@ -734,6 +734,15 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         case 13: return launch_v2<DT, ODT, 256, 32, 64, 32, 3>(a, is1x1, s);
         case 14: return launch_v2<DT, ODT, 64, 128, 32, 64, 4>(a, is1x1, s);
         case 15: return launch_v2<DT, ODT, 128, 64, 64, 32, 4>(a, is1x1, s);
+        // 2-stage rings: half the LDS, twice the resident blocks -- for short K (1x1 convs, stem) where the
+        // ring never fills and occupancy hides the operand latency instead
+        case 21: return launch_v2<DT, ODT, 128, 128, 64, 64, 2>(a, is1x1, s);
+        case 22: return launch_v2<DT, ODT, 256, 64, 64, 64, 2>(a, is1x1, s);
+        case 23: return launch_v2<DT, ODT, 256, 32, 64, 32, 2>(a, is1x1, s);
+        case 24: return launch_v2<DT, ODT, 64, 128, 32, 64, 2>(a, is1x1, s);
+        case 25: return launch_v2<DT, ODT, 128, 64, 64, 32, 2>(a, is1x1, s);
+        case 26: return launch_v2<DT, ODT, 128, 32, 32, 32, 2>(a, is1x1, s);   // 20 KB LDS: 8 blocks / CU
+        case 27: return launch_v2<DT, ODT, 64, 64, 32, 32, 2>(a, is1x1, s);    // 16 KB LDS
         case 1: return launch_cfg<DT, ODT, 128, 128, 64, 64>(a, is1x1, s);
         case 2: return launch_cfg<DT, ODT, 256, 64, 64, 64>(a, is1x1, s);
         case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(a, is1x1, s);

@@ -247,11 +247,11 @@ class Plan:
         hit = Plan._TUNE_CACHE.get(key)
         if hit is not None:
             return hit
-        cands = [11, 12, 13, 14, 15]
+        cands = [11, 12, 14, 15, 21, 22, 24, 25, 27]
         if d.cout_pad <= 32:
-            cands = [13, 15, 12]
+            cands = [13, 23, 26, 25]
         elif d.cout_pad <= 64:
-            cands = [12, 15, 13, 11]
+            cands = [12, 15, 22, 25, 23, 26, 27]
         best, best_ms = 0, float("inf")
         stream = _lib.stream_ptr()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
