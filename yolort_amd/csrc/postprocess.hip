@@ -80,95 +80,124 @@ struct DecodeArgs {
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+constexpr int DEC_PIX_PER_WAVE = 8;     // pixels walked by one wave
+constexpr int DEC_BUF = 512;            // candidate records buffered per wave in LDS before ONE global atomic
+
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+    // One wave walks DEC_PIX_PER_WAVE consecutive pixels.  Candidates are appended to a per-wave LDS
+    // buffer and flushed with a single atomicAdd on the global counter (one hot word saturates at
+    // ~88 atomics/us: one atomic per pixel made this kernel atomic-bound).
+    __shared__ uint64_t buf_hi[4][DEC_BUF];
+    __shared__ uint32_t buf_lo[4][DEC_BUF];
     const int lane = threadIdx.x & 63;
-    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wl = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wl;
     const int64_t npix = (int64_t)a.n * a.h * a.w;
-    if (pix >= npix) return;
     const int hw = a.h * a.w;
-    const int img = (int)(pix / hw);
-    const int rem = (int)(pix - (int64_t)img * hw);
-    const int y = rem / a.w, x = rem - y * a.w;
     const int nch = 3 * a.K;
-    const float* row = a.logits + pix * a.cs;
-    // channels handled by this lane in pass p: c = (p*64 + lane)*4 + e
     const int npass = cdiv(nch, 256);
-    // objectness + box logits of the three anchors (uniform loads, L1 hits)
-    float obj[3];
-    bool any_obj = false;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        obj[k] = sigmoid_acc(row[k * a.K + 4]);
-        any_obj |= obj[k] > a.thr;
-    }
-    // decoded boxes: lanes 0..2 own anchor `lane`
-    if (lane < 3) {
-        const float* r = row + lane * a.K;
-        const float sx = sigmoid_acc(r[0]), sy = sigmoid_acc(r[1]), sw = sigmoid_acc(r[2]), sh = sigmoid_acc(r[3]);
-        // _utils.py:59-60: xy = (s*2 - 0.5 + grid) * stride ; wh = (s*2)**2 * anchor   (each op rounded)
-        const float cx = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sx, 2.0f), 0.5f), (float)x), a.stride);
-        const float cy = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sy, 2.0f), 0.5f), (float)y), a.stride);
-        const float w2 = __fmul_rn(sw, 2.0f), h2 = __fmul_rn(sh, 2.0f);
-        const float bw = __fmul_rn(__fmul_rn(w2, w2), a.anc[2 * lane]);
-        const float bh = __fmul_rn(__fmul_rn(h2, h2), a.anc[2 * lane + 1]);
-        // box_convert cxcywh -> xyxy (box_head.py:358)
-        const float hw_ = __fmul_rn(0.5f, bw), hh_ = __fmul_rn(0.5f, bh);
-        f32x4 b = {__fsub_rn(cx, hw_), __fsub_rn(cy, hh_), __fadd_rn(cx, hw_), __fadd_rn(cy, hh_)};
-        const int anchor = a.level_off + (lane * a.h + y) * a.w + x;
-        *reinterpret_cast<f32x4*>(a.boxes_all + ((int64_t)img * a.total_anchors + anchor) * 4) = b;
-    }
-    if (!any_obj) return;
-    for (int p = 0; p < npass; ++p) {
-        const int c0 = (p * 64 + lane) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c0 + 3 < nch) v = *reinterpret_cast<const f32x4*>(row + c0);
-        else
-            for (int e = 0; e < 4; ++e)
-                if (c0 + e < nch) v[e] = row[c0 + e];
-        float sc[4];
-        unsigned cand[4];
-        int cnt = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c0 + e;
-            const int k = c / a.K, cls = c - k * a.K - 5;
-            bool ok = (c < nch) && (cls >= 0);
-            float s = 0.f;
-            if (ok) {
-                const float o = k == 0 ? obj[0] : (k == 1 ? obj[1] : obj[2]);
-                s = __fmul_rn(sigmoid_acc(v[e]), o);  // box_head.py:357 scores = cls * obj
-                ok = s > a.thr;                        // box_head.py:418 strict >
-            }
-            sc[e] = s;
-            const int anchor = a.level_off + (k * a.h + y) * a.w + x;
-            cand[e] = ((unsigned)anchor << a.label_bits) | (unsigned)(cls < 0 ? 0 : cls);
-            if (!ok) cand[e] = 0xffffffffu;
-            cnt += ok ? 1 : 0;
-        }
-        // wave-level ordered allocation: inclusive scan of cnt over lanes
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        const int total = __shfl(incl, 63, 64);
-        if (total == 0) continue;
+    uint64_t* bhi = buf_hi[wl];
+    uint32_t* blo = buf_lo[wl];
+    int fill = 0;   // records in the LDS buffer (wave-uniform)
+
+    auto flush = [&]() {
+        if (fill == 0) return;
         int base = 0;
-        if (lane == 0) base = atomicAdd(&a.status[ST_NCAND], total);
+        if (lane == 0) base = atomicAdd(&a.status[ST_NCAND], fill);
         base = __shfl(base, 0, 64);
-        int pos = base + incl - cnt;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (cand[e] != 0xffffffffu) {
-                if (pos < a.cap) {
-                    a.hi[pos] = ((uint64_t)(unsigned)img << 32) | (uint64_t)(~__float_as_uint(sc[e]));
-                    a.lo[pos] = cand[e];
-                }
-                ++pos;
+        for (int i = lane; i < fill; i += 64) {
+            const int pos = base + i;
+            if (pos < a.cap) {
+                a.hi[pos] = bhi[i];
+                a.lo[pos] = blo[i];
             }
         }
+        fill = 0;
+    };
+
+    for (int pp = 0; pp < DEC_PIX_PER_WAVE; ++pp) {
+        const int64_t pix = wave * DEC_PIX_PER_WAVE + pp;
+        if (pix >= npix) break;
+        const int img = (int)(pix / hw);
+        const int rem = (int)(pix - (int64_t)img * hw);
+        const int y = rem / a.w, x = rem - y * a.w;
+        const float* row = a.logits + pix * a.cs;
+        float obj[3];
+        bool any_obj = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            obj[k] = sigmoid_acc(row[k * a.K + 4]);
+            any_obj |= obj[k] > a.thr;
+        }
+        if (lane < 3) {
+            const float* r = row + lane * a.K;
+            const float sx = sigmoid_acc(r[0]), sy = sigmoid_acc(r[1]), sw = sigmoid_acc(r[2]), sh = sigmoid_acc(r[3]);
+            // _utils.py:59-60: xy = (s*2 - 0.5 + grid) * stride ; wh = (s*2)**2 * anchor   (each op rounded)
+            const float cx = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sx, 2.0f), 0.5f), (float)x), a.stride);
+            const float cy = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sy, 2.0f), 0.5f), (float)y), a.stride);
+            const float w2 = __fmul_rn(sw, 2.0f), h2 = __fmul_rn(sh, 2.0f);
+            const float bw = __fmul_rn(__fmul_rn(w2, w2), a.anc[2 * lane]);
+            const float bh = __fmul_rn(__fmul_rn(h2, h2), a.anc[2 * lane + 1]);
+            // box_convert cxcywh -> xyxy (box_head.py:358)
+            const float hw_ = __fmul_rn(0.5f, bw), hh_ = __fmul_rn(0.5f, bh);
+            f32x4 b = {__fsub_rn(cx, hw_), __fsub_rn(cy, hh_), __fadd_rn(cx, hw_), __fadd_rn(cy, hh_)};
+            const int anchor = a.level_off + (lane * a.h + y) * a.w + x;
+            *reinterpret_cast<f32x4*>(a.boxes_all + ((int64_t)img * a.total_anchors + anchor) * 4) = b;
+        }
+        if (!any_obj) continue;
+        if (fill + nch > DEC_BUF) flush();   // a pixel yields at most nch - 15 records
+        for (int p = 0; p < npass; ++p) {
+            const int c0 = (p * 64 + lane) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + 3 < nch) v = *reinterpret_cast<const f32x4*>(row + c0);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < nch) v[e] = row[c0 + e];
+            float sc[4];
+            unsigned cand[4];
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                const int k = c / a.K, cls = c - k * a.K - 5;
+                bool ok = (c < nch) && (cls >= 0);
+                float s = 0.f;
+                if (ok) {
+                    const float o = k == 0 ? obj[0] : (k == 1 ? obj[1] : obj[2]);
+                    s = __fmul_rn(sigmoid_acc(v[e]), o);  // box_head.py:357 scores = cls * obj
+                    ok = s > a.thr;                        // box_head.py:418 strict >
+                }
+                sc[e] = s;
+                const int anchor = a.level_off + (k * a.h + y) * a.w + x;
+                cand[e] = ((unsigned)anchor << a.label_bits) | (unsigned)(cls < 0 ? 0 : cls);
+                if (!ok) cand[e] = 0xffffffffu;
+                cnt += ok ? 1 : 0;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (total == 0) continue;
+            if (fill + total > DEC_BUF) flush();   // only reachable when nch > DEC_BUF (many classes)
+            int pos = fill + incl - cnt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (cand[e] != 0xffffffffu) {
+                    if (pos < DEC_BUF) {
+                        bhi[pos] = ((uint64_t)(unsigned)img << 32) | (uint64_t)(~__float_as_uint(sc[e]));
+                        blo[pos] = cand[e];
+                    }
+                    ++pos;
+                }
+            }
+            fill += total;
+            if (fill > DEC_BUF) fill = DEC_BUF;   // unreachable for total <= DEC_BUF; guards the buffer
+        }
     }
+    flush();
 }
 
 __global__ void finalize_count_kernel(int* status, int cap) {
@@ -347,20 +376,25 @@ __device__ __forceinline__ bool iou_gt(const f32x4 bi, float area_i, const f32x4
     return iou > thr;
 }
 
+constexpr int NMS_KCAP = 384;   // kept boxes per wave held in LDS (6 KiB / wave); the rest spills to HBM scratch
+
 __global__ __launch_bounds__(256) void nms_segments_kernel(const uint64_t* phi, const uint32_t* plo, const uint64_t* ghi, const uint32_t* glo,
                                                            const float* boxes_all, int total_anchors, int label_bits, const int* status, int cap,
                                                            const uint32_t* seg_start, float* kept_box, uint8_t* keep, float thr) {
+    __shared__ f32x4 kept_lds[4][NMS_KCAP];
     const int n = ncand(status, cap);
     const int nseg = status[ST_NSEG];
     const int lane = threadIdx.x & 63;
+    const int wave_local = threadIdx.x >> 6;
     const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * 256) >> 6;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    f32x4* kl = kept_lds[wave_local];
     for (int s = wave_global; s < nseg; s += nwaves) {
         const int start = (int)seg_start[s];
         const uint64_t key = phi[start];
         int kept_cnt = 0;
-        f32x4* kb = reinterpret_cast<f32x4*>(kept_box) + start;
+        f32x4* kb = reinterpret_cast<f32x4*>(kept_box) + start;   // spill area: kept <= segment length
         for (int c = start;; c += 64) {
             const int p = c + lane;
             const bool valid = p < n && phi[p] == key;
@@ -376,8 +410,14 @@ __global__ __launch_bounds__(256) void nms_segments_kernel(const uint64_t* phi, 
             }
             const float area = __fmul_rn(__fsub_rn(box[2], box[0]), __fsub_rn(box[3], box[1]));
             bool alive = valid;
-            // against boxes already kept in this segment (higher score)
-            for (int j = 0; j < kept_cnt; ++j) {
+            // against boxes already kept in this segment (higher score): LDS broadcast reads, HBM beyond NMS_KCAP
+            const int in_lds = kept_cnt < NMS_KCAP ? kept_cnt : NMS_KCAP;
+            for (int j = 0; j < in_lds; ++j) {
+                const f32x4 k = kl[j];
+                const float ka = __fmul_rn(__fsub_rn(k[2], k[0]), __fsub_rn(k[3], k[1]));
+                if (alive && iou_gt(k, ka, box, area, thr)) alive = false;
+            }
+            for (int j = NMS_KCAP; j < kept_cnt; ++j) {
                 const f32x4 k = kb[j];
                 const float ka = __fmul_rn(__fsub_rn(k[2], k[0]), __fsub_rn(k[3], k[1]));
                 if (alive && iou_gt(k, ka, box, area, thr)) alive = false;
@@ -399,11 +439,12 @@ __global__ __launch_bounds__(256) void nms_segments_kernel(const uint64_t* phi, 
                 todo &= mask;
             }
             if (alive) {
-                kb[kept_cnt + __popcll(mask & lt)] = box;
+                const int slot = kept_cnt + __popcll(mask & lt);
+                if (slot < NMS_KCAP) kl[slot] = box; else kb[slot] = box;
                 keep[r] = 1;
             }
             kept_cnt += __popcll(mask);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // kept boxes visible to this wave's later loads
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // kept boxes (LDS / HBM) visible to this wave's later reads
             if (vmask != ~0ull) break;  // last (partial) step of the segment
         }
     }
@@ -584,7 +625,7 @@ int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
         a.n = d->n; a.K = d->num_classes + 5; a.level_off = level_off; a.total_anchors = total_anchors; a.label_bits = label_bits;
         a.thr = d->score_thresh; a.boxes_all = w.boxes_all; a.hi = w.hi[0]; a.lo = w.lo[0]; a.status = d->status; a.cap = d->cand_cap;
         const int64_t npix = (int64_t)d->n * a.h * a.w;
-        hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((npix + 4 * DEC_PIX_PER_WAVE - 1) / (4 * DEC_PIX_PER_WAVE))), dim3(256), 0, s, a);
         level_off += 3 * a.h * a.w;
     }
     hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(64), 0, s, d->status, d->cand_cap);
