@@ -138,6 +138,16 @@ def test_conv_v1_v2_agree_at_scale(dev, k, s, p, cin, cout, hw):
         _run_conv(dev, torch.float16, n=2, cin=cin, cout=cout, h=hw, w=hw, k=k, s=s, p=p, tile=tile, seed=k + cin)
 
 
+@pytest.mark.parametrize("variant", [31, 32, 33, 34, 35, 36, 37])
+@pytest.mark.parametrize("shape", [dict(n=2, cin=32, cout=32, h=40, w=40), dict(n=1, cin=64, cout=64, h=33, w=21), dict(n=2, cin=128, cout=128, h=20, w=20),
+                                   dict(n=1, cin=32, cout=64, h=8, w=16), dict(n=3, cin=64, cout=96, h=17, w=35)])
+def test_conv3x3_halo_kernel(dev, variant, shape):
+    """LDS-halo 3x3 s1 kernel (activation patch resident in LDS across the nine taps), incl. ragged
+    image sizes (partial patches), residual and channel-slice views"""
+    _run_conv(dev, torch.float16, k=3, s=1, p=1, tile=variant, residual=True, x_cs_extra=32, y_cs_extra=64, seed=variant, **shape)
+    _run_conv(dev, torch.bfloat16, k=3, s=1, p=1, tile=variant, seed=variant + 1, **shape)
+
+
 def test_conv_head_fp32_out(dev):
     from yolort_amd import engine
     g = torch.Generator().manual_seed(3)
