@@ -165,19 +165,24 @@ def test_conv_head_fp32_out(dev):
     assert (got - ref).abs().max().item() < 2e-3
 
 
-def test_stem_superpixel(dev):
-    """Conv(3, c, k=6, s=2, p=2) (darknetv6.py:81) through the NHWC4 super-pixel formulation."""
+@pytest.mark.parametrize("tile", [0, 13, 23, 26, 41, -100])
+@pytest.mark.parametrize("cout,hw", [(32, (64, 96)), (48, (96, 160)), (16, (32, 64)), (64, (160, 224))])
+def test_stem_superpixel(dev, tile, cout, hw):
+    """Conv(3, c, k=6, s=2, p=2) (darknetv6.py:81) through the NHWC4 super-pixel formulation: generic
+    implicit-GEMM tiles, the dedicated stem kernel (41) and the autotuned choice (0)."""
     from yolort_amd import engine
-    g = torch.Generator().manual_seed(5)
-    x = torch.rand(2, 3, 64, 96, generator=g).half().float()
-    wt = (torch.randn(32, 3, 6, 6, generator=g) / 10).half().float()
-    b = torch.randn(32, generator=g) * 0.1
+    g = torch.Generator().manual_seed(5 + cout)
+    x = torch.rand(2, 3, hw[0], hw[1], generator=g).half().float()
+    wt = (torch.randn(cout, 3, 6, 6, generator=g) / 10).half().float()
+    b = torch.randn(cout, generator=g) * 0.1
     ref = F.silu(F.conv2d(x, wt, b, 2, 2))
     plan = engine.Plan(dev, torch.float16)
-    xv = plan.alloc(2, 64, 96, 4, zero=True)
+    xv = plan.alloc(2, hw[0], hw[1], 4, zero=True)
     xv.as_tensor()[..., :3].copy_(_nhwc(x).to(dev, torch.float16))
     pc = engine.PackedConv(wt, b, None, torch.float16, dev, stem_superpixel=True)
-    y = plan.conv(xv, pc, 2, 2)
+    if tile in (13, 23, 26) and cout > 32:
+        pytest.skip("32-wide cout tiles only")
+    y = plan.conv(xv, pc, 2, 2, tile=tile)
     plan.run()
     got = y.as_tensor().float().cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape

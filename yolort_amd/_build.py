@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libyolort_amd.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "preproc_pool.hip", "postprocess.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_stem.hip", "preproc_pool.hip", "postprocess.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "conv_common.hpp"), os.path.join(os.path.dirname(PKG), "include", "yolort_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 

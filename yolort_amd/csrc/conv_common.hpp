@@ -73,5 +73,7 @@ __device__ __forceinline__ void glds16(const uint16_t* g, uint16_t* lds_wave_uni
 
 // 3x3 stride-1 LDS-halo kernel (conv3x3_halo.hip); returns YMI_EINVAL when the shape does not apply
 int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
+// dedicated stem kernel (conv_stem.hip): 6x3 s(2,1) super-pixel form, input patch in LDS, weights in registers
+int conv_stem_launch(const ConvArgs& a, int dtype, int out_dtype, hipStream_t s);
 
 }  // namespace ymi

@@ -663,6 +663,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         return YMI_EINVAL;
     }
     if (tile >= 31 && tile <= 39) return conv3x3_halo_launch(a, DT, ODT, tile - 30, s);   // LDS-halo 3x3 s1 kernel
+    if (tile == 41) return conv_stem_launch(a, DT, ODT, s);                                // dedicated stem kernel
     switch (tile) {
         case 11: return launch_v2<DT, ODT, 128, 128, 64, 64, 4>(a, is1x1, s);
         case 12: return launch_v2<DT, ODT, 256, 64, 64, 64, 3>(a, is1x1, s);

@@ -1,0 +1,166 @@
+// YOLOv5 r6.0 stem: Conv(3, c, k=6, s=2, p=2) + BN + SiLU (reference yolort/models/darknetv6.py:81,
+// yolort/v5/models/common.py:69-70) over the NHWC4 (RGB0) letterboxed batch.
+//
+// The plan presents the stem as a 6x3, stride (2,1), pad (2,1) convolution over width-halved
+// "super-pixels" of 8 channels (2 pixels x RGB0, 16 bytes).  The implicit-GEMM kernel runs it at the
+// LDS-fill limit (every super-pixel is fetched 9 times).  This kernel instead gives each block an
+// 8 x 32 output tile of one image: its (2*8+4) x (32+2) super-pixel input patch (10.9 KiB) is DMA'd into
+// LDS once, the whole folded weight matrix (<= 64 x 144) sits in registers, and the 18 taps read their
+// MFMA fragments from the patch at constant offsets (16-byte lane stride: conflict free).
+// K = 18 taps x 8 = 144 = 9 MFMA k16 steps (lanes 0-31 take tap 2s, lanes 32-63 tap 2s+1).
+#include "conv_common.hpp"
+
+namespace ymi {
+
+constexpr int STH = 8, STW = 32;                 // output tile
+constexpr int SPH = 2 * STH + 4, SPW = STW + 2;  // input patch: 20 rows x 34 super-pixels
+constexpr int SPIECES = 11;                      // ceil(20*34 / 64) DMA pieces of 64 super-pixels (1 KiB)
+
+template <int DT, int ODT, int TN>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    typedef typename Mfma<DT>::frag frag;
+    __shared__ __attribute__((aligned(16))) uint16_t patch[12 * 512];   // 12 KiB (680 super-pixels used)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = a.nblk_m;
+    int t = xcd_remap(blockIdx.x, nblk);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int img = t / tiles_y;
+    const int oy0 = ty * STH, ox0 = tx * STW;
+
+    // ---- patch: super-pixel q -> (row q/34, col q%34) -> input (2*oy0 - 2 + row, ox0 - 1 + col) ----
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int pi = wave * 3 + j;
+        pi = pi < SPIECES ? pi : SPIECES - 1;
+        const int q = pi * 64 + lane;
+        const int qc = q < SPH * SPW ? q : SPH * SPW - 1;
+        const int pr = qc / SPW, pc = qc - pr * SPW;
+        const int iy = 2 * oy0 - 2 + pr, ix = ox0 - 1 + pc;
+        const bool ok = (q < SPH * SPW) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w_in);
+        const int off = ok ? ((img * a.h + iy) * a.w_in + ix) * a.x_cs : a.x_zero_off;
+        glds16(a.x + off, patch + pi * 512);
+    }
+    // ---- weights: all 9 k16-steps of this lane's cout row(s) into registers (L2-resident, 16 B loads) ----
+    frag wf[TN][9];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const uint16_t* wr = a.w + (int64_t)(i * 32 + (lane & 31)) * a.k_pad + 8 * (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) wf[i][s] = *reinterpret_cast<const frag*>(wr + 16 * s);
+    }
+    f32x16 acc[TN][2];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // wave w owns output rows 2w, 2w+1 of the tile (two groups of 32 pixels)
+    const int hi = lane >> 5, px = lane & 31;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        // tap = 2s + hi -> (ky, kx') = (tap / 3, tap % 3): compile-time per half
+        const int tap0 = 2 * s, tap1 = 2 * s + 1;
+        const int o0 = (tap0 / 3) * SPW + (tap0 % 3), o1 = (tap1 / 3) * SPW + (tap1 % 3);
+        const int toff = hi ? o1 : o0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 2 * (2 * wave + j);   // patch row of output row (2w + j) at ky = 0
+            const frag af = *reinterpret_cast<const frag*>(patch + (row * SPW + px + toff) * 8);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) acc[i][j] = Mfma<DT>::run(wf[i][s], af, acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: bias + SiLU, permlane32 swap, 16-byte stores ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int oy = oy0 + 2 * wave + j, ox = ox0 + px;
+        const bool m_ok = oy < a.ho && ox < a.wo;
+        const int64_t m = ((int64_t)img * a.ho + oy) * a.wo + ox;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int cbase = i * 32;
+            if (cbase >= a.cout) continue;
+            uint32_t pk[4][2];
+            float v[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cbase + g * 8 + hi * 4;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (co < a.cout_pad) b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tv = acc[i][j][g * 4 + e] + b[e];
+                    if (a.act == YMI_ACT_SILU) tv = silu(tv);
+                    v[g][e] = tv;
+                }
+                pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
+                pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
+            }
+            if constexpr (ODT == YMI_F32) {
+                if (!m_ok) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cbase + g * 8 + hi * 4;
+                    float* yp = reinterpret_cast<float*>(a.y) + m * a.y_cs + co;
+                    for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[g][e];
+                }
+            } else {
+                const bool wide = cbase + 32 <= a.cout;
+                if (wide) {
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        uint32_t ax = pk[g][0], ay = pk[g][1], bx = pk[g + 1][0], by = pk[g + 1][1];
+                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                        ax = rx[0]; bx = rx[1];
+                        ay = ry[0]; by = ry[1];
+                        if (m_ok) {
+                            u32x4 o = {ax, ay, bx, by};
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + cbase + (g + hi) * 8) = o;
+                        }
+                    }
+                } else if (m_ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = cbase + g * 8 + hi * 4;
+                        uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + co;
+                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[g][e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int ODT>
+static int stem_launch_t(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    const int tiles_x = cdiv(a.wo, STW), tiles_y = cdiv(a.ho, STH);
+    a.nblk_m = a.n * tiles_x * tiles_y;
+    a.nblk_n = 1;
+    dim3 grid(a.nblk_m), block(256);
+    if (a.cout_pad <= 32) hipLaunchKernelGGL((conv_stem_kernel<DT, ODT, 1>), grid, block, 0, s, a, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_stem_kernel<DT, ODT, 2>), grid, block, 0, s, a, tiles_x, tiles_y);
+    return check_launch("conv_stem_kernel");
+}
+
+int conv_stem_launch(const ConvArgs& a, int dtype, int out_dtype, hipStream_t s) {
+    YMI_REQUIRE(a.cin == 8 && a.kh == 6 && a.kw == 3 && a.sh == 2 && a.sw == 1 && a.ph == 2 && a.pw == 1 && a.x_cs == 8 && a.k_pad >= 144 &&
+                    a.cout_pad <= 64 && a.zeros != nullptr && a.split == 0 && a.res == nullptr,
+                "ymi_conv2d: the stem kernel handles the 6x3 s(2,1) p(2,1) super-pixel form with cout <= 64 only");
+    if (dtype == YMI_F16) return out_dtype == YMI_F32 ? stem_launch_t<YMI_F16, YMI_F32>(a, s) : stem_launch_t<YMI_F16, YMI_F16>(a, s);
+    return out_dtype == YMI_F32 ? stem_launch_t<YMI_BF16, YMI_F32>(a, s) : stem_launch_t<YMI_BF16, YMI_BF16>(a, s);
+}
+
+}  // namespace ymi

@@ -255,6 +255,8 @@ class Plan:
         if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin % 32 == 0 and d.cout_split == 0 and d.k_pad == 9 * d.cin:
             # LDS-halo kernel variants (activation patch resident in LDS across the nine taps)
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
+        if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
+            cands = cands + [41]   # dedicated stem kernel
         best, best_ms = 0, float("inf")
         stream = _lib.stream_ptr()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
