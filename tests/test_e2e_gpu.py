@@ -167,6 +167,78 @@ def test_mixed_sizes_and_yolo_forward(dev):
         assert frac >= 0.9 and miou >= 0.9, (frac, miou)
 
 
+def test_baseline_config1_yolov5n_thr045(dev):
+    """BASELINE.json configs[0]: yolov5n score_thresh=0.45 on 2 x 640x640 random images (the reference's own
+    CPU-runnable case), here with the seeded synthetic weights so that detections exist."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models import yolov5n
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    m = yolov5n(score_thresh=0.45)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+    m = m.to(dev).half().eval()
+    imgs = [synth_images(1, 640, 640, seed=i + 1)[0] for i in range(2)]
+    dets = m.predict([im.to(dev) for im in imgs])
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs, sd, score_thresh=0.45)
+    for r, d in zip(ref, dets):
+        assert len(r["scores"]) > 20
+        frac, miou, _ = match_fraction(_np(r), _np(d), margin=0.03, thr=0.45)
+        assert frac >= 0.9 and miou >= 0.93, (frac, miou, len(r["scores"]))
+
+
+def test_baseline_config3_yolov5m_bf16_dynamic_1280(dev):
+    """BASELINE.json configs[2] at reduced batch: yolov5m bf16, size (1280,1280), images whose shapes hit the
+    letterbox rounding traps -> per-image bilinear gather + common canvas."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models import yolov5m
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_m_r60"
+    m = yolov5m(size=(1280, 1280), score_thresh=0.3)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0))
+    m = m.to(dev).to(torch.bfloat16).eval()
+    shapes = [(641, 480), (375, 500), (1281, 1279)]
+    imgs = [synth_images(1, h, w, seed=31 + i)[0] for i, (h, w) in enumerate(shapes)]
+    dets = m.predict([im.to(dev) for im in imgs])
+    e = next(iter(m.model._entries.values()))
+    assert (e.x.h, e.x.w) == (1280, 1280)   # canvas of the mixed batch
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs, sd, size=(1280, 1280), score_thresh=0.3)
+    for r, d in zip(ref, dets):
+        frac, miou, _ = match_fraction(_np(r), _np(d), iou_thr=0.5, score_tol=0.15, margin=0.1, thr=0.3)
+        assert frac >= 0.6 and miou >= 0.7, (frac, miou, len(r["scores"]))
+
+
+def test_uint8_ingest_matches_float_path(dev):
+    """uint8 images: /255 is fused into the letterbox kernel; same detections as feeding x/255."""
+    from yolort_amd.utils.synth import synth_images
+    m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.3, head_gain=1.0)
+    u8 = [(synth_images(1, 240, 320, seed=7)[0] * 255).round().to(torch.uint8), (synth_images(1, 300, 200, seed=8)[0] * 255).round().to(torch.uint8)]
+    a = m.predict([u.to(dev) for u in u8])
+    b = m.predict([(u.float() / 255.0).to(dev) for u in u8])
+    # the float path rounds x/255 to fp16 before the resize, the uint8 path after it: same detections up to that rounding
+    for x, y in zip(a, b):
+        frac, miou, ds = match_fraction(_np(y), _np(x), margin=0.02, thr=0.3, score_tol=0.02)
+        assert frac >= 0.97 and miou >= 0.97, (frac, miou, ds)
+
+
+def test_async_pipeline_matches_sync(dev):
+    """several batches in flight (forward_async) return exactly what the synchronous calls return"""
+    from yolort_amd.utils.synth import synth_images
+    m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(160, 160), score_thresh=0.3, head_gain=1.0)
+    batches = [[synth_images(1, 128, 160, seed=50 + 2 * i)[0].to(dev), synth_images(1, 160, 120, seed=51 + 2 * i)[0].to(dev)] for i in range(6)]
+    sync = [m.forward(b) for b in batches]
+    pend = [m.forward_async(b) for b in batches[:3]]
+    out = [p.result() for p in pend]
+    pend = [m.forward_async(b) for b in batches[3:]]
+    out += [p.result() for p in pend]
+    for s_, o_ in zip(sync, out):
+        for x, y in zip(s_, o_):
+            assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["scores"], y["scores"]) and torch.equal(x["boxes"], y["boxes"])
+
+
 def test_p6_model_runs(dev):
     from oracle import yolov5_oracle as O
     from yolort_amd.utils.synth import synth_images
