@@ -28,6 +28,9 @@ struct Workspace {
     uint32_t* seg_start;  // (cand_cap) segment start positions (unordered)
     float* kept_box;      // (cand_cap, 4) per-segment kept boxes
     uint8_t* keep;        // (cand_cap) keep flag indexed by global rank r
+    int* img_count;       // (n) candidates appended per image (per-image sort path)
+    uint64_t* p_hi;       // per-class order P of the per-image sort path (cand_cap each)
+    uint32_t* p_lo;
     int64_t total;
 };
 
@@ -50,6 +53,9 @@ static Workspace carve(void* ws, int n, int total_anchors, int cand_cap) {
     w.seg_start = (uint32_t*)take((int64_t)cand_cap * 4);
     w.kept_box = (float*)take((int64_t)cand_cap * 16);
     w.keep = (uint8_t*)take((int64_t)cand_cap);
+    w.img_count = (int*)take((int64_t)(n > 0 ? n : 1) * 4);
+    w.p_hi = (uint64_t*)take((int64_t)cand_cap * 8);
+    w.p_lo = (uint32_t*)take((int64_t)cand_cap * 4);
     w.total = off;
     return w;
 }
@@ -76,6 +82,8 @@ struct DecodeArgs {
     uint32_t* lo;
     int* status;
     int cap;
+    int* img_count;   // non-null: append to per-image regions [img*cap_img, +cap_img) (per-image LDS sort path)
+    int cap_img;
 };
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -98,18 +106,31 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     const int npass = cdiv(nch, 256);
     uint64_t* bhi = buf_hi[wl];
     uint32_t* blo = buf_lo[wl];
-    int fill = 0;   // records in the LDS buffer (wave-uniform)
+    int fill = 0;      // records in the LDS buffer (wave-uniform)
+    int fill_img = 0;  // image the buffered records belong to (per-image path flushes on image change)
 
     auto flush = [&]() {
         if (fill == 0) return;
         int base = 0;
-        if (lane == 0) base = atomicAdd(&a.status[ST_NCAND], fill);
-        base = __shfl(base, 0, 64);
-        for (int i = lane; i < fill; i += 64) {
-            const int pos = base + i;
-            if (pos < a.cap) {
-                a.hi[pos] = bhi[i];
-                a.lo[pos] = blo[i];
+        if (a.img_count != nullptr) {
+            if (lane == 0) base = atomicAdd(&a.img_count[fill_img], fill);
+            base = __shfl(base, 0, 64);
+            for (int i = lane; i < fill; i += 64) {
+                const int pos = base + i;
+                if (pos < a.cap_img) {
+                    a.hi[(int64_t)fill_img * a.cap_img + pos] = bhi[i];
+                    a.lo[(int64_t)fill_img * a.cap_img + pos] = blo[i];
+                }
+            }
+        } else {
+            if (lane == 0) base = atomicAdd(&a.status[ST_NCAND], fill);
+            base = __shfl(base, 0, 64);
+            for (int i = lane; i < fill; i += 64) {
+                const int pos = base + i;
+                if (pos < a.cap) {
+                    a.hi[pos] = bhi[i];
+                    a.lo[pos] = blo[i];
+                }
             }
         }
         fill = 0;
@@ -145,7 +166,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
             *reinterpret_cast<f32x4*>(a.boxes_all + ((int64_t)img * a.total_anchors + anchor) * 4) = b;
         }
         if (!any_obj) continue;
-        if (fill + nch > DEC_BUF) flush();   // a pixel yields at most nch - 15 records
+        if (fill + nch > DEC_BUF || img != fill_img) flush();   // a pixel yields at most nch - 15 records
+        fill_img = img;
         for (int p = 0; p < npass; ++p) {
             const int c0 = (p * 64 + lane) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -337,6 +359,121 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* hi_i
         __builtin_amdgcn_wave_barrier();
         if (dig[r] != 0x100u && (peers[r] & lt) == 0) wave_base[wave][dig[r]] += __popcll(peers[r]);
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2b. per-image sort in LDS (the common case: <= 16384 candidates per image).  decode appended each
+//     image's records to its own region, so ONE launch (a 1024-thread block per image) replaces the
+//     ten three-kernel radix passes: bitonic sort of the unique 64-bit keys (~score << 32 | cand)
+//     gives the G order (score descending, ties by candidate index), a second bitonic sort of
+//     (label << 32 | rank) gives the per-class P order the NMS walks.  G and P are written compactly
+//     (image offsets = prefix of the counts), exactly as the radix path leaves them.
+// ------------------------------------------------------------------------------------------
+constexpr int IMG_SORT_MAX = 16384;
+
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, int np2) {
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = key[i], y = key[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((x > y) == asc) { key[i] = y; key[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// number of keys of the sorted run `run[0..len)` that are < key (keys are unique)
+__device__ __forceinline__ int lower_bound_u64(const uint64_t* run, int len, uint64_t key) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (run[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Sorts keys[0..n) (HBM, unique 64-bit keys) ascending into dst order: runs of up to `lds_keys` keys are
+// bitonic-sorted in LDS and written back; with more than one run every key's final rank is its rank
+// in its own run plus its lower_bound in every other run (merge by ranking, fully parallel).
+// rank_out[i] receives the final rank of the key stored at position i after the run sort.
+__device__ void sort_runs(uint64_t* keys, int n, uint64_t* lds_key, int lds_keys, uint32_t* rank_out) {
+    const int nruns = (n + lds_keys - 1) / lds_keys;
+    for (int r = 0; r < nruns; ++r) {
+        const int r0 = r * lds_keys;
+        const int len = n - r0 < lds_keys ? n - r0 : lds_keys;
+        int np2 = 64;
+        while (np2 < len) np2 <<= 1;
+        for (int i = threadIdx.x; i < np2; i += blockDim.x) lds_key[i] = i < len ? keys[r0 + i] : ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(lds_key, np2);
+        for (int i = threadIdx.x; i < len; i += blockDim.x) keys[r0 + i] = lds_key[i];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i / lds_keys;
+        int rank = i - r * lds_keys;
+        if (nruns > 1) {
+            const uint64_t k = keys[i];
+            for (int q = 0; q < nruns; ++q) {
+                if (q == r) { rank += 0; continue; }
+                const int q0 = q * lds_keys;
+                const int qlen = n - q0 < lds_keys ? n - q0 : lds_keys;
+                rank += lower_bound_u64(keys + q0, qlen, k);
+            }
+            // ranks of earlier runs' elements are already counted through lower_bound; add nothing else
+        }
+        rank_out[i] = (uint32_t)rank;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void sort_image_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, int cap_img, int n_img,
+                                                          int label_bits, int lds_keys, uint64_t* ghi, uint32_t* glo, uint64_t* phi, uint32_t* plo,
+                                                          uint8_t* keep, int* status) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_key[];
+    __shared__ int s_off;
+    const int img = blockIdx.x;
+    const int raw = img_count[img];
+    const int n_i = raw < cap_img ? raw : cap_img;
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int j = 0; j < img; ++j) { const int c = img_count[j]; off += c < cap_img ? c : cap_img; }
+        s_off = off;
+        atomicAdd(&status[ST_NCAND], n_i);
+        if (raw > cap_img) { status[ST_OVERFLOW] = 1; atomicMax(&status[ST_RSV], raw); }
+    }
+    const int64_t base = (int64_t)img * cap_img;
+    uint64_t* keys = in_hi + base;      // this image's region doubles as key scratch (u64 per record)
+    uint32_t* rank = in_lo + base;      // ... and as rank scratch once the candidate ids moved into the keys
+    for (int i = threadIdx.x; i < n_i; i += blockDim.x)
+        keys[i] = ((uint64_t)(uint32_t)keys[i] << 32) | rank[i];   // ~score << 32 | cand  (same index read / written)
+    __syncthreads();
+    const int off = s_off;
+    // G order: score descending, ties by candidate index
+    sort_runs(keys, n_i, lds_key, lds_keys, rank);
+    const uint32_t lmask = (1u << label_bits) - 1u;
+    for (int i = threadIdx.x; i < n_i; i += blockDim.x) {
+        const uint64_t k = keys[i];
+        const uint32_t r = rank[i];
+        ghi[off + r] = ((uint64_t)(unsigned)img << 32) | (k >> 32);
+        glo[off + r] = (uint32_t)k;
+        keep[off + r] = 0;
+        keys[i] = ((uint64_t)((uint32_t)k & lmask) << 32) | r;   // label << 32 | rank in G (unique)
+    }
+    __syncthreads();
+    // P order: by label, then by G rank
+    sort_runs(keys, n_i, lds_key, lds_keys, rank);
+    for (int i = threadIdx.x; i < n_i; i += blockDim.x) {
+        const uint64_t k = keys[i];
+        const uint32_t r = rank[i];
+        phi[off + r] = ((uint64_t)(unsigned)img << 16) | (k >> 32);
+        plo[off + r] = (uint32_t)off + (uint32_t)k;
     }
 }
 
@@ -548,6 +685,23 @@ static int radix_pass(const Workspace& w, SortState& st, int* status, int cap, i
     return check_launch("radix pass");
 }
 
+// segments -> class-aware NMS -> top-k gather, given G (arrays w.hi/lo[g]) and the per-class order P
+static int nms_gather(const Workspace& w, int g, const uint64_t* phi, const uint32_t* plo, int* status, int cap, int n_img, int label_bits, int total_anchors,
+                      float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count, hipStream_t s) {
+    const int nthr_blocks = cdiv(cap, 256);
+    uint32_t* seg_start = w.seg_start;
+    float* kept_box = w.kept_box;
+    hipLaunchKernelGGL(find_segments_kernel, dim3(nthr_blocks), dim3(256), 0, s, phi, status, cap, seg_start);
+    hipLaunchKernelGGL(nms_segments_kernel, dim3(1024), dim3(256), 0, s, phi, plo, w.hi[g], w.lo[g], w.boxes_all, total_anchors, label_bits, status, cap,
+                       seg_start, kept_box, w.keep, nms_thresh);
+    GatherArgs ga;
+    ga.ghi = w.hi[g]; ga.glo = w.lo[g]; ga.keep = w.keep; ga.boxes_all = w.boxes_all; ga.rescale = rescale; ga.status = status;
+    ga.cap = cap; ga.total_anchors = total_anchors; ga.label_bits = label_bits; ga.K = K;
+    ga.out_boxes = out_boxes; ga.out_scores = out_scores; ga.out_labels = out_labels; ga.out_count = out_count;
+    hipLaunchKernelGGL(gather_topk_kernel, dim3(n_img), dim3(256), 0, s, ga);
+    return check_launch("nms/gather");
+}
+
 // sorts records in w.hi/lo[st.cur] by (img, score desc, cand asc), then runs NMS + gather.
 static int sort_nms_gather(const Workspace& w, SortState st, int* status, int cap, int n_img, int lo_bits, int label_bits, int total_anchors,
                            float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count,
@@ -586,15 +740,7 @@ static int sort_nms_gather(const Workspace& w, SortState st, int* status, int ca
         plo = w.lo[p];
     }
     (void)label_passes;
-    hipLaunchKernelGGL(find_segments_kernel, dim3(nthr_blocks), dim3(256), 0, s, phi, status, cap, seg_start);
-    hipLaunchKernelGGL(nms_segments_kernel, dim3(1024), dim3(256), 0, s, phi, plo, w.hi[g], w.lo[g], w.boxes_all, total_anchors, label_bits, status, cap,
-                       seg_start, kept_box, w.keep, nms_thresh);
-    GatherArgs ga;
-    ga.ghi = w.hi[g]; ga.glo = w.lo[g]; ga.keep = w.keep; ga.boxes_all = w.boxes_all; ga.rescale = rescale; ga.status = status;
-    ga.cap = cap; ga.total_anchors = total_anchors; ga.label_bits = label_bits; ga.K = K;
-    ga.out_boxes = out_boxes; ga.out_scores = out_scores; ga.out_labels = out_labels; ga.out_count = out_count;
-    hipLaunchKernelGGL(gather_topk_kernel, dim3(n_img), dim3(256), 0, s, ga);
-    return check_launch("nms/gather");
+    return nms_gather(w, g, phi, plo, status, cap, n_img, label_bits, total_anchors, nms_thresh, K, rescale, out_boxes, out_scores, out_labels, out_count, s);
 }
 
 int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
@@ -617,6 +763,12 @@ int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
     YMI_REQUIRE(d->ws_bytes >= w.total, "ymi_postprocess: workspace too small (%lld < %lld)", (long long)d->ws_bytes, (long long)w.total);
     YMI_CHECK_HIP(hipMemsetAsync(d->status, 0, 4 * sizeof(int), s));
     YMI_CHECK_HIP(hipMemsetAsync(d->out_count, 0, (size_t)d->n * sizeof(int), s));
+    // per-image LDS sort when an image's capacity fits the 160 KB LDS; else the global radix path
+    // per-image sort path: every image owns a power-of-two sized region of the record arrays
+    int cap_img = 64;
+    while (cap_img * 2 <= d->cand_cap / d->n) cap_img *= 2;
+    const bool per_image = d->cand_cap / d->n >= 64;
+    if (per_image) YMI_CHECK_HIP(hipMemsetAsync(w.img_count, 0, (size_t)d->n * sizeof(int), s));
     int level_off = 0;
     for (int l = 0; l < d->num_levels; ++l) {
         DecodeArgs a;
@@ -624,12 +776,25 @@ int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
         for (int k = 0; k < 6; ++k) a.anc[k] = d->anchors[l][k];
         a.n = d->n; a.K = d->num_classes + 5; a.level_off = level_off; a.total_anchors = total_anchors; a.label_bits = label_bits;
         a.thr = d->score_thresh; a.boxes_all = w.boxes_all; a.hi = w.hi[0]; a.lo = w.lo[0]; a.status = d->status; a.cap = d->cand_cap;
+        a.img_count = per_image ? w.img_count : nullptr; a.cap_img = cap_img;
         const int64_t npix = (int64_t)d->n * a.h * a.w;
         hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((npix + 4 * DEC_PIX_PER_WAVE - 1) / (4 * DEC_PIX_PER_WAVE))), dim3(256), 0, s, a);
         level_off += 3 * a.h * a.w;
     }
+    int rc;
+    if (per_image) {
+        const int lds_keys = cap_img < IMG_SORT_MAX ? cap_img : IMG_SORT_MAX;
+        const size_t lds = (size_t)lds_keys * 8;
+        if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)sort_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // decode wrote arrays [0] (per-image regions); G goes to arrays [1] (compact), P to its own pair
+        hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, label_bits, lds_keys, w.hi[1], w.lo[1],
+                           w.p_hi, w.p_lo, w.keep, d->status);
+        if ((rc = check_launch("decode/sort_image")) != YMI_OK) return rc;
+        return nms_gather(w, 1, w.p_hi, w.p_lo, d->status, d->cand_cap, d->n, label_bits, total_anchors, d->nms_thresh, d->detections_per_img, d->rescale,
+                          d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);
+    }
     hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(64), 0, s, d->status, d->cand_cap);
-    int rc = check_launch("decode");
+    rc = check_launch("decode");
     if (rc != YMI_OK) return rc;
     return sort_nms_gather(w, SortState{0}, d->status, d->cand_cap, d->n, label_bits + anchor_bits, label_bits, total_anchors, d->nms_thresh,
                            d->detections_per_img, d->rescale, d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);

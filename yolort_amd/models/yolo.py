@@ -66,7 +66,11 @@ class PendingDetections:
         self.event.synchronize()
         host = e.result_host.tolist()
         if host[1] != 0:   # candidate capacity exceeded (nothing truncated): grow, rebuild, redo synchronously
-            return self.owner._redo_with_capacity(e, self.rows, host[0])
+            n = e.x.n
+            per_image = host[3] if host[3] > 0 else (host[0] + n - 1) // n   # status[3]: largest per-image count (per-image sort path)
+            if os.environ.get("YOLORT_AMD_VERBOSE"):
+                print(f"[yolort_amd] candidate capacity {self.owner.cand_cap_per_image}/image exceeded (status {host[:4]}): growing", flush=True)
+            return self.owner._redo_with_capacity(e, self.rows, per_image)
         p = e.post
         return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), host[4:])
 
@@ -178,7 +182,8 @@ class YOLO(nn.Module):
             e.plan.run(0, e.n_conv_ops, graph=self.use_graph, stream=main)
         side = e.post_stream
         side.wait_stream(main)
-        e.plan.run(e.n_conv_ops, -1, stream=side)
+        if os.environ.get("YOLORT_AMD_DEBUG_SKIP_POST", "0") != "1":   # tuning aid: upper bound without sort/NMS
+            e.plan.run(e.n_conv_ops, -1, stream=side)
         with torch.cuda.stream(side):
             e.result_host.copy_(torch.cat([e.post.status, e.post.count]), non_blocking=True)
         e.done = torch.cuda.Event()
@@ -196,8 +201,14 @@ class YOLO(nn.Module):
             e.main_stream.wait_event(e.done)
         return e
 
-    def _redo_with_capacity(self, e: _PlanEntry, rescale_rows, needed: int) -> List[Dict[str, Tensor]]:
-        self.cand_cap_per_image = int(needed * 1.25 / e.x.n) + 1024
+    def _redo_with_capacity(self, e: _PlanEntry, rescale_rows, needed_per_image: int) -> List[Dict[str, Tensor]]:
+        # per-image regions are powers of two (the kernel rounds the capacity DOWN to one): grow to the next power
+        # of two that holds the largest image.  Batches submitted before an earlier growth land here too and
+        # simply re-run on the already grown plan.
+        cap_eff = 1 << (self.cand_cap_per_image.bit_length() - 1)
+        if needed_per_image > cap_eff or e.post.cand_cap >= self.cand_cap_per_image * e.x.n:
+            want = max(int(needed_per_image * 1.25) + 1024, 2 * cap_eff)
+            self.cand_cap_per_image = 1 << (want - 1).bit_length()
         x_old = e.x
         torch.cuda.synchronize()
         e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)

@@ -67,6 +67,8 @@ def postprocess_logits(head_outputs: Sequence[Tensor], strides: Sequence[float],
         st = pb.status.cpu().tolist()
         if st[1] == 0:
             break
-        cap = int(st[0] * 1.25) + 1024  # nothing is truncated silently: grow and redo
+        need = max(st[0], st[3] * n)     # st[3]: largest per-image count when the per-image sort path overflowed
+        cap = max(int(need * 1.25) + 1024, 2 * cap)  # nothing is truncated silently: grow and redo
+        cap = n * (1 << ((cap + n - 1) // n - 1).bit_length())   # per-image regions are powers of two
     counts = pb.count.cpu().tolist()
     return slab_to_list(pb.boxes, pb.scores, pb.labels, counts)
