@@ -249,6 +249,28 @@ def test_letterbox_vs_oracle(dev):
     assert (nt8.nchw().float().cpu() - ref8).abs().max().item() <= 5e-5
 
 
+@pytest.mark.parametrize("hw,S", [((640, 640), 640), ((480, 640), 640), ((320, 256), 320)])
+def test_letterbox_identity_fast_path(dev, hw, S):
+    """batches whose images already have the resized size take the interleave-copy kernel: bit-identical to the
+    bilinear kernel's result, which for scale 1 is the source pixel (oracle, fp32 exact)"""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models.transform import YOLOTransform
+    from yolort_amd.utils.synth import synth_images
+    imgs = [synth_images(1, hw[0], hw[1], seed=70 + i)[0] for i in range(3)]
+    ref, sizes = O.letterbox(imgs, S, S, 32)
+    assert sizes == [hw] * 3
+    t = YOLOTransform(S, S)
+    nt, _ = t([im.to(dev) for im in imgs], None, dtype=torch.float32)
+    assert torch.equal(nt.nchw().cpu(), ref)
+    nt16, _ = t([im.half().to(dev) for im in imgs], None, dtype=torch.float16)
+    ref16, _ = O.letterbox([im.half().float() for im in imgs], S, S, 32)
+    assert torch.equal(nt16.nchw().float().cpu(), ref16.half().float())
+    u8 = [(im * 255).round().to(torch.uint8) for im in imgs]
+    ref8, _ = O.letterbox([u.float() / 255.0 for u in u8], S, S, 32)
+    nt8, _ = t([u.to(dev) for u in u8], None, dtype=torch.float32)
+    assert torch.equal(nt8.nchw().cpu(), ref8)
+
+
 def _rand_boxes(rng, n, span=200.0):
     xy = rng.random((n, 2), dtype=np.float32) * span
     wh = rng.random((n, 2), dtype=np.float32) * 60 + 2

@@ -70,7 +70,7 @@ __device__ __forceinline__ float load_elem(const void* p, int64_t i) {
     if constexpr (DT == YMI_F16) return h2f(((const uint16_t*)p)[i]);
     else if constexpr (DT == YMI_BF16) return bf2f(((const uint16_t*)p)[i]);
     else if constexpr (DT == YMI_F32) return ((const float*)p)[i];
-    else return (float)((const uint8_t*)p)[i] * (1.0f / 255.0f);
+    else return (float)((const uint8_t*)p)[i] / 255.0f;   // true division, like the reference's `read_image(...) / 255.0`
 }
 template <int DT>
 __device__ __forceinline__ uint16_t to16(float v) {
