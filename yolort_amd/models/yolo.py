@@ -246,10 +246,16 @@ class YOLO(nn.Module):
     @classmethod
     def load_from_yolov5(cls, checkpoint_path: str, score_thresh: float = 0.25, nms_thresh: float = 0.45, version: str = "r6.0",
                          post_process: Optional[nn.Module] = None):
-        raise NotImplementedError(
-            "loading pickled ultralytics checkpoints (reference yolo.py:185-223, _checkpoint.py) is the next row of the "
-            "scope table (SURVEY.md 8f-1); load a yolort-format state_dict with model.load_state_dict instead"
-        )
+        """Load model state from a checkpoint trained by ultralytics/yolov5 (reference yolo.py:185-223)."""
+        from ._checkpoint import load_from_ultralytics
+
+        info = load_from_ultralytics(checkpoint_path, version=version)
+        backbone_name = f"darknet_{info['size']}_{version.replace('.', '_')}"
+        backbone = darknet_pan_backbone(backbone_name, info["depth_multiple"], info["width_multiple"], version=version, use_p6=info["use_p6"])
+        model = cls(backbone, info["num_classes"], strides=info["strides"], anchor_grids=info["anchor_grids"], score_thresh=score_thresh,
+                    nms_thresh=nms_thresh, post_process=post_process)
+        model.load_state_dict(info["state_dict"])
+        return model
 
 
 def build_model(backbone_name: str, depth_multiple: float, width_multiple: float, version: str, weights_name: Optional[str] = None,
