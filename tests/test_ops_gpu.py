@@ -104,6 +104,18 @@ def test_conv_tiles(dev, tile):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=37, w=29, k=1, s=1, p=0, tile=tile, residual=True)
 
 
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 71, 72, 73, 74, 75, 76, 77])
+def test_conv_software_pipelined_tiles(dev, tile):
+    """v2 tiles with the software-pipelined main loop (fragment double-buffering, DMA issue between MFMAs):
+    short K (1..2 steps, fewer than the ring depth), long K (3x3, 3x3 stride 2), residual, views, ragged M / cout"""
+    _run_conv(dev, torch.float16, n=2, cin=32, cout=64, h=23, w=17, k=1, s=1, p=0, tile=tile, seed=tile)               # 1 step
+    _run_conv(dev, torch.float16, n=2, cin=64, cout=96, h=37, w=29, k=1, s=1, p=0, tile=tile, residual=True, x_cs_extra=32, y_cs_extra=64, seed=tile + 1)
+    _run_conv(dev, torch.float16, n=2, cin=96, cout=128, h=20, w=20, k=1, s=1, p=0, tile=tile, seed=tile + 2)           # 3 steps
+    _run_conv(dev, torch.float16, n=2, cin=64, cout=128, h=37, w=29, k=3, s=1, p=1, tile=tile, seed=tile + 3)           # 18 steps
+    _run_conv(dev, torch.bfloat16, n=1, cin=128, cout=255, h=21, w=19, k=3, s=2, p=1, tile=tile, act=False, seed=tile + 4)
+    _run_conv(dev, torch.float16, n=3, cin=256, cout=64, h=20, w=20, k=1, s=1, p=0, tile=tile, seed=tile + 5)           # 8 steps
+
+
 def test_conv_views_and_residual(dev):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=20, w=20, k=3, s=1, p=1, residual=True, x_cs_extra=64, y_cs_extra=128)
     _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)

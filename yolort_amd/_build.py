@@ -12,10 +12,11 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIBDIR, "libyolort_amd.so")
+LIB = os.environ.get("YOLORT_AMD_BUILD_OUT") or os.path.join(LIBDIR, "libyolort_amd.so")   # override: tuning builds only
 SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_stem.hip", "preproc_pool.hip", "postprocess.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "conv_common.hpp"), os.path.join(os.path.dirname(PKG), "include", "yolort_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+FLAGS += os.environ.get("YOLORT_AMD_BUILD_FLAGS", "").split()   # e.g. -DYMI_STAMPS for tools/stamp_conv.py
 
 
 def _hipcc() -> str:
@@ -35,7 +36,7 @@ def _digest() -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.stamp")
+    stamp = LIB + ".stamp" if os.environ.get("YOLORT_AMD_BUILD_OUT") else os.path.join(LIBDIR, "build.stamp")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
@@ -43,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + (".dbg.o" if os.environ.get("YOLORT_AMD_BUILD_OUT") else ".o"))
         cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

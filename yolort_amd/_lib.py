@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libyolort_amd.so")
+LIB_PATH = os.environ.get("YOLORT_AMD_LIB") or os.path.join(_HERE, "lib", "libyolort_amd.so")   # override: tuning builds only
 
 YMI_F16, YMI_BF16, YMI_F32, YMI_U8 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU = 0, 1

@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     const int oy0 = ty * HTH, ox0 = tx * HTW, n0 = bn * BN;
     const int nchunks = a.cin / 32;
     const int nsteps = nchunks * 9;
+    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
 
     // ---- patch DMA geometry: 12 pieces of 16 pixels, 3 per wave; lane (pixel q, position pos) fetches
     //      k-chunk pos ^ ((q>>2)&3) of input pixel (oy0-1+q/18, ox0-1+q%18), or the zero page ----
@@ -96,12 +98,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     };
 
     f32x16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     // issue-side position (chunk, tap) of the next weight step to fetch
     int is_step = 0, is_chunk = 0, is_tap = 0;
@@ -177,79 +174,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
         else if (++dx == 3) { dx = 0; ++dy; }
     }
 
-    // ---- epilogue (direct 16-byte stores after a permlane32 swap, as conv_igemm v2) ----
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
+    // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
+    finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, [&](int j, int64_t& m, bool& ok) {
         const int oy = oy0 + 2 * (wave_m / 32 + j) + ((lane >> 4) & 1), ox = ox0 + (lane & 15);
-        const bool m_ok = oy < a.ho && ox < a.wo;
-        const int m = (img * a.ho + oy) * a.wo + ox;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int cbase = n0 + wave_n + i * 32;   // wave-uniform
-            if (cbase >= a.cout) continue;
-            float v[4][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cbase + g * 8 + hi * 4;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (co < a.cout) b = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float tv = acc[i][j][g * 4 + e] + b[e];
-                    if (a.act == YMI_ACT_SILU) tv = silu(tv);
-                    v[g][e] = tv;
-                }
-                if (a.res != nullptr && m_ok && co < a.cout) {
-                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (int64_t)m * a.res_cs + co);
-                    v[g][0] += from16<DT>((uint16_t)(rv[0] & 0xffff));
-                    v[g][1] += from16<DT>((uint16_t)(rv[0] >> 16));
-                    v[g][2] += from16<DT>((uint16_t)(rv[1] & 0xffff));
-                    v[g][3] += from16<DT>((uint16_t)(rv[1] >> 16));
-                }
-            }
-            if constexpr (ODT == YMI_F32) {
-                if (!m_ok) continue;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = cbase + g * 8 + hi * 4;
-                    if (co >= a.cout) continue;
-                    float* yp = reinterpret_cast<float*>(a.y) + (int64_t)m * a.y_cs + co;
-                    for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[g][e];
-                }
-            } else {
-                uint32_t pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
-                    pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
-                }
-                const bool wide = cbase + 32 <= a.cout;   // wave-uniform
-                if (wide) {
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        uint32_t ax = pk[g][0], ay = pk[g][1], bx = pk[g + 1][0], by = pk[g + 1][1];
-                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                        ax = rx[0]; bx = rx[1];
-                        ay = ry[0]; by = ry[1];
-                        if (m_ok) {
-                            const int co = cbase + (g + hi) * 8;
-                            u32x4 o = {ax, ay, bx, by};
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co) = o;
-                        }
-                    }
-                } else if (m_ok) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co = cbase + g * 8 + hi * 4;
-                        if (co >= a.cout) continue;
-                        uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
-                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[g][e]);
-                    }
-                }
-            }
-        }
-    }
+        ok = oy < a.ho && ox < a.wo;
+        m = ((int64_t)img * a.ho + oy) * a.wo + ox;
+    });
 }
 
 template <int DT, int ODT, int BN, int WM, int WN, int STAGES>

@@ -1,14 +1,13 @@
 // Shared pieces of the convolution kernels (conv_igemm.hip, conv3x3_halo.hip).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace ymi {
 
 constexpr int BK = 32;          // k elements per main-loop step
 constexpr int LDS_PITCH = 40;   // halfs per LDS row (32 + 8 pad) = 80 bytes
-// v2 epilogue flavour: false = direct 16-byte stores from the MFMA layout after a permlane32 swap,
-// true = stage the tile through LDS and write whole pixel rows (measured slower on yolov5s: -4%)
-constexpr bool STAGED_EPILOGUE = false;
 
 template <int DT>
 struct Mfma;
@@ -60,6 +59,15 @@ __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) {
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N-1
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -70,6 +78,155 @@ __device__ __forceinline__ void glds16(const uint16_t* g, uint16_t* lds_wave_uni
                                      (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Shared epilogue of the convolution kernels.  Every kernel computes D[cout][pixel] 32x32 sub-tiles with
+// the swapped MFMA: lane l owns pixel column (l & 31); accumulator register g*4+e holds cout row
+// g*8 + 4*(l>>5) + e of the sub-tile.
+//   * the bias is folded into the accumulator INIT (loaded once at kernel entry, its latency hidden behind
+//     the geometry math and the DMA prologue) -- a bias load per sub-tile group in the epilogue costs one
+//     serialized L2 round trip each (16 per wave for a 64x64 wave tile: measured ~2x the epilogue's math)
+//   * the residual (Bottleneck shortcut) of a whole wave tile is fetched in one batch before the math
+// ---------------------------------------------------------------------------------------------------
+template <int TN>
+__device__ __forceinline__ void load_bias(const ConvArgs& a, int cbase0, int hi, f32x4 (&b)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = cbase0 + i * 32 + g * 8 + hi * 4;
+            b[i][g] = *reinterpret_cast<const f32x4*>(a.bias + (co < a.cout_pad ? co : 0));   // rows past cout_pad are never stored
+        }
+}
+
+template <int TN, int TM>
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[TN][TM], const f32x4 (&b)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] = b[i][g][e];
+}
+
+__device__ __forceinline__ void load_residual(const ConvArgs& a, int64_t m, bool m_ok, int cbase, int hi, u32x2 (&r)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = cbase + g * 8 + hi * 4;
+        u32x2 z = {0u, 0u};
+        r[g] = z;
+        if (m_ok && co < a.cout) r[g] = *reinterpret_cast<const u32x2*>(a.res + m * a.res_cs + co);
+    }
+}
+
+// activation (+ residual) + conversion + store of one 32x32 sub-tile; cbase (first cout of the sub-tile) is wave-uniform
+template <int DT, int ODT, bool RES>
+__device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& acc, int64_t m, bool m_ok, int cbase, int hi, const u32x2 (&r)[4]) {
+    float v[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = acc[g * 4 + e];
+            if (a.act == YMI_ACT_SILU) t = silu(t);
+            v[g][e] = t;
+        }
+        if constexpr (RES) {
+            v[g][0] += from16<DT>((uint16_t)(r[g][0] & 0xffff));
+            v[g][1] += from16<DT>((uint16_t)(r[g][0] >> 16));
+            v[g][2] += from16<DT>((uint16_t)(r[g][1] & 0xffff));
+            v[g][3] += from16<DT>((uint16_t)(r[g][1] >> 16));
+        }
+    }
+    if constexpr (ODT == YMI_F32) {
+        if (!m_ok) return;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = cbase + g * 8 + hi * 4;
+            if (co >= a.cout) continue;
+            float* yp = reinterpret_cast<float*>(a.y) + m * a.y_cs + co;
+            if (co + 3 < a.cout) {
+                f32x4 o = {v[g][0], v[g][1], v[g][2], v[g][3]};
+                *reinterpret_cast<f32x4*>(yp) = o;
+            } else {
+                for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[g][e];
+            }
+        }
+    } else {
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
+            pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
+        }
+        const bool wide = (cbase + 32 <= a.cout) && ((a.split & 7) == 0);   // wave-uniform
+        if (wide) {
+            // groups (g, g+1): after the swap lanes < 32 hold cols [g*8, g*8+8), lanes >= 32 hold [(g+1)*8, (g+1)*8+8)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint32_t ax = pk[g][0], ay = pk[g][1], bx = pk[g + 1][0], by = pk[g + 1][1];
+                auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                ax = rx[0]; bx = rx[1];
+                ay = ry[0]; by = ry[1];
+                if (m_ok) {
+                    const int co = cbase + (g + hi) * 8;
+                    uint16_t* yp;
+                    if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + m * a.y2_cs + (co - a.split);
+                    else yp = reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + co;
+                    u32x4 o = {ax, ay, bx, by};
+                    *reinterpret_cast<u32x4*>(yp) = o;
+                }
+            }
+        } else if (m_ok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cbase + g * 8 + hi * 4;
+                if (co >= a.cout) continue;
+                uint16_t* yp;
+                if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + m * a.y2_cs + (co - a.split);
+                else yp = reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + co;
+                if (co + 3 < a.cout) {
+                    u32x2 o = {pk[g][0], pk[g][1]};
+                    *reinterpret_cast<u32x2*>(yp) = o;
+                } else {
+                    for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[g][e]);
+                }
+            }
+        }
+    }
+}
+
+// whole wave tile: TM pixel groups x TN cout groups.  pix(j, m, m_ok) yields the output pixel index of this lane in group j.
+template <int DT, int ODT, int TN, int TM, class PixFn>
+__device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int hi, PixFn&& pix) {
+    int64_t m[TM];
+    bool m_ok[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) pix(j, m[j], m_ok[j]);
+    if (a.res != nullptr) {   // wave-uniform
+        u32x2 rv[TM][TN][4];
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                if (cbase0 + i * 32 < a.cout) load_residual(a, m[j], m_ok[j], cbase0 + i * 32, hi, rv[j][i]);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, true>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, rv[j][i]);
+    } else {
+        const u32x2 none[4] = {};
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, false>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, none);
+    }
+}
 
 // 3x3 stride-1 LDS-halo kernel (conv3x3_halo.hip); returns YMI_EINVAL when the shape does not apply
 int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);

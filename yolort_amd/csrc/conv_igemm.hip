@@ -228,7 +228,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // v_permlane32_swap so that each lane stores 8 consecutive output channels (16 B) per store.
 // =============================================================================================
 // UTAP (uniform tap): cin % 32 == 0 and kh*kw <= 32 -> scalar tap arithmetic + per-row validity bitmask, no im2col table
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP>
+#ifdef YMI_STAMPS   // tuning aid (never in the shipped build): s_memtime timeline of the pipelined main loop, wave 0 of each block
+__device__ unsigned long long ymi_stamps[2048 * 128];
+#define YMI_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && (i) < 128) ymi_stamps[blockIdx.x * 128 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define YMI_STAMP(i) ((void)0)
+#endif
+
+// PIPE: software-pipelined main loop -- MFMA fragments are double-buffered in registers (the LDS reads of the next
+// half-step and the DMA issue of a later stage sit between the MFMAs of the current one), so a single wave keeps
+// its SIMD's matrix pipe busy instead of serialising wait -> barrier -> DMA issue -> LDS latency -> MFMA.
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
 __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
@@ -255,6 +268,8 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
     const int bm = lb / a.nblk_n, bn = lb % a.nblk_n;
     const int m0 = bm * BM, n0 = bn * BN;
     const int nsteps = a.k_pad / BK;
+    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
 
     if constexpr (!IS1X1 && !UTAP) {
         for (int i = tid; i < a.k_pad / 8; i += 256) ktab_lds[i] = a.ktab[i];
@@ -309,19 +324,49 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
         w_off[j] = (n0 + pi * 16 + sub_row) * a.k_pad + chunk * 8;
     }
 
-    // UTAP running state (issue() is called for steps 0,1,2,... in order): all wave-uniform scalars
+    // UTAP running state (stages are issued in order 0,1,2,...): all wave-uniform scalars
     int u_tap = 0, u_c0 = 0, u_dx = 0, u_kbase = 0;
-    auto issue = [&](int step) {
-        uint16_t* stage = smem + (step % STAGES) * STAGE_HALFS;
+    // one stage = issue_begin(step); issue_piece(0..P-1); issue_end()  (pieces 0..PA-1 activations, PA..P-1 weights)
+    uint16_t* cur_stage = smem;
+    int cur_koff = 0, cur_step = 0, cur_dy = 0, cur_dx = 0;
+    bool cur_tap_ok = true;
+    auto issue_begin = [&](int step) {
+        cur_stage = smem + (step % STAGES) * STAGE_HALFS;
+        cur_step = step;
         if constexpr (UTAP) {
-            // cin % 32 == 0: the four chunks of a step share one tap -> tap/channel math is scalar
-            const int koff = u_kbase + chunk * 8;
-#pragma unroll
-            for (int j = 0; j < PA; ++j) {
-                const bool ok = (a_aux[j] >> u_tap) & 1;
-                const int off = ok ? a_off[j] + koff : a.x_zero_off;
-                glds16(a.x + off, stage + a_slot[j]);
+            cur_koff = u_kbase + chunk * 8;   // cin % 32 == 0: the four chunks of a step share one tap -> scalar tap math
+        } else if constexpr (IS1X1) {
+            cur_koff = (step * 4 + chunk) * 8;
+            cur_tap_ok = cur_koff < a.cin;
+        } else {
+            const int2 t = ktab_lds[step * 4 + chunk];
+            cur_koff = t.x;
+            cur_tap_ok = t.y >= 0;
+            cur_dy = t.y >> 16;
+            cur_dx = t.y & 0xffff;
+        }
+    };
+    auto issue_piece = [&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        if constexpr (j < PA) {
+            bool ok;
+            if constexpr (UTAP) {
+                ok = (a_aux[j] >> u_tap) & 1;
+            } else {
+                ok = cur_tap_ok & (a_aux[j] >= 0);
+                if constexpr (!IS1X1) {
+                    const int iy = (a_aux[j] >> 16) - 16384 + cur_dy, ix = (a_aux[j] & 0xffff) - 16384 + cur_dx;
+                    ok = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w_in);
+                }
             }
+            const int off = ok ? a_off[j] + cur_koff : a.x_zero_off;
+            glds16(a.x + off, cur_stage + a_slot[j]);
+        } else if constexpr (j < P) {
+            glds16(a.w + (w_off[j - PA] + cur_step * BK), cur_stage + w_slot[j - PA]);
+        }
+    };
+    auto issue_end = [&]() {
+        if constexpr (UTAP) {
             // advance to the next 32-channel chunk / tap / kernel row (element offsets relative to (iy0, ix0))
             u_c0 += BK;
             u_kbase += BK;
@@ -335,52 +380,102 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
                     u_kbase += (a.w_in - a.kw) * a.x_cs;
                 }
             }
-        } else {
-            int koff, dy = 0, dx = 0;
-            bool tap_ok;
-            if constexpr (IS1X1) {
-                koff = (step * 4 + chunk) * 8;
-                tap_ok = koff < a.cin;
-            } else {
-                const int2 t = ktab_lds[step * 4 + chunk];
-                koff = t.x;
-                tap_ok = t.y >= 0;
-                dy = t.y >> 16;
-                dx = t.y & 0xffff;
-            }
-#pragma unroll
-            for (int j = 0; j < PA; ++j) {
-                bool ok = tap_ok & (a_aux[j] >= 0);
-                if constexpr (!IS1X1) {
-                    const int iy = (a_aux[j] >> 16) - 16384 + dy, ix = (a_aux[j] & 0xffff) - 16384 + dx;
-                    ok = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w_in);
-                }
-                const int off = ok ? a_off[j] + koff : a.x_zero_off;
-                glds16(a.x + off, stage + a_slot[j]);
-            }
         }
-#pragma unroll
-        for (int j = 0; j < PW; ++j) glds16(a.w + (w_off[j] + step * BK), stage + w_slot[j]);
+    };
+    auto issue = [&](int step) {
+        issue_begin(step);
+        static_for<0, P>(issue_piece);
+        issue_end();
     };
 
     f32x16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     if constexpr (!IS1X1 && !UTAP) __syncthreads();   // ktab visible (no DMA in flight yet: plain barrier is fine)
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nsteps && !(a.debug & 2)) issue(s);
-
     const int frow = lane & 31;
     const int swz = (lane >> 2) & 3;
     int pos[2];
     pos[0] = ((0 + (lane >> 5)) ^ swz) * 8;   // element offset of this lane's k-chunk, ks = 0
     pos[1] = ((2 + (lane >> 5)) ^ swz) * 8;   // ks = 1
+
+    if constexpr (PIPE) {
+        YMI_STAMP(0);
+        // ---- software-pipelined main loop: all STAGES slots are in use (one being read, STAGES-1 in flight) ----
+        static_for<0, STAGES>([&](auto st) {
+            if (decltype(st)::value < nsteps) issue(decltype(st)::value);
+        });
+        auto wait_pending = [&](int pend) {   // returns once at most `pend` later stages of this wave are in flight
+            if (pend >= 3) wait_vmcnt<3 * P>();
+            else if (pend == 2) wait_vmcnt<2 * P>();
+            else if (pend == 1) wait_vmcnt<P>();
+            else wait_vmcnt<0>();
+        };
+        YMI_STAMP(1);
+        wait_pending((nsteps < STAGES ? nsteps : STAGES) - 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        YMI_STAMP(2);
+
+        constexpr int NM = TN * TM;        // MFMAs per half-step
+        constexpr int NF = TM + TN;        // fragments per half-step
+        frag fa[2][TM], fw[2][TN];
+        const uint16_t* as = smem + wave_m * 32;
+        const uint16_t* ws = smem + (BM + wave_n) * 32;
+        auto read_frag = [&](auto buft, auto qt, const uint16_t* sa, const uint16_t* sw, int p) {
+            constexpr int buf = decltype(buft)::value, q = decltype(qt)::value;
+            if constexpr (q < TM) fa[buf][q] = *reinterpret_cast<const frag*>(sa + (q * 32 + frow) * 32 + p);
+            else if constexpr (q < NF) fw[buf][q - TM] = *reinterpret_cast<const frag*>(sw + ((q - TM) * 32 + frow) * 32 + p);
+        };
+        // MFMAs on fragment buffer `cur`; after the q-th MFMA run the extra items [q*PER, (q+1)*PER) of `extra`
+        auto mfma_group = [&](auto curt, auto nextra_t, auto&& extra) {
+            constexpr int cur = decltype(curt)::value, NE = decltype(nextra_t)::value;
+            constexpr int PER = (NE + NM - 1) / NM;
+            static_for<0, NM>([&](auto qt) {
+                constexpr int q = decltype(qt)::value, i = q / TM, j = q % TM;
+                acc[i][j] = Mfma<DT>::run(fw[cur][i], fa[cur][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, PER>([&](auto et) {
+                    constexpr int e = q * PER + decltype(et)::value;
+                    if constexpr (e < NE) extra(std::integral_constant<int, e>{});
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        static_for<0, NF>([&](auto qt) { read_frag(std::integral_constant<int, 0>{}, qt, as, ws, pos[0]); });
+        int slot = 0;
+        // ONE loop body for every step (no per-case copies of the MFMA groups: the accumulators stay put).  On the last
+        // step the "next stage" fragment reads fetch stale LDS bytes that nobody uses, and the wait / barrier are idle.
+        for (int step = 0; step < nsteps; ++step) {
+            // first half-step; meanwhile fetch the second half-step's fragments of the same stage
+            mfma_group(std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{},
+                       [&](auto et) { read_frag(std::integral_constant<int, 1>{}, et, as, ws, pos[1]); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `step`
+            const int issued = step + STAGES < nsteps ? step + STAGES : nsteps;
+            YMI_STAMP(4 + step * 3);
+            wait_pending(issued - (step + 2));                    // this wave's pieces of stage step+1 have landed
+            YMI_STAMP(5 + step * 3);
+            __builtin_amdgcn_s_barrier();                         // ... everyone's have; slot `slot` is free
+            __builtin_amdgcn_sched_barrier(0);
+            YMI_STAMP(6 + step * 3);
+            const int nslot = slot + 1 == STAGES ? 0 : slot + 1;
+            as = smem + nslot * STAGE_HALFS + wave_m * 32;
+            ws = smem + nslot * STAGE_HALFS + (BM + wave_n) * 32;
+            const bool refill = step + STAGES < nsteps;           // wave-uniform
+            if (refill) issue_begin(step + STAGES);
+            __builtin_amdgcn_sched_barrier(0);
+            // second half-step; meanwhile fetch the next stage's first fragments and refill the freed slot
+            mfma_group(std::integral_constant<int, 1>{}, std::integral_constant<int, NF + P>{}, [&](auto et) {
+                constexpr int e = decltype(et)::value;
+                if constexpr (e < NF) read_frag(std::integral_constant<int, 0>{}, et, as, ws, pos[0]);
+                else if (refill) issue_piece(std::integral_constant<int, e - NF>{});
+            });
+            if (refill) issue_end();
+            slot = nslot;
+        }
+    } else {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nsteps && !(a.debug & 2)) issue(s);
 
     for (int step = 0; step < nsteps; ++step) {
         // this wave's pieces of stage `step` have landed once at most `ahead` later stages are pending
@@ -408,201 +503,15 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
                 for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(wf[i], af[j], acc[i][j]);
         }
     }
+    }
 
-    if constexpr (!STAGED_EPILOGUE) {
-    // ---- epilogue ----
-    const int hi = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wave_m + j * 32 + frow;
-        const bool m_ok = m < a.M;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int cbase = n0 + wave_n + i * 32;   // wave-uniform
-            if (cbase >= a.cout) continue;
-            float v[4][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cbase + g * 8 + hi * 4;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (co < a.cout) b = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][g * 4 + e] + b[e];
-                    if (a.act == YMI_ACT_SILU) t = silu(t);
-                    v[g][e] = t;
-                }
-                if (a.res != nullptr && m_ok && co < a.cout) {
-                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (int64_t)m * a.res_cs + co);
-                    v[g][0] += from16<DT>((uint16_t)(rv[0] & 0xffff));
-                    v[g][1] += from16<DT>((uint16_t)(rv[0] >> 16));
-                    v[g][2] += from16<DT>((uint16_t)(rv[1] & 0xffff));
-                    v[g][3] += from16<DT>((uint16_t)(rv[1] >> 16));
-                }
-            }
-            if constexpr (ODT == YMI_F32) {
-                if (!m_ok) continue;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = cbase + g * 8 + hi * 4;
-                    if (co >= a.cout) continue;
-                    float* yp = reinterpret_cast<float*>(a.y) + (int64_t)m * a.y_cs + co;
-                    if (co + 3 < a.cout) {
-                        f32x4 o = {v[g][0], v[g][1], v[g][2], v[g][3]};
-                        *reinterpret_cast<f32x4*>(yp) = o;
-                    } else {
-                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[g][e];
-                    }
-                }
-            } else {
-                uint32_t pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
-                    pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
-                }
-                const bool wide = (cbase + 32 <= a.cout) && ((a.split & 7) == 0);   // wave-uniform
-                if (wide) {
-                    // groups (g, g+1): lanes < 32 end with cols [g*8, g*8+8), lanes >= 32 with [(g+1)*8, (g+1)*8+8)
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        uint32_t ax = pk[g][0], ay = pk[g][1], bx = pk[g + 1][0], by = pk[g + 1][1];
-                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                        ax = rx[0]; bx = rx[1];
-                        ay = ry[0]; by = ry[1];
-                        if (m_ok) {
-                            const int co = cbase + (g + hi) * 8;
-                            uint16_t* yp;
-                            if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co - a.split);
-                            else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
-                            u32x4 o = {ax, ay, bx, by};
-                            *reinterpret_cast<u32x4*>(yp) = o;
-                        }
-                    }
-                } else if (m_ok) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co = cbase + g * 8 + hi * 4;
-                        if (co >= a.cout) continue;
-                        uint16_t* yp;
-                        if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co - a.split);
-                        else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
-                        if (co + 3 < a.cout) {
-                            u32x2 o = {pk[g][0], pk[g][1]};
-                            *reinterpret_cast<u32x2*>(yp) = o;
-                        } else {
-                            for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[g][e]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    } else {
-    // ---- epilogue ----
-    // 16-bit outputs: bias + SiLU in fp32 -> packed to the output dtype -> staged through LDS as a
-    // [BM][BN] tile (the operand ring is dead by now) -> written back as WHOLE pixel rows, 16 B per
-    // lane with consecutive lanes on consecutive channels.  A direct store from the MFMA layout would
-    // touch 32 cache lines with 32-byte pieces per instruction (measured ~1 TB/s); the staged form
-    // writes full 64..256-byte runs.  The residual (Bottleneck shortcut) is added at this stage from
-    // equally coalesced 16-byte loads.  fp32 outputs (head logits) keep the direct float4 path.
-    const int hi = lane >> 5;
-    if constexpr (ODT == YMI_F32) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m0 + wave_m + j * 32 + frow;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = n0 + wave_n + i * 32 + g * 8 + hi * 4;
-                    if (co >= a.cout) continue;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[i][j][g * 4 + e] + b[e];
-                        if (a.act == YMI_ACT_SILU) t = silu(t);
-                        v[e] = t;
-                    }
-                    float* yp = reinterpret_cast<float*>(a.y) + (int64_t)m * a.y_cs + co;
-                    if (co + 3 < a.cout) {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(yp) = o;
-                    } else {
-                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[e];
-                    }
-                }
-            }
-        }
-    } else {
-        constexpr int OPITCH = BN + 8;   // halfs per staged row (+16 B: spreads ds_write_b64 over banks)
-        static_assert(BM * OPITCH * 2 <= STAGES * (BM + BN) * 64, "output tile must fit in the operand ring");
-        uint16_t* ot = smem;
-        __builtin_amdgcn_s_barrier();    // every wave is done reading the last operand stage
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int row = wave_m + j * 32 + frow;
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = wave_n + i * 32 + g * 8 + hi * 4;   // column inside the tile
-                    const int co = n0 + cl;
-                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                    if (co < a.cout_pad) b = *reinterpret_cast<const f32x4*>(a.bias + co);
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[i][j][g * 4 + e] + b[e];
-                        if (a.act == YMI_ACT_SILU) t = silu(t);
-                        v[e] = t;
-                    }
-                    u32x2 o;
-                    o[0] = (uint32_t)to16<DT>(v[0]) | ((uint32_t)to16<DT>(v[1]) << 16);
-                    o[1] = (uint32_t)to16<DT>(v[2]) | ((uint32_t)to16<DT>(v[3]) << 16);
-                    *reinterpret_cast<u32x2*>(ot + row * OPITCH + cl) = o;
-                }
-            }
-        }
-        __syncthreads();
-        constexpr int CPR = BN / 8;              // 16-byte chunks per tile row
-        constexpr int CHUNKS = BM * CPR;
-#pragma unroll 4
-        for (int c = tid; c < CHUNKS; c += 256) {
-            const int row = c / CPR, cl = (c % CPR) * 8;
-            const int m = m0 + row, co = n0 + cl;
-            if (m >= a.M || co >= a.cout) continue;
-            u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OPITCH + cl);
-            if (co + 7 < a.cout) {
-                if (a.res != nullptr) {
-                    const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (int64_t)m * a.res_cs + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = from16<DT>((uint16_t)(v[e] & 0xffff)) + from16<DT>((uint16_t)(r[e] & 0xffff));
-                        const float hi2 = from16<DT>((uint16_t)(v[e] >> 16)) + from16<DT>((uint16_t)(r[e] >> 16));
-                        v[e] = (uint32_t)to16<DT>(lo) | ((uint32_t)to16<DT>(hi2) << 16);
-                    }
-                }
-                uint16_t* yp;
-                if (a.split > 0 && co >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co - a.split);
-                else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
-                *reinterpret_cast<u32x4*>(yp) = v;
-            } else {   // ragged last chunk (cout % 8 != 0): element-wise
-                for (int e = 0; e < 8 && co + e < a.cout; ++e) {
-                    float t = from16<DT>((uint16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffff));
-                    if (a.res != nullptr) t += from16<DT>(a.res[(int64_t)m * a.res_cs + co + e]);
-                    uint16_t* yp;
-                    if (a.split > 0 && co + e >= a.split) yp = reinterpret_cast<uint16_t*>(a.y2) + (int64_t)m * a.y2_cs + (co + e - a.split);
-                    else yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co + e;
-                    *yp = to16<DT>(t);
-                }
-            }
-        }
-    }
-    }
+    YMI_STAMP(3);
+    // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
+    finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, [&](int j, int64_t& m, bool& ok) {
+        m = m0 + wave_m + j * 32 + frow;
+        ok = m < a.M;
+    });
+    YMI_STAMP(127);
 }
 
 template <typename K>
@@ -612,7 +521,7 @@ static int launch_v2_kernel(K kfn, const ConvArgs& a, size_t lds, dim3 grid, hip
     return check_launch("conv_igemm_v2_kernel");
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES>
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE = false>
 static int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, BM);
@@ -620,9 +529,14 @@ static int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     const bool utap = (a.cin % 32 == 0) && (a.kh * a.kw <= 32);
     const size_t lds = (size_t)STAGES * (BM + BN) * 64 + ((is1x1 || utap) ? 0 : (size_t)a.k_pad) + 16;
     dim3 grid(a.nblk_m * a.nblk_n);
-    if (utap) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, true>, a, lds, grid, s);
-    if (is1x1) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, true, false>, a, lds, grid, s);
-    return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, false>, a, lds, grid, s);
+    if (utap) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, true, PIPE>, a, lds, grid, s);
+    if constexpr (PIPE) {
+        set_error("ymi_conv2d: the software-pipelined tiles need cin %% 32 == 0");
+        return YMI_EINVAL;
+    } else {
+        if (is1x1) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, true, false>, a, lds, grid, s);
+        return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, false>, a, lds, grid, s);
+    }
 }
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN>
@@ -663,7 +577,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         return YMI_EINVAL;
     }
     if (tile >= 31 && tile <= 39) return conv3x3_halo_launch(a, DT, ODT, tile - 30, s);   // LDS-halo 3x3 s1 kernel
-    if (tile == 41) return conv_stem_launch(a, DT, ODT, s);                                // dedicated stem kernel
+    if (tile == 41) return conv_stem_launch(a, DT, ODT, s);
     switch (tile) {
         case 11: return launch_v2<DT, ODT, 128, 128, 64, 64, 4>(a, is1x1, s);
         case 12: return launch_v2<DT, ODT, 256, 64, 64, 64, 3>(a, is1x1, s);
@@ -679,6 +593,19 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         case 25: return launch_v2<DT, ODT, 128, 64, 64, 32, 2>(a, is1x1, s);
         case 26: return launch_v2<DT, ODT, 128, 32, 32, 32, 2>(a, is1x1, s);   // 20 KB LDS: 8 blocks / CU
         case 27: return launch_v2<DT, ODT, 64, 64, 32, 32, 2>(a, is1x1, s);    // 16 KB LDS
+        // software-pipelined main loop (61..65 = 11..15, 71..77 = 21..27)
+        case 61: return launch_v2<DT, ODT, 128, 128, 64, 64, 4, true>(a, is1x1, s);
+        case 62: return launch_v2<DT, ODT, 256, 64, 64, 64, 3, true>(a, is1x1, s);
+        case 63: return launch_v2<DT, ODT, 256, 32, 64, 32, 3, true>(a, is1x1, s);
+        case 64: return launch_v2<DT, ODT, 64, 128, 32, 64, 4, true>(a, is1x1, s);
+        case 65: return launch_v2<DT, ODT, 128, 64, 64, 32, 4, true>(a, is1x1, s);
+        case 71: return launch_v2<DT, ODT, 128, 128, 64, 64, 2, true>(a, is1x1, s);
+        case 72: return launch_v2<DT, ODT, 256, 64, 64, 64, 2, true>(a, is1x1, s);
+        case 73: return launch_v2<DT, ODT, 256, 32, 64, 32, 2, true>(a, is1x1, s);
+        case 74: return launch_v2<DT, ODT, 64, 128, 32, 64, 2, true>(a, is1x1, s);
+        case 75: return launch_v2<DT, ODT, 128, 64, 64, 32, 2, true>(a, is1x1, s);
+        case 76: return launch_v2<DT, ODT, 128, 32, 32, 32, 2, true>(a, is1x1, s);
+        case 77: return launch_v2<DT, ODT, 64, 64, 32, 32, 2, true>(a, is1x1, s);
         case 1: return launch_cfg<DT, ODT, 128, 128, 64, 64>(a, is1x1, s);
         case 2: return launch_cfg<DT, ODT, 256, 64, 64, 64>(a, is1x1, s);
         case 3: return launch_cfg<DT, ODT, 256, 32, 64, 32>(a, is1x1, s);
@@ -743,6 +670,12 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
 }
 
 }  // namespace ymi
+
+#ifdef YMI_STAMPS
+extern "C" int ymi_debug_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ymi::ymi_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int ymi_conv2d(const ymi_conv_desc* d, void* stream) { return ymi::conv2d_launch(d, (hipStream_t)stream); }
 

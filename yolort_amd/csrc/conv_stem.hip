@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, int ti
     const int img = t / tiles_y;
     const int oy0 = ty * STH, ox0 = tx * STW;
 
+    f32x4 bias_regs[TN][4];
+    load_bias<TN>(a, 0, lane >> 5, bias_regs);
     // ---- patch: super-pixel q -> (row q/34, col q%34) -> input (2*oy0 - 2 + row, ox0 - 1 + col) ----
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -54,12 +56,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, int ti
         for (int s = 0; s < 9; ++s) wf[i][s] = *reinterpret_cast<const frag*>(wr + 16 * s);
     }
     f32x16 acc[TN][2];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    init_acc<TN, 2>(acc, bias_regs);   // accumulate on top of the bias
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -81,66 +78,12 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, int ti
         }
     }
 
-    // ---- epilogue: bias + SiLU, permlane32 swap, 16-byte stores ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    // ---- epilogue: SiLU, 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
+    finish_wave_tile<DT, ODT, TN, 2>(a, acc, 0, hi, [&](int j, int64_t& m, bool& ok) {
         const int oy = oy0 + 2 * wave + j, ox = ox0 + px;
-        const bool m_ok = oy < a.ho && ox < a.wo;
-        const int64_t m = ((int64_t)img * a.ho + oy) * a.wo + ox;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int cbase = i * 32;
-            if (cbase >= a.cout) continue;
-            uint32_t pk[4][2];
-            float v[4][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cbase + g * 8 + hi * 4;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (co < a.cout_pad) b = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float tv = acc[i][j][g * 4 + e] + b[e];
-                    if (a.act == YMI_ACT_SILU) tv = silu(tv);
-                    v[g][e] = tv;
-                }
-                pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
-                pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
-            }
-            if constexpr (ODT == YMI_F32) {
-                if (!m_ok) continue;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = cbase + g * 8 + hi * 4;
-                    float* yp = reinterpret_cast<float*>(a.y) + m * a.y_cs + co;
-                    for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = v[g][e];
-                }
-            } else {
-                const bool wide = cbase + 32 <= a.cout;
-                if (wide) {
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        uint32_t ax = pk[g][0], ay = pk[g][1], bx = pk[g + 1][0], by = pk[g + 1][1];
-                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                        ax = rx[0]; bx = rx[1];
-                        ay = ry[0]; by = ry[1];
-                        if (m_ok) {
-                            u32x4 o = {ax, ay, bx, by};
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + cbase + (g + hi) * 8) = o;
-                        }
-                    }
-                } else if (m_ok) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co = cbase + g * 8 + hi * 4;
-                        uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + co;
-                        for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[g][e]);
-                    }
-                }
-            }
-        }
-    }
+        ok = oy < a.ho && ox < a.wo;
+        m = ((int64_t)img * a.ho + oy) * a.wo + ox;
+    });
 }
 
 template <int DT, int ODT>
