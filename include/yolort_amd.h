@@ -171,6 +171,24 @@ typedef struct ymi_post_desc {
 int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_cap);
 int ymi_postprocess(const ymi_post_desc* d, void* stream);
 
+/* The same post-process in three stages, for the FUSED head (below):
+ *   ymi_post_begin        resets the candidate counters of the descriptor's workspace
+ *   <candidate producers> ymi_conv_head_decode once per pyramid level (any order, same or ordered streams)
+ *   ymi_post_finish       sort + class-aware NMS + top-k + rescale from the appended records
+ * ymi_postprocess == begin + decode of the fp32 logits + finish.  logits[] / lcstride[] are ignored by
+ * begin / finish / ymi_conv_head_decode; lh / lw / stride / anchors describe the levels as before. */
+int ymi_post_begin(const ymi_post_desc* d, void* stream);
+int ymi_post_finish(const ymi_post_desc* d, void* stream);
+
+/* Detection head of pyramid level `level` (the biased 1x1 conv of yolort/models/box_head.py:36,74) with the
+ * decode + sigmoid + multi-label threshold of box_head.py:345-360,414-418 and _utils.py:59-60 fused into the
+ * convolution's epilogue: the fp32 logits never reach memory, boxes of every anchor and the candidate records go
+ * straight into `post`'s workspace (bit-identical to what ymi_postprocess derives from stored logits).
+ * conv: 1x1 stride 1, cin % 32 == 0, k_pad == cin, act NONE, zeros required, y ignored.  Weight rows / bias are
+ * packed per anchor: anchor q's K = num_classes + 5 outputs occupy rows q*RA .. q*RA+K-1, RA = round_up(K, 32)
+ * (<= 128), remaining rows zero; cout = cout_pad = 3*RA. */
+int ymi_conv_head_decode(const ymi_conv_desc* conv, const ymi_post_desc* post, int level, void* stream);
+
 /* Stand-alone class-aware NMS on caller-provided candidates of ONE image (kept indices in
  * score-descending stable order, like torchvision.ops.batched_nms called at box_head.py:422).
  * boxes (n,4) fp32 xyxy, scores (n) fp32, labels (n) int32; keep_out (n) int32, count_out int32[1]. */
@@ -194,6 +212,9 @@ int ymi_plan_add_upsample2x(ymi_plan* p, const void* x, int x_cstride, int n, in
 int ymi_plan_add_copy_view(ymi_plan* p, const void* x, int x_cstride, int npix, int c, void* y,
                            int y_cstride, int dtype);
 int ymi_plan_add_postprocess(ymi_plan* p, const ymi_post_desc* d);
+int ymi_plan_add_post_begin(ymi_plan* p, const ymi_post_desc* d);
+int ymi_plan_add_head_decode(ymi_plan* p, const ymi_conv_desc* conv, const ymi_post_desc* d, int level);
+int ymi_plan_add_post_finish(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_num_ops(const ymi_plan* p);
 /* runs ops [first, last) on stream (last < 0 = all); use_graph != 0 replays a captured hipGraph */
 int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream);

@@ -72,7 +72,12 @@ def test_yolov5n_against_reference_golden(dev, golden_dir, dtype):
     S, thr = int(z["S"]), float(z["thr"])
     m = _model("yolov5_darknet_pan_n_r60", dev, dtype, size=(S, S), score_thresh=thr, nms_thresh=0.45, head_gain=float(z["head_gain"]))
     imgs_cpu = [synth_images(1, int(h), int(w), seed=11 + i)[0] for i, (h, w) in enumerate(z["sizes"])]
+    dets_fused = m.predict([im.to(dev) for im in imgs_cpu])       # default: decode fused into the head convolution
+    m.model.fuse_head_decode = False                               # keep the logits as buffers to compare them below
     dets = m.predict([im.to(dev) for im in imgs_cpu])
+    for a, b in zip(dets_fused, dets):                             # both forms must agree bit for bit
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), f"fused / unfused head disagree on {k}"
     e = next(iter(m.model._entries.values()))
     # inherent storage-precision error of this network, from the oracle's emulation mode
     sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
@@ -141,6 +146,29 @@ def test_yolov5s_640_vs_oracle(dev):
         print(f"yolov5s 640: {len(r['scores'])} ref dets, matched {frac:.3f}, median IoU {miou:.4f}, max dscore {ds:.4f}")
         assert len(r["scores"]) > 10
         assert frac >= 0.93 and miou >= 0.93, f"matched {frac:.3f} (max dscore {ds}) of {len(r['scores'])}"
+
+
+@pytest.mark.parametrize("arch,num_classes,dtype", [("yolov5_darknet_pan_s_r60", 80, torch.float16), ("yolov5_darknet_pan_n_r60", 20, torch.bfloat16),
+                                                    ("yolov5_darknet_pan_n_r60", 3, torch.float16), ("yolov5_darknet_pan_n_r60", 100, torch.float16)])
+def test_fused_head_decode_equals_unfused(dev, arch, num_classes, dtype):
+    """ymi_conv_head_decode (decode + threshold in the head conv's epilogue) must produce exactly the records
+    the stored-logits path produces: same detections bit for bit, same candidate count; K = num_classes + 5 covers
+    every anchor padding (32, 64, 96, 128 rows) and a batch whose 20x20 / 10x10 levels make waves span images"""
+    from yolort_amd.utils.synth import synth_images
+    m = _model(arch, dev, dtype, num_classes=num_classes, score_thresh=0.2, nms_thresh=0.45)
+    x = torch.stack([im for im in synth_images(5, 320, 320, seed=5)]).to(dev).to(dtype)
+    outs, ncand = [], []
+    for fused in (True, False):
+        m.model.fuse_head_decode = fused
+        outs.append(m.model(x))
+        e = next(iter(m.model._entries.values()))
+        assert (e.logits is None) == fused
+        ncand.append(int(e.post.status[0].item()))
+    assert ncand[0] == ncand[1] and ncand[0] > 0
+    for a, b in zip(*outs):
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), f"fused / unfused head disagree on {k}"
+    assert sum(len(d["scores"]) for d in outs[0]) > 0
 
 
 def test_mixed_sizes_and_yolo_forward(dev):

@@ -16,12 +16,22 @@ lib.ymi_debug_stamps.restype = C.c_int
 lib.ymi_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 
 for case in sys.argv[1:]:
-    n, cin, cout, h, w, k, s, p, tile = map(int, case.split(","))
     plan = engine.Plan(dev, torch.float16)
-    x = plan.alloc(n, h, w, cin); x.base.normal_()
-    wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
-    pc = engine.PackedConv(wt, None, None, torch.float16, dev)
-    plan.conv(x, pc, s, p, tile=tile)
+    if case.startswith("head,"):   # head,n,cin,hw,thr : fused head + decode of one level (80 classes)
+        _, n, cin, h, thr = case.split(",")
+        n, cin, h, w, k = int(n), int(cin), int(h), int(h), 1
+        x = plan.alloc(n, h, w, cin); x.base.normal_()
+        wt = torch.randn(288, cin, 1, 1) / cin ** 0.5
+        pc = engine.PackedConv(wt, torch.full((288,), -2.0), None, torch.float16, dev)
+        pb, pd = plan.post_desc([(h, w)], n, [8.0], [[10, 13, 16, 30, 33, 23]], 80, float(thr), 0.45, 300, 16384 * n)
+        plan.head_decode(x, pc, pd, 0)
+        cin = cin
+    else:
+        n, cin, cout, h, w, k, s, p, tile = map(int, case.split(","))
+        x = plan.alloc(n, h, w, cin); x.base.normal_()
+        wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+        pc = engine.PackedConv(wt, None, None, torch.float16, dev)
+        plan.conv(x, pc, s, p, tile=tile)
     for _ in range(3):
         plan.run()
     torch.cuda.synchronize()

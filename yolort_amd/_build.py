@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.environ.get("YOLORT_AMD_BUILD_OUT") or os.path.join(LIBDIR, "libyolort_amd.so")   # override: tuning builds only
 SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_stem.hip", "preproc_pool.hip", "postprocess.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "conv_common.hpp"), os.path.join(os.path.dirname(PKG), "include", "yolort_amd.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(os.path.dirname(PKG), "include", "yolort_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 FLAGS += os.environ.get("YOLORT_AMD_BUILD_FLAGS", "").split()   # e.g. -DYMI_STAMPS for tools/stamp_conv.py
 

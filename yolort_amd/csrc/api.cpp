@@ -20,8 +20,11 @@ void set_error(const char* fmt, ...) {
 
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);
 int postprocess_launch(const ymi_post_desc* d, hipStream_t s);
+int post_begin_launch(const ymi_post_desc* d, hipStream_t s);
+int post_finish_launch(const ymi_post_desc* d, hipStream_t s);
+int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s);
 
-enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST };
+enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_POST_FINISH };
 
 struct Op {
     OpKind kind;
@@ -40,6 +43,9 @@ static int run_op(const Op& op, hipStream_t s) {
         case OP_UP: return ymi_upsample2x(op.x, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.y, op.i[5], op.i[6], s);
         case OP_COPY: return ymi_copy_view(op.x, op.i[0], op.i[1], op.i[2], op.y, op.i[3], op.i[4], s);
         case OP_POST: return postprocess_launch(&op.post, s);
+        case OP_POST_BEGIN: return post_begin_launch(&op.post, s);
+        case OP_HEAD_DECODE: return conv_head_decode_launch(&op.conv, &op.post, op.i[0], s);
+        case OP_POST_FINISH: return post_finish_launch(&op.post, s);
     }
     set_error("unknown op kind");
     return YMI_EINVAL;
@@ -141,6 +147,33 @@ extern "C" int ymi_plan_add_postprocess(ymi_plan* p, const ymi_post_desc* d) {
     p->ops.push_back(op);
     drop_graph(p);
     return (int)p->ops.size() - 1;
+}
+
+static int add_post_op(ymi_plan* p, OpKind kind, const ymi_post_desc* d, const ymi_conv_desc* conv, int level) {
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = kind;
+    op.post = *d;
+    if (conv) op.conv = *conv;
+    op.i[0] = level;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_post_begin(ymi_plan* p, const ymi_post_desc* d) {
+    YMI_REQUIRE(p && d, "ymi_plan_add_post_begin: null argument");
+    return add_post_op(p, OP_POST_BEGIN, d, nullptr, 0);
+}
+
+extern "C" int ymi_plan_add_head_decode(ymi_plan* p, const ymi_conv_desc* conv, const ymi_post_desc* d, int level) {
+    YMI_REQUIRE(p && conv && d, "ymi_plan_add_head_decode: null argument");
+    return add_post_op(p, OP_HEAD_DECODE, d, conv, level);
+}
+
+extern "C" int ymi_plan_add_post_finish(ymi_plan* p, const ymi_post_desc* d) {
+    YMI_REQUIRE(p && d, "ymi_plan_add_post_finish: null argument");
+    return add_post_op(p, OP_POST_FINISH, d, nullptr, 0);
 }
 
 extern "C" int ymi_plan_num_ops(const ymi_plan* p) { return p ? (int)p->ops.size() : 0; }

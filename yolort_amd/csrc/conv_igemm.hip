@@ -19,6 +19,7 @@
 // Replaces: yolort/v5/models/common.py:69-70 (Conv.forward: conv2d -> BatchNorm2d -> SiLU, BN folded),
 //           common.py:115-116 (Bottleneck residual), yolort/models/box_head.py:36,74 (head conv).
 #include "conv_common.hpp"
+#include "head_decode.hpp"
 
 namespace ymi {
 
@@ -241,8 +242,10 @@ __device__ unsigned long long ymi_stamps[2048 * 128];
 // PIPE: software-pipelined main loop -- MFMA fragments are double-buffered in registers (the LDS reads of the next
 // half-step and the DMA issue of a later stage sit between the MFMAs of the current one), so a single wave keeps
 // its SIMD's matrix pipe busy instead of serialising wait -> barrier -> DMA issue -> LDS latency -> MFMA.
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
-__global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
+// The epilogue is a functor: epi(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem) -- plain stores (StoreEpilogue)
+// or the fused detection decode of the head (head_decode.hpp).
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE, class Epi>
+__device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi) {
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -506,12 +509,47 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
     }
 
     YMI_STAMP(3);
-    // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
-    finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, [&](int j, int64_t& m, bool& ok) {
-        m = m0 + wave_m + j * 32 + frow;
-        ok = m < a.M;
-    });
+    epi(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem);
     YMI_STAMP(127);
+}
+
+// SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp)
+template <int DT, int ODT>
+struct StoreEpilogue {
+    const ConvArgs& a;
+    template <int TN, int TM>
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[TN][TM], int mbase, int cbase0, int lane, int, uint16_t*) const {
+        finish_wave_tile<DT, ODT, TN, TM>(a, acc, cbase0, lane >> 5, [&](int j, int64_t& m, bool& ok) {
+            m = mbase + j * 32 + (lane & 31);
+            ok = m < a.M;
+        });
+    }
+};
+
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
+__global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
+    conv_igemm_v2_body<DT, ODT, BM, BN, WM, WN, STAGES, IS1X1, UTAP, PIPE>(a, StoreEpilogue<DT, ODT>{a});
+}
+
+// ---- detection head with the decode fused into the epilogue (head_decode.hpp): 128 pixels x (3 anchors x 32*TNA rows) ----
+constexpr int HD_STAGES = 3;   // operand ring depth of the head kernel (its LDS footprint is set by the decode buffers anyway)
+
+template <int TNA>
+struct DecodeEpilogue {
+    const ConvArgs& a;
+    const HeadDecodeArgs& h;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[3 * TNA][1], int mbase, int, int lane, int wave, uint16_t* smem) const {
+        __syncthreads();   // every wave is done with the operand ring: it becomes the record buffers
+        uint64_t* bhi = reinterpret_cast<uint64_t*>(smem) + wave * HD_BUF;
+        uint32_t* blo = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + 4 * HD_BUF) + wave * HD_BUF;
+        u32x4* wl = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(smem) + 4 * HD_BUF * 12) + wave * HD_WL;
+        head_decode_wave<TNA>(a, h, acc, mbase + (lane & 31), lane, bhi, blo, wl);
+    }
+};
+
+template <int DT, int TNA>
+__global__ __launch_bounds__(256) void conv_head_decode_kernel(const ConvArgs a, const HeadDecodeArgs h) {
+    conv_igemm_v2_body<DT, YMI_F32, 128, 96 * TNA, 32, 96 * TNA, HD_STAGES, false, true, true>(a, DecodeEpilogue<TNA>{a, h});
 }
 
 template <typename K>
@@ -615,6 +653,28 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     }
 }
 
+// descriptor -> kernel arguments (shared by ymi_conv2d and ymi_conv_head_decode); validation of the zero page included
+static int fill_conv_args(const ymi_conv_desc* d, ConvArgs& a) {
+    a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = d->bias; a.ktab = (const int2*)d->ktab;
+    a.y = d->y; a.res = (const uint16_t*)d->res;
+    a.n = d->n; a.h = d->h; a.w_in = d->w_in; a.cin = d->cin; a.x_cs = d->x_cstride;
+    a.ho = d->ho; a.wo = d->wo; a.cout = d->cout; a.cout_pad = d->cout_pad; a.y_cs = d->y_cstride; a.res_cs = d->res_cstride;
+    a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw; a.k_pad = d->k_pad; a.act = d->act;
+    a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
+    a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
+    a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
+    auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
+    a.magic_hw = magic(d->ho * d->wo);
+    a.magic_w = magic(d->wo);
+    if (d->zeros != nullptr) {
+        const int64_t dz = ((const char*)d->zeros - (const char*)d->x) / 2;
+        YMI_REQUIRE(dz > -((int64_t)1 << 31) && dz < ((int64_t)1 << 31) && ((const char*)d->zeros - (const char*)d->x) % 16 == 0,
+                    "ymi_conv2d: desc.zeros must lie within +-4 GiB of x and be 16-byte aligned relative to it (use the tail of x's buffer)");
+        a.x_zero_off = (int)dz;
+    }
+    return YMI_OK;
+}
+
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     YMI_REQUIRE(d != nullptr, "ymi_conv2d: null descriptor");
     YMI_REQUIRE(d->x && d->w && d->bias && d->y, "ymi_conv2d: null buffer");
@@ -633,23 +693,7 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
         return YMI_EINVAL;
     }
     ConvArgs a;
-    a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = d->bias; a.ktab = (const int2*)d->ktab;
-    a.y = d->y; a.res = (const uint16_t*)d->res;
-    a.n = d->n; a.h = d->h; a.w_in = d->w_in; a.cin = d->cin; a.x_cs = d->x_cstride;
-    a.ho = d->ho; a.wo = d->wo; a.cout = d->cout; a.cout_pad = d->cout_pad; a.y_cs = d->y_cstride; a.res_cs = d->res_cstride;
-    a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw; a.k_pad = d->k_pad; a.act = d->act;
-    a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
-    a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
-    a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
-    auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
-    a.magic_hw = magic(d->ho * d->wo);
-    a.magic_w = magic(d->wo);
-    if (d->zeros != nullptr) {
-        const int64_t dz = ((const char*)d->zeros - (const char*)d->x) / 2;
-        YMI_REQUIRE(dz > -((int64_t)1 << 31) && dz < ((int64_t)1 << 31) && ((const char*)d->zeros - (const char*)d->x) % 16 == 0,
-                    "ymi_conv2d: desc.zeros must lie within +-4 GiB of x and be 16-byte aligned relative to it (use the tail of x's buffer)");
-        a.x_zero_off = (int)dz;
-    }
+    { const int rc_args = fill_conv_args(d, a); if (rc_args != YMI_OK) return rc_args; }
     YMI_REQUIRE(a.split == 0 || (d->y2 != nullptr && a.split % 8 == 0 && a.split < d->cout && d->res == nullptr && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0),
                 "ymi_conv2d: invalid second-output configuration");
     YMI_REQUIRE(a.split == 0 || a.zeros != nullptr, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");
@@ -669,6 +713,72 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     }
 }
 
+
+template <int DT, int TNA>
+static int launch_head_decode(const ConvArgs& a0, const HeadDecodeArgs& h, hipStream_t s) {
+    ConvArgs a = a0;
+    constexpr int BN = 96 * TNA;
+    a.nblk_m = cdiv(a.M, 128);
+    a.nblk_n = 1;
+    size_t lds = (size_t)HD_STAGES * (128 + BN) * 64 + 16;
+    const size_t need = (size_t)HD_LDS_BYTES + 16;   // the ring doubles as the per-wave record buffers and worklists
+    if (lds < need) lds = need;
+    auto kfn = conv_head_decode_kernel<DT, TNA>;
+    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kfn, dim3(a.nblk_m), dim3(256), lds, s, a, h);
+    return check_launch("conv_head_decode_kernel");
+}
+
+// Head conv of pyramid level `level` with decode + threshold fused into the epilogue.  The descriptor's weights hold
+// every anchor's K rows padded to RA = round_up(K, 32) rows (cout = cout_pad = 3*RA); y is not written.
+int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s) {
+    YMI_REQUIRE(d != nullptr && post != nullptr, "ymi_conv_head_decode: null descriptor");
+    YMI_REQUIRE(level >= 0 && level < post->num_levels && post->num_levels <= YMI_MAX_LEVELS, "ymi_conv_head_decode: level %d out of range", level);
+    YMI_REQUIRE(d->x && d->w && d->bias && d->zeros, "ymi_conv_head_decode: null buffer (x, w, bias and the zero page are required)");
+    const int K = post->num_classes + 5;
+    const int ra = (K + 31) / 32 * 32;
+    YMI_REQUIRE(ra <= 128, "ymi_conv_head_decode: %d outputs per anchor exceed 128 (use ymi_conv2d + ymi_postprocess)", K);
+    YMI_REQUIRE(d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->cin % 32 == 0 && d->k_pad == d->cin,
+                "ymi_conv_head_decode: a 1x1 stride-1 convolution with cin %% 32 == 0 and k_pad == cin is required");
+    YMI_REQUIRE(d->cout == 3 * ra && d->cout_pad == 3 * ra, "ymi_conv_head_decode: cout / cout_pad must be 3 x %d (anchor-padded packing)", ra);
+    YMI_REQUIRE(d->res == nullptr && d->cout_split == 0 && d->act == YMI_ACT_NONE, "ymi_conv_head_decode: no residual / second output / activation");
+    YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16, "ymi_conv_head_decode: dtype must be F16 or BF16");
+    YMI_REQUIRE(d->x_cstride % 8 == 0, "ymi_conv_head_decode: x_cstride must be a multiple of 8");
+    YMI_REQUIRE(d->n == post->n && d->ho == post->lh[level] && d->wo == post->lw[level] && d->h == d->ho && d->w_in == d->wo,
+                "ymi_conv_head_decode: conv geometry %dx%dx%d does not match level %d of the post-process (%dx%dx%d)", d->n, d->ho, d->wo, level, post->n,
+                post->lh[level], post->lw[level]);
+    YMI_REQUIRE((int64_t)d->n * d->h * d->w_in * d->x_cstride < ((int64_t)1 << 31) && (int64_t)d->n * d->ho * d->wo < ((int64_t)1 << 31),
+                "ymi_conv_head_decode: tensor too large for 32-bit offsets");
+    YMI_REQUIRE(post->status && post->ws && post->n >= 1 && post->cand_cap >= 1, "ymi_conv_head_decode: incomplete post-process descriptor");
+    const PostLayout L = post_layout(post);
+    YMI_REQUIRE(L.label_bits + L.anchor_bits <= 32, "ymi_conv_head_decode: candidate index exceeds 32 bits");
+    const Workspace w = carve(post->ws, post->n, L.total_anchors, post->cand_cap);
+    YMI_REQUIRE(post->ws_bytes >= w.total, "ymi_conv_head_decode: workspace too small");
+    ConvArgs a;
+    { const int rc_args = fill_conv_args(d, a); if (rc_args != YMI_OK) return rc_args; }
+    if (a.M == 0) return YMI_OK;
+    HeadDecodeArgs h;
+    h.stride = post->stride[level];
+    for (int k = 0; k < 6; ++k) h.anc[k] = post->anchors[level][k];
+    h.K = K;
+    h.level_off = 0;
+    for (int l = 0; l < level; ++l) h.level_off += 3 * post->lh[l] * post->lw[l];
+    h.sink = make_sink(post, w, L);
+    const int tna = ra / 32;
+#define YMI_HD_CASE(T)                                                                                 \
+    case T:                                                                                            \
+        return d->dtype == YMI_F16 ? launch_head_decode<YMI_F16, T>(a, h, s) : launch_head_decode<YMI_BF16, T>(a, h, s);
+    switch (tna) {
+        YMI_HD_CASE(1)
+        YMI_HD_CASE(2)
+        YMI_HD_CASE(3)
+        YMI_HD_CASE(4)
+    }
+#undef YMI_HD_CASE
+    set_error("ymi_conv_head_decode: unsupported anchor padding %d", ra);
+    return YMI_EINVAL;
+}
+
 }  // namespace ymi
 
 #ifdef YMI_STAMPS
@@ -678,6 +788,9 @@ extern "C" int ymi_debug_stamps(unsigned long long* out, int n) {
 #endif
 
 extern "C" int ymi_conv2d(const ymi_conv_desc* d, void* stream) { return ymi::conv2d_launch(d, (hipStream_t)stream); }
+extern "C" int ymi_conv_head_decode(const ymi_conv_desc* conv, const ymi_post_desc* post, int level, void* stream) {
+    return ymi::conv_head_decode_launch(conv, post, level, (hipStream_t)stream);
+}
 
 extern "C" int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_pad, int32_t* t) {
     if (cin % 8 != 0 || k_pad % 32 != 0 || t == nullptr) {

@@ -1,0 +1,147 @@
+// Detection head with the decode FUSED into the convolution epilogue (gfx950).
+//
+// The reference runs the 1x1 head conv (yolort/models/box_head.py:36,74), concatenates the logits of all levels
+// (:328-343), then decodes and thresholds them (:345-360, :414-418).  Unfused, the fp32 logits make a round trip
+// through HBM (209 MB written + read per 32-image batch at 640x640) only for > 99.8 % of them to be discarded.
+// Here the head weights are packed with every anchor's K = num_classes + 5 rows padded to RA = 32*TNA rows, the tile
+// is 128 pixels x (3*RA) couts, and each wave owns 32 pixels x ALL couts: lanes l and l+32 together hold the K logits
+// of pixel l for each anchor, so objectness / box logits cross between them with one ds_bpermute each and no LDS
+// staging.  The wave then
+//   * decodes the box of every (pixel, anchor) and stores it to boxes_all (NMS looks boxes up by anchor index),
+//   * skips anchors whose objectness fails the threshold for all 32 pixels (score = cls*obj <= obj),
+//   * pre-filters class logits against theta = logit(thr / obj) - margin (one log per anchor instead of a sigmoid
+//     per class) and pushes the survivors -- few per register row -- onto a per-wave LDS worklist,
+//   * drains the worklist 64 entries at a time (every lane busy): exact score as in the unfused kernel
+//     (sigmoid_acc, rounded product, strict >), records appended to a per-wave LDS buffer flushed with one atomic.
+//     (The LDS operand ring is dead by then and is reused for both.)
+// Records and boxes are bit-identical to decode_kernel's (postprocess.hip), so sort / NMS / top-k are unchanged.
+#pragma once
+#include "conv_common.hpp"
+#include "post_common.hpp"
+
+namespace ymi {
+
+constexpr int HD_BUF = 1024;   // records per wave buffer (12 KiB); one append adds at most 64
+constexpr int HD_WL = 512;     // worklist entries per wave (8 KiB): pre-filter survivors waiting for their exact score
+constexpr int HD_LDS_BYTES = 4 * (HD_BUF * 12 + HD_WL * 16);   // per block (4 waves); overlays the dead operand ring
+
+struct HeadDecodeArgs {
+    float stride;
+    float anc[6];
+    int K;            // outputs per anchor (num_classes + 5)
+    int level_off;    // index of this level's first anchor within an image
+    CandSink sink;
+};
+
+// acc[3*TNA][1]: sub-tile s of anchor q is acc[q*TNA + s][0]; register g*4+e of lane (px, hi) is channel
+// c = s*32 + g*8 + hi*4 + e of that anchor (c < K real, else zero padding)
+template <int TNA>
+__device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDecodeArgs& h, const f32x16 (&acc)[3 * TNA][1], int m, int lane,
+                                                 uint64_t* bhi, uint32_t* blo, u32x4* wl) {
+    const CandSink& k_ = h.sink;
+    const int hi = lane >> 5;
+    const bool m_ok = m < a.M;
+    const int mm = m_ok ? m : 0;
+    const int hw = a.ho * a.wo;
+    const int img = fast_div(mm, hw, a.magic_hw);
+    const int rem = mm - img * hw;
+    const int y = fast_div(rem, a.wo, a.magic_w), x = rem - y * a.wo;
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int fill = 0;                                            // records buffered (wave-uniform)
+    int fill_img = __builtin_amdgcn_readfirstlane(img);     // image they belong to
+    int wl_fill = 0;                                         // worklist entries (wave-uniform)
+    auto flush = [&]() {
+        flush_records(k_, bhi, blo, fill, fill_img, lane);
+        fill = 0;
+    };
+    // append the records of the lanes with ok set; the lanes of one call can belong to different images
+    auto append = [&](bool ok, float s, unsigned lo, int img_l) {
+        uint64_t mask = __ballot(ok);
+        while (mask) {
+            const int first = __builtin_ctzll(mask);
+            const int img0 = __builtin_amdgcn_readlane(img_l, first);
+            const uint64_t sub = mask & __ballot(img_l == img0);
+            if (img0 != fill_img) {
+                flush();
+                fill_img = img0;
+            }
+            const int cnt = __popcll(sub);
+            if (fill + cnt > HD_BUF) flush();
+            if (ok && img_l == img0) {
+                const int pos = fill + __popcll(sub & lt);
+                bhi[pos] = ((uint64_t)(unsigned)img_l << 32) | (uint64_t)(~__float_as_uint(s));
+                blo[pos] = lo;
+            }
+            fill += cnt;
+            mask &= ~sub;
+        }
+    };
+    // exact scores of worklist entries, 64 at a time; `all` = also the last partial batch
+    auto drain = [&](bool all) {
+        int base = 0;
+        while (wl_fill - base >= 64 || (all && base < wl_fill)) {
+            const int i = base + lane;
+            const bool have = i < wl_fill;
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (have) e = wl[i];
+            const float sc = __fmul_rn(sigmoid_acc(__uint_as_float(e[0])), __uint_as_float(e[1]));   // box_head.py:357 scores = cls * obj
+            append(have && sc > k_.thr, sc, e[2], (int)e[3]);                                      // box_head.py:418 strict >
+            base += 64;
+        }
+        const int left = wl_fill > base ? wl_fill - base : 0;
+        if (left > 0 && base > 0) {   // move the partial batch to the front
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (lane < left) e = wl[base + lane];
+            if (lane < left) wl[lane] = e;
+        }
+        wl_fill = left;
+    };
+    auto push = [&](bool pre, float v, float o, unsigned lo) {
+        const uint64_t mask = __ballot(pre);
+        const int cnt = __popcll(mask);
+        if (wl_fill + cnt > HD_WL) drain(false);   // leaves < 64 entries
+        if (pre) {
+            u32x4 e = {__float_as_uint(v), __float_as_uint(o), lo, (unsigned)img};
+            wl[wl_fill + __popcll(mask & lt)] = e;
+        }
+        wl_fill += cnt;
+    };
+
+    // compile-time indices everywhere: the accumulators must stay in registers (a runtime index sends them to scratch)
+    static_for<0, 3>([&](auto qt) {
+        constexpr int q = decltype(qt)::value;
+        // channels 0..3 (box) live on the hi = 0 lane, 4..7 (objectness, first classes) on the hi = 1 lane
+        const float t0 = acc[q * TNA][0][0], t1 = acc[q * TNA][0][1], t2 = acc[q * TNA][0][2], t3 = acc[q * TNA][0][3];
+        const float u0 = __shfl_xor(t0, 32, 64), u1 = __shfl_xor(t1, 32, 64), u2 = __shfl_xor(t2, 32, 64), u3 = __shfl_xor(t3, 32, 64);
+        const float lx = hi ? u0 : t0, ly = hi ? u1 : t1, lw = hi ? u2 : t2, lh = hi ? u3 : t3;
+        const float lobj = hi ? t0 : u0;
+        const int anchor = h.level_off + (q * a.ho + y) * a.wo + x;
+        if (hi == 0 && m_ok) {
+            const f32x4 b = decode_box(lx, ly, lw, lh, x, y, h.stride, h.anc[2 * q], h.anc[2 * q + 1]);
+            *reinterpret_cast<f32x4*>(k_.boxes_all + ((int64_t)img * k_.total_anchors + anchor) * 4) = b;
+        }
+        const float o = sigmoid_acc(lobj);
+        const bool pass = m_ok && o > k_.thr;      // score = cls * obj <= obj
+        if (__ballot(pass) == 0) return;            // wave-uniform: nothing to find for this anchor
+        // cls * o > thr  =>  sigmoid(v) > thr / o  =>  v > logit(thr / o); the margin keeps the filter a superset
+        float theta = INFINITY;
+        if (pass) {
+            const float p = k_.thr / o;
+            theta = __logf(p / (1.0f - p)) - 0.02f;
+        }
+        const unsigned lo_base = (unsigned)anchor << k_.label_bits;
+        static_for<0, TNA * 16>([&](auto rt) {
+            constexpr int r = decltype(rt)::value;
+            constexpr int s = r / 16, g = (r % 16) / 4, e = r % 4;
+            const int c = s * 32 + g * 8 + hi * 4 + e;
+            const float v = acc[q * TNA + s][0][g * 4 + e];
+            const bool pre = (c >= 5) && (c < h.K) && (v > theta);
+            if (__ballot(pre) == 0) return;          // the common case
+            push(pre, v, o, lo_base | (unsigned)(c - 5));
+        });
+    });
+    drain(true);
+    flush();
+}
+
+}  // namespace ymi

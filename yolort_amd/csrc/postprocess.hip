@@ -12,53 +12,10 @@
 // with L = label bits.  Sorting records ascending by (hi, lo) gives, per image, score descending
 // with ties in candidate order (anchor asc, class asc) == a stable descending sort of the
 // reference's torch.where order (box_head.py:418).
-#include "common.hpp"
+#include "post_common.hpp"
 
 namespace ymi {
 
-// status words (device int32[4])
-enum { ST_NCAND = 0, ST_OVERFLOW = 1, ST_NSEG = 2, ST_RSV = 3 };
-
-struct Workspace {
-    // all device pointers, carved from the caller's `ws`
-    float* boxes_all;     // (n, A, 4) decoded xyxy boxes of every anchor
-    uint64_t* hi[2];      // ping-pong record arrays (cand_cap each)
-    uint32_t* lo[2];
-    uint32_t* hist;       // (max_blocks, 256) per-block digit counts / offsets
-    uint32_t* seg_start;  // (cand_cap) segment start positions (unordered)
-    float* kept_box;      // (cand_cap, 4) per-segment kept boxes
-    uint8_t* keep;        // (cand_cap) keep flag indexed by global rank r
-    int* img_count;       // (n) candidates appended per image (per-image sort path)
-    uint64_t* p_hi;       // per-class order P of the per-image sort path (cand_cap each)
-    uint32_t* p_lo;
-    int64_t total;
-};
-
-constexpr int SORT_ITEMS = 2048;  // records per block per radix pass (256 threads x 8)
-
-static int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
-
-static Workspace carve(void* ws, int n, int total_anchors, int cand_cap) {
-    Workspace w;
-    char* p = (char*)ws;
-    int64_t off = 0;
-    auto take = [&](int64_t bytes) { char* q = p ? p + off : nullptr; off += align_up(bytes); return q; };
-    const int max_blocks = cdiv(cand_cap, SORT_ITEMS);
-    w.boxes_all = (float*)take((int64_t)n * total_anchors * 16);
-    w.hi[0] = (uint64_t*)take((int64_t)cand_cap * 8);
-    w.hi[1] = (uint64_t*)take((int64_t)cand_cap * 8);
-    w.lo[0] = (uint32_t*)take((int64_t)cand_cap * 4);
-    w.lo[1] = (uint32_t*)take((int64_t)cand_cap * 4);
-    w.hist = (uint32_t*)take((int64_t)max_blocks * 256 * 4 + 1024);
-    w.seg_start = (uint32_t*)take((int64_t)cand_cap * 4);
-    w.kept_box = (float*)take((int64_t)cand_cap * 16);
-    w.keep = (uint8_t*)take((int64_t)cand_cap);
-    w.img_count = (int*)take((int64_t)(n > 0 ? n : 1) * 4);
-    w.p_hi = (uint64_t*)take((int64_t)cand_cap * 8);
-    w.p_lo = (uint32_t*)take((int64_t)cand_cap * 4);
-    w.total = off;
-    return w;
-}
 
 // ------------------------------------------------------------------------------------------
 // 1. decode + threshold.  One wave per feature-map pixel: its 3 x K logits are contiguous in the
@@ -74,19 +31,8 @@ struct DecodeArgs {
     float anc[6];
     int n, K;              // images, outputs per anchor (num_classes + 5)
     int level_off;         // index of this level's first anchor within an image
-    int total_anchors;     // anchors per image over all levels
-    int label_bits;
-    float thr;
-    float* boxes_all;
-    uint64_t* hi;
-    uint32_t* lo;
-    int* status;
-    int cap;
-    int* img_count;   // non-null: append to per-image regions [img*cap_img, +cap_img) (per-image LDS sort path)
-    int cap_img;
+    CandSink sink;
 };
-
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 constexpr int DEC_PIX_PER_WAVE = 8;     // pixels walked by one wave
 constexpr int DEC_BUF = 512;            // candidate records buffered per wave in LDS before ONE global atomic
@@ -97,6 +43,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     // ~88 atomics/us: one atomic per pixel made this kernel atomic-bound).
     __shared__ uint64_t buf_hi[4][DEC_BUF];
     __shared__ uint32_t buf_lo[4][DEC_BUF];
+    const CandSink& k_ = a.sink;
     const int lane = threadIdx.x & 63;
     const int wl = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wl;
@@ -110,29 +57,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     int fill_img = 0;  // image the buffered records belong to (per-image path flushes on image change)
 
     auto flush = [&]() {
-        if (fill == 0) return;
-        int base = 0;
-        if (a.img_count != nullptr) {
-            if (lane == 0) base = atomicAdd(&a.img_count[fill_img], fill);
-            base = __shfl(base, 0, 64);
-            for (int i = lane; i < fill; i += 64) {
-                const int pos = base + i;
-                if (pos < a.cap_img) {
-                    a.hi[(int64_t)fill_img * a.cap_img + pos] = bhi[i];
-                    a.lo[(int64_t)fill_img * a.cap_img + pos] = blo[i];
-                }
-            }
-        } else {
-            if (lane == 0) base = atomicAdd(&a.status[ST_NCAND], fill);
-            base = __shfl(base, 0, 64);
-            for (int i = lane; i < fill; i += 64) {
-                const int pos = base + i;
-                if (pos < a.cap) {
-                    a.hi[pos] = bhi[i];
-                    a.lo[pos] = blo[i];
-                }
-            }
-        }
+        flush_records(k_, bhi, blo, fill, fill_img, lane);
         fill = 0;
     };
 
@@ -148,22 +73,13 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             obj[k] = sigmoid_acc(row[k * a.K + 4]);
-            any_obj |= obj[k] > a.thr;
+            any_obj |= obj[k] > k_.thr;
         }
         if (lane < 3) {
             const float* r = row + lane * a.K;
-            const float sx = sigmoid_acc(r[0]), sy = sigmoid_acc(r[1]), sw = sigmoid_acc(r[2]), sh = sigmoid_acc(r[3]);
-            // _utils.py:59-60: xy = (s*2 - 0.5 + grid) * stride ; wh = (s*2)**2 * anchor   (each op rounded)
-            const float cx = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sx, 2.0f), 0.5f), (float)x), a.stride);
-            const float cy = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sy, 2.0f), 0.5f), (float)y), a.stride);
-            const float w2 = __fmul_rn(sw, 2.0f), h2 = __fmul_rn(sh, 2.0f);
-            const float bw = __fmul_rn(__fmul_rn(w2, w2), a.anc[2 * lane]);
-            const float bh = __fmul_rn(__fmul_rn(h2, h2), a.anc[2 * lane + 1]);
-            // box_convert cxcywh -> xyxy (box_head.py:358)
-            const float hw_ = __fmul_rn(0.5f, bw), hh_ = __fmul_rn(0.5f, bh);
-            f32x4 b = {__fsub_rn(cx, hw_), __fsub_rn(cy, hh_), __fadd_rn(cx, hw_), __fadd_rn(cy, hh_)};
+            const f32x4 b = decode_box(r[0], r[1], r[2], r[3], x, y, a.stride, a.anc[2 * lane], a.anc[2 * lane + 1]);
             const int anchor = a.level_off + (lane * a.h + y) * a.w + x;
-            *reinterpret_cast<f32x4*>(a.boxes_all + ((int64_t)img * a.total_anchors + anchor) * 4) = b;
+            *reinterpret_cast<f32x4*>(k_.boxes_all + ((int64_t)img * k_.total_anchors + anchor) * 4) = b;
         }
         if (!any_obj) continue;
         if (fill + nch > DEC_BUF || img != fill_img) flush();   // a pixel yields at most nch - 15 records
@@ -187,11 +103,11 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
                 if (ok) {
                     const float o = k == 0 ? obj[0] : (k == 1 ? obj[1] : obj[2]);
                     s = __fmul_rn(sigmoid_acc(v[e]), o);  // box_head.py:357 scores = cls * obj
-                    ok = s > a.thr;                        // box_head.py:418 strict >
+                    ok = s > k_.thr;                       // box_head.py:418 strict >
                 }
                 sc[e] = s;
                 const int anchor = a.level_off + (k * a.h + y) * a.w + x;
-                cand[e] = ((unsigned)anchor << a.label_bits) | (unsigned)(cls < 0 ? 0 : cls);
+                cand[e] = ((unsigned)anchor << k_.label_bits) | (unsigned)(cls < 0 ? 0 : cls);
                 if (!ok) cand[e] = 0xffffffffu;
                 cnt += ok ? 1 : 0;
             }
@@ -664,11 +580,6 @@ __global__ __launch_bounds__(256) void gather_topk_kernel(const GatherArgs a) {
 // ------------------------------------------------------------------------------------------
 // host-side orchestration
 // ------------------------------------------------------------------------------------------
-static int bits_for(int64_t v) {  // number of bits needed to represent values in [0, v)
-    int b = 0;
-    while (((int64_t)1 << b) < v) ++b;
-    return b;
-}
 
 struct SortState {
     int cur;  // index of the array pair holding the current order
@@ -743,61 +654,89 @@ static int sort_nms_gather(const Workspace& w, SortState st, int* status, int ca
     return nms_gather(w, g, phi, plo, status, cap, n_img, label_bits, total_anchors, nms_thresh, K, rescale, out_boxes, out_scores, out_labels, out_count, s);
 }
 
-int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
+static int post_validate(const ymi_post_desc* d, bool need_logits, PostLayout& L, Workspace& w) {
     YMI_REQUIRE(d != nullptr, "ymi_postprocess: null descriptor");
     YMI_REQUIRE(d->num_levels >= 1 && d->num_levels <= YMI_MAX_LEVELS, "ymi_postprocess: num_levels %d out of range", d->num_levels);
     YMI_REQUIRE(d->n >= 1 && d->n <= 65535, "ymi_postprocess: batch size %d out of range", d->n);
     YMI_REQUIRE(d->num_classes >= 1 && d->num_classes <= 4096, "ymi_postprocess: num_classes %d out of range", d->num_classes);
     YMI_REQUIRE(d->out_boxes && d->out_scores && d->out_labels && d->out_count && d->status && d->ws, "ymi_postprocess: null buffer");
     YMI_REQUIRE(d->detections_per_img >= 1 && d->cand_cap >= 1, "ymi_postprocess: detections_per_img and cand_cap must be positive");
-    int total_anchors = 0;
     for (int l = 0; l < d->num_levels; ++l) {
-        YMI_REQUIRE(d->logits[l] != nullptr, "ymi_postprocess: logits[%d] is null", l);
-        YMI_REQUIRE(d->lcstride[l] >= 3 * (d->num_classes + 5) && d->lcstride[l] % 4 == 0, "ymi_postprocess: lcstride[%d]=%d too small / not a multiple of 4", l, d->lcstride[l]);
-        total_anchors += 3 * d->lh[l] * d->lw[l];
+        YMI_REQUIRE(d->lh[l] >= 1 && d->lw[l] >= 1, "ymi_postprocess: level %d has an empty grid", l);
+        if (need_logits) {
+            YMI_REQUIRE(d->logits[l] != nullptr, "ymi_postprocess: logits[%d] is null", l);
+            YMI_REQUIRE(d->lcstride[l] >= 3 * (d->num_classes + 5) && d->lcstride[l] % 4 == 0, "ymi_postprocess: lcstride[%d]=%d too small / not a multiple of 4", l, d->lcstride[l]);
+        }
     }
-    const int label_bits = bits_for(d->num_classes) < 1 ? 1 : bits_for(d->num_classes);
-    const int anchor_bits = bits_for(total_anchors);
-    YMI_REQUIRE(label_bits + anchor_bits <= 32, "ymi_postprocess: %d anchors x %d classes exceed the 32-bit candidate index", total_anchors, d->num_classes);
-    const Workspace w = carve(d->ws, d->n, total_anchors, d->cand_cap);
+    L = post_layout(d);
+    YMI_REQUIRE(L.label_bits + L.anchor_bits <= 32, "ymi_postprocess: %d anchors x %d classes exceed the 32-bit candidate index", L.total_anchors, d->num_classes);
+    w = carve(d->ws, d->n, L.total_anchors, d->cand_cap);
     YMI_REQUIRE(d->ws_bytes >= w.total, "ymi_postprocess: workspace too small (%lld < %lld)", (long long)d->ws_bytes, (long long)w.total);
+    return YMI_OK;
+}
+
+// stage 1 of 3: reset the counters the candidate producers append to
+int post_begin_launch(const ymi_post_desc* d, hipStream_t s) {
+    PostLayout L;
+    Workspace w;
+    int rc = post_validate(d, false, L, w);
+    if (rc != YMI_OK) return rc;
     YMI_CHECK_HIP(hipMemsetAsync(d->status, 0, 4 * sizeof(int), s));
     YMI_CHECK_HIP(hipMemsetAsync(d->out_count, 0, (size_t)d->n * sizeof(int), s));
-    // per-image LDS sort when an image's capacity fits the 160 KB LDS; else the global radix path
-    // per-image sort path: every image owns a power-of-two sized region of the record arrays
-    int cap_img = 64;
-    while (cap_img * 2 <= d->cand_cap / d->n) cap_img *= 2;
-    const bool per_image = d->cand_cap / d->n >= 64;
-    if (per_image) YMI_CHECK_HIP(hipMemsetAsync(w.img_count, 0, (size_t)d->n * sizeof(int), s));
+    if (L.per_image) YMI_CHECK_HIP(hipMemsetAsync(w.img_count, 0, (size_t)d->n * sizeof(int), s));
+    return YMI_OK;
+}
+
+// stage 2 of 3 (unfused form): decode + threshold of the fp32 head outputs
+static int post_decode_launch(const ymi_post_desc* d, hipStream_t s) {
+    PostLayout L;
+    Workspace w;
+    int rc = post_validate(d, true, L, w);
+    if (rc != YMI_OK) return rc;
     int level_off = 0;
     for (int l = 0; l < d->num_levels; ++l) {
         DecodeArgs a;
         a.logits = d->logits[l]; a.h = d->lh[l]; a.w = d->lw[l]; a.cs = d->lcstride[l]; a.stride = d->stride[l];
         for (int k = 0; k < 6; ++k) a.anc[k] = d->anchors[l][k];
-        a.n = d->n; a.K = d->num_classes + 5; a.level_off = level_off; a.total_anchors = total_anchors; a.label_bits = label_bits;
-        a.thr = d->score_thresh; a.boxes_all = w.boxes_all; a.hi = w.hi[0]; a.lo = w.lo[0]; a.status = d->status; a.cap = d->cand_cap;
-        a.img_count = per_image ? w.img_count : nullptr; a.cap_img = cap_img;
+        a.n = d->n; a.K = d->num_classes + 5; a.level_off = level_off;
+        a.sink = make_sink(d, w, L);
         const int64_t npix = (int64_t)d->n * a.h * a.w;
         hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((npix + 4 * DEC_PIX_PER_WAVE - 1) / (4 * DEC_PIX_PER_WAVE))), dim3(256), 0, s, a);
         level_off += 3 * a.h * a.w;
     }
-    int rc;
-    if (per_image) {
+    return check_launch("decode_kernel");
+}
+
+// stage 3 of 3: sort, class-aware NMS, top-k + rescale, from the records the producers appended
+int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
+    PostLayout L;
+    Workspace w;
+    int rc = post_validate(d, false, L, w);
+    if (rc != YMI_OK) return rc;
+    if (L.per_image) {
+        const int cap_img = L.cap_img;
         const int lds_keys = cap_img < IMG_SORT_MAX ? cap_img : IMG_SORT_MAX;
         const size_t lds = (size_t)lds_keys * 8;
         if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)sort_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // decode wrote arrays [0] (per-image regions); G goes to arrays [1] (compact), P to its own pair
-        hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, label_bits, lds_keys, w.hi[1], w.lo[1],
+        // the producers wrote arrays [0] (per-image regions); G goes to arrays [1] (compact), P to its own pair
+        hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, L.label_bits, lds_keys, w.hi[1], w.lo[1],
                            w.p_hi, w.p_lo, w.keep, d->status);
-        if ((rc = check_launch("decode/sort_image")) != YMI_OK) return rc;
-        return nms_gather(w, 1, w.p_hi, w.p_lo, d->status, d->cand_cap, d->n, label_bits, total_anchors, d->nms_thresh, d->detections_per_img, d->rescale,
+        if ((rc = check_launch("sort_image")) != YMI_OK) return rc;
+        return nms_gather(w, 1, w.p_hi, w.p_lo, d->status, d->cand_cap, d->n, L.label_bits, L.total_anchors, d->nms_thresh, d->detections_per_img, d->rescale,
                           d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);
     }
     hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(64), 0, s, d->status, d->cand_cap);
-    rc = check_launch("decode");
+    rc = check_launch("finalize_count");
     if (rc != YMI_OK) return rc;
-    return sort_nms_gather(w, SortState{0}, d->status, d->cand_cap, d->n, label_bits + anchor_bits, label_bits, total_anchors, d->nms_thresh,
+    return sort_nms_gather(w, SortState{0}, d->status, d->cand_cap, d->n, L.label_bits + L.anchor_bits, L.label_bits, L.total_anchors, d->nms_thresh,
                            d->detections_per_img, d->rescale, d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);
+}
+
+int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {
+    int rc = post_begin_launch(d, s);
+    if (rc != YMI_OK) return rc;
+    if ((rc = post_decode_launch(d, s)) != YMI_OK) return rc;
+    return post_finish_launch(d, s);
 }
 
 // ---- stand-alone batched NMS (one image) -------------------------------------------------
@@ -847,6 +786,8 @@ extern "C" int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_c
 }
 
 extern "C" int ymi_postprocess(const ymi_post_desc* d, void* stream) { return postprocess_launch(d, (hipStream_t)stream); }
+extern "C" int ymi_post_begin(const ymi_post_desc* d, void* stream) { return post_begin_launch(d, (hipStream_t)stream); }
+extern "C" int ymi_post_finish(const ymi_post_desc* d, void* stream) { return post_finish_launch(d, (hipStream_t)stream); }
 
 extern "C" int64_t ymi_nms_ws_bytes(int n) {
     if (n <= 0) n = 1;

@@ -236,7 +236,7 @@ class Plan:
         ref_reads = 2 if out2 is not None else 1
         self._record(self.lib.ymi_plan_add_conv(self.handle, C.byref(d)), name, kind="conv",
                      flops=flops, bytes=float(ref_reads * x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz),
-                     ref_convs=ref_reads,
+                     ref_convs=ref_reads, tile=int(d.tile),
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
 
@@ -302,30 +302,62 @@ class Plan:
                      kind="copy", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * 2 * 2), shape=f"c{x.c} {x.h}x{x.w}")
         return out
 
-    def postprocess(self, logits: Sequence[View], strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
-                    score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None) -> "PostBuffers":
-        n = logits[0].n
-        total_anchors = sum(3 * v.h * v.w for v in logits)
+    def post_desc(self, levels: Sequence[Tuple[int, int]], n: int, strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
+                  score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None,
+                  logits: Optional[Sequence[View]] = None) -> Tuple["PostBuffers", PostDesc]:
+        """descriptor + output slab + workspace of one post-process; `levels` = [(h, w)] per pyramid level"""
+        total_anchors = sum(3 * h * w for h, w in levels)
         pb = PostBuffers(self, n, detections_per_img, total_anchors, cand_cap, rescale)
         d = PostDesc()
-        for i, v in enumerate(logits):
-            if v.dtype != torch.float32:
-                raise YmiError("post-process expects fp32 head logits")
-            d.logits[i] = v.ptr
-            d.lh[i], d.lw[i], d.lcstride[i] = v.h, v.w, v.cs
+        for i, (h, w) in enumerate(levels):
+            d.lh[i], d.lw[i] = h, w
             d.stride[i] = float(strides[i])
             for k in range(6):
                 d.anchors[i][k] = float(anchors[i][k])
-        d.num_levels, d.n, d.num_classes = len(logits), n, num_classes
+            if logits is not None:
+                v = logits[i]
+                if v.dtype != torch.float32:
+                    raise YmiError("post-process expects fp32 head logits")
+                d.logits[i], d.lcstride[i] = v.ptr, v.cs
+        d.num_levels, d.n, d.num_classes = len(levels), n, num_classes
         d.score_thresh, d.nms_thresh, d.detections_per_img = score_thresh, nms_thresh, detections_per_img
         d.rescale = None if pb.rescale is None else pb.rescale.data_ptr()
         d.out_boxes, d.out_scores, d.out_labels, d.out_count = pb.boxes.data_ptr(), pb.scores.data_ptr(), pb.labels.data_ptr(), pb.count.data_ptr()
         d.status = pb.status.data_ptr()
         d.ws, d.ws_bytes, d.cand_cap = pb.ws.data_ptr(), pb.ws.numel(), cand_cap
+        pb.total_anchors = total_anchors
         self.keep.extend([pb, d])
+        return pb, d
+
+    def postprocess(self, logits: Sequence[View], strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
+                    score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None) -> "PostBuffers":
+        """decode of stored fp32 logits + sort + NMS + top-k as ONE op (the unfused form)"""
+        pb, d = self.post_desc([(v.h, v.w) for v in logits], logits[0].n, strides, anchors, num_classes, score_thresh, nms_thresh, detections_per_img,
+                               cand_cap, rescale, logits=logits)
         self._record(self.lib.ymi_plan_add_postprocess(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0,
-                     bytes=float(sum(v.n * v.h * v.w * 3 * (num_classes + 5) * 4 for v in logits)), shape=f"A={total_anchors}")
+                     bytes=float(sum(v.n * v.h * v.w * 3 * (num_classes + 5) * 4 for v in logits)), shape=f"A={pb.total_anchors}")
         return pb
+
+    # fused head: post_begin -> head_decode per level -> post_finish (the logits never reach memory)
+    def post_begin(self, d: PostDesc) -> None:
+        self._record(self.lib.ymi_plan_add_post_begin(self.handle, C.byref(d)), "post_begin", kind="post", flops=0.0, bytes=0.0, shape="counters")
+
+    def head_decode(self, x: View, pc: PackedConv, d: PostDesc, level: int, name: str = "head") -> None:
+        if x.c != pc.cin:
+            raise YmiError(f"{name}: input view has {x.c} channels, packed weights expect {pc.cin}")
+        if x.tail < 0:
+            raise YmiError(f"{name}: the fused head needs a plan-allocated input (zero tail)")
+        cd = self.conv_desc(x, pc, (1, 1), (0, 0), ACT_NONE, x, None)   # y is ignored by the fused head
+        cd.y = None
+        cd.y_cstride, cd.out_dtype = 0, dtype_code(torch.float32)
+        k_real = int(d.num_classes) + 5
+        self._record(self.lib.ymi_plan_add_head_decode(self.handle, C.byref(cd), C.byref(d), level), name, kind="conv",
+                     flops=2.0 * x.n * x.h * x.w * 3 * k_real * pc.k_real,
+                     bytes=float(x.n * x.h * x.w * x.c * 2 + 3 * k_real * pc.k * 2 + x.n * x.h * x.w * 3 * 16),
+                     ref_convs=1, tile=0, shape=f"{x.c}->{3 * k_real} k1x1 s1 {x.h}x{x.w} +decode")
+
+    def post_finish(self, d: PostDesc, total_anchors: int) -> None:
+        self._record(self.lib.ymi_plan_add_post_finish(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0, bytes=0.0, shape=f"A={total_anchors}")
 
     # ---- execution ----
     @property

@@ -50,6 +50,37 @@ class YOLOHead(HipModule):
         self._packed[key] = (sig, pc)
         return pc
 
+    def can_fuse_decode(self, plan: Plan, x: Sequence[View]) -> bool:
+        """the fused head needs <= 128 outputs per anchor, 3 anchors, 32-aligned input channels and the pipelined kernels"""
+        return (self.num_anchors == 3 and self.num_outputs <= 128 and not plan.use_v1 and all(f.c % 32 == 0 and f.tail >= 0 and f.h * f.w >= 1 for f in x))
+
+    def packed_anchor_major(self, i: int, dtype, device, cin_view: int) -> PackedConv:
+        """head weights for ymi_conv_head_decode: anchor q's K rows at q*RA .. q*RA+K-1, RA = round_up(K, 32), rest zero"""
+        m = self.head[i]
+        sig = (m.weight._version, m.bias._version, m.weight.data_ptr())
+        key = ("fused", i, dtype, device, cin_view)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        k = self.num_outputs
+        ra = (k + 31) // 32 * 32
+        w = m.weight.detach()
+        wp = torch.zeros(3 * ra, w.shape[1], 1, 1, dtype=w.dtype, device=w.device)
+        bp = torch.zeros(3 * ra, dtype=m.bias.dtype, device=w.device)
+        for q in range(3):
+            wp[q * ra: q * ra + k] = w[q * k: (q + 1) * k]
+            bp[q * ra: q * ra + k] = m.bias.detach()[q * k: (q + 1) * k]
+        pc = PackedConv(wp, bp, None, dtype, device, cin_pad=cin_view)
+        pc.k_real = w.shape[1]
+        self._packed[key] = (sig, pc)
+        return pc
+
+    def emit_fused(self, plan: Plan, x: Sequence[View], post_desc) -> None:
+        """head conv + decode + threshold in one kernel per level (csrc/head_decode.hpp); nothing is returned: boxes and
+        candidate records land in the post-process workspace of `post_desc`"""
+        for i, f in enumerate(x):
+            plan.head_decode(f, self.packed_anchor_major(i, plan.dtype, plan.device, f.c), post_desc, i, name=f"head.{i}")
+
     def emit(self, plan: Plan, x: Sequence[View], out=None) -> List[View]:
         """returns fp32 logits views (N,H,W,A*K) with channel a*K + k"""
         outs = []

@@ -110,6 +110,9 @@ class YOLO(nn.Module):
         self._entries: Dict[Tuple, _PlanEntry] = {}
         self._ring: Dict[Tuple, List[_PlanEntry]] = {}
         self._ring_pos = 0
+        # decode + threshold inside the head convolution's epilogue (the fp32 logits never reach memory); False keeps the
+        # logits as plan buffers (`entry.logits`) and decodes them in the post-process op -- identical detections
+        self.fuse_head_decode = os.environ.get("YOLORT_AMD_FUSED_HEAD", "1") != "0"
         self.pipeline_depth = 4   # plan instances per shape: later batches run while batch i is post-processed / collected
         self._has_warned = False
         # measurement hook (bench.py): (n_ops, starts, ends) -> HIP events around ops [0, n_ops) of every run
@@ -123,7 +126,7 @@ class YOLO(nn.Module):
         cdt = compute_dtype_of(self)
         pp = self.post_process
         post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
-        key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image)
+        key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode)
         ring = self._ring.get(key)
         if ring is not None:
             self._ring_pos = (self._ring_pos + 1) % len(ring)
@@ -147,11 +150,18 @@ class YOLO(nn.Module):
         n_backbone = plan.num_ops
         logits = post = rescale = None
         if self.fused():
-            logits = self.head.emit(plan, feats)
             rescale = torch.zeros(n, 3, device=device, dtype=torch.float32)
             ag = self.anchor_generator
-            post = plan.postprocess(logits, [float(s) for s in ag.strides], ag.anchor_grids, self.num_classes, float(pp.score_thresh), float(pp.nms_thresh),
-                                    int(pp.detections_per_img), self.cand_cap_per_image * n, rescale=rescale)
+            strides = [float(s) for s in ag.strides]
+            args = (self.num_classes, float(pp.score_thresh), float(pp.nms_thresh), int(pp.detections_per_img), self.cand_cap_per_image * n)
+            if self.fuse_head_decode and self.head.can_fuse_decode(plan, feats):
+                post, pd = plan.post_desc([(f.h, f.w) for f in feats], n, strides, ag.anchor_grids, *args, rescale=rescale)
+                plan.post_begin(pd)
+                self.head.emit_fused(plan, feats, pd)
+                plan.post_finish(pd, post.total_anchors)
+            else:
+                logits = self.head.emit(plan, feats)
+                post = plan.postprocess(logits, strides, ag.anchor_grids, *args, rescale=rescale)
         return _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
 
     def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> PendingDetections:

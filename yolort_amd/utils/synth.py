@@ -63,10 +63,14 @@ def synth_state_dict(
             v = np.ones(shape, np.float32)
         elif ".head." in key and key.endswith(".weight"):
             v = rng.standard_normal(shape, dtype=np.float32) * (head_gain / np.sqrt(shape[1]))
+            if shape[0] % num_outputs:   # a head with another class count: three anchors per level
+                num_outputs = shape[0] // 3
             v = v.reshape(shape[0] // num_outputs, num_outputs, *shape[1:])
             v[:, :4] *= 0.25  # box regressors: small logits -> sigmoid near 0.5 -> anchor-sized boxes
             v = _fp16_round(v.reshape(shape))
         elif ".head." in key and key.endswith(".bias"):
+            if shape[0] % num_outputs:
+                num_outputs = shape[0] // 3
             b = np.zeros((shape[0] // num_outputs, num_outputs), np.float32)
             b[:, 4] = obj_bias
             b[:, 5:] = cls_bias
