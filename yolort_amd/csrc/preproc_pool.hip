@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const LetterboxArgs a) {
 // the bilinear weights are exactly (1,0), so the result equals the source pixel bit for bit and the
 // kernel degenerates into a planar-CHW -> NHWC4 interleave.  Four pixels per thread: one 8-byte load
 // per plane (16-bit inputs), one 32-byte store.
-template <int IDT, int ODT>
+template <int IDT, int ODT, int PX>   // PX = 4 or 8 pixels per thread
 __global__ __launch_bounds__(256) void letterbox_copy_kernel(const LetterboxArgs a) {
-    const int wq = a.wb / 4;
+    const int wq = a.wb / PX;
     const int64_t total = (int64_t)a.n * a.hb * wq;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
@@ -95,24 +95,33 @@ __global__ __launch_bounds__(256) void letterbox_copy_kernel(const LetterboxArgs
     const int img = (int)(t / a.hb);
     const int hin = a.geom[img][0], win = a.geom[img][1];
     const int yy = y - a.geom[img][4];
-    const int x0 = xq * 4 - a.geom[img][5];
-    float v[4][3];
+    const int x0 = xq * PX - a.geom[img][5];
+    float v[PX][3];
     const bool row_in = (unsigned)yy < (unsigned)hin;
-    const bool all_in = row_in && x0 >= 0 && x0 + 3 < win && (win % 4 == 0) && (a.geom[img][5] % 4 == 0);
+    const bool all_in = row_in && x0 >= 0 && x0 + PX - 1 < win && (win % PX == 0) && (a.geom[img][5] % PX == 0);
+    const int64_t plane = (int64_t)hin * win;
     if (all_in && (IDT == YMI_F16 || IDT == YMI_BF16)) {
-        const int64_t plane = (int64_t)hin * win;
+        constexpr int SDT = IDT == YMI_BF16 ? YMI_BF16 : YMI_F16;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const u32x2 p = *reinterpret_cast<const u32x2*>((const uint16_t*)a.img[img] + c * plane + (int64_t)yy * win + x0);
-            v[0][c] = from16<IDT == YMI_BF16 ? YMI_BF16 : YMI_F16>((uint16_t)(p[0] & 0xffff));
-            v[1][c] = from16<IDT == YMI_BF16 ? YMI_BF16 : YMI_F16>((uint16_t)(p[0] >> 16));
-            v[2][c] = from16<IDT == YMI_BF16 ? YMI_BF16 : YMI_F16>((uint16_t)(p[1] & 0xffff));
-            v[3][c] = from16<IDT == YMI_BF16 ? YMI_BF16 : YMI_F16>((uint16_t)(p[1] >> 16));
+            const uint16_t* src = (const uint16_t*)a.img[img] + c * plane + (int64_t)yy * win + x0;
+            uint32_t w[PX / 2];
+            if constexpr (PX == 8) {
+                const u32x4 p = *reinterpret_cast<const u32x4*>(src);
+                w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
+            } else {
+                const u32x2 p = *reinterpret_cast<const u32x2*>(src);
+                w[0] = p[0]; w[1] = p[1];
+            }
+#pragma unroll
+            for (int i = 0; i < PX / 2; ++i) {
+                v[2 * i][c] = from16<SDT>((uint16_t)(w[i] & 0xffff));
+                v[2 * i + 1][c] = from16<SDT>((uint16_t)(w[i] >> 16));
+            }
         }
     } else {
-        const int64_t plane = (int64_t)hin * win;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PX; ++i) {
             const int xx = x0 + i;
             const bool in = row_in && (unsigned)xx < (unsigned)win;
 #pragma unroll
@@ -120,22 +129,23 @@ __global__ __launch_bounds__(256) void letterbox_copy_kernel(const LetterboxArgs
         }
     }
     if constexpr (ODT == YMI_F32) {
-        float* o = (float*)a.out + (((int64_t)img * a.hb + y) * a.wb + xq * 4) * 4;
+        float* o = (float*)a.out + (((int64_t)img * a.hb + y) * a.wb + xq * PX) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { o[4 * i] = v[i][0]; o[4 * i + 1] = v[i][1]; o[4 * i + 2] = v[i][2]; o[4 * i + 3] = 0.f; }
+        for (int i = 0; i < PX; ++i) {
+            f32x4 q = {v[i][0], v[i][1], v[i][2], 0.f};
+            *reinterpret_cast<f32x4*>(o + 4 * i) = q;
+        }
     } else {
-        uint16_t* o = (uint16_t*)a.out + (((int64_t)img * a.hb + y) * a.wb + xq * 4) * 4;
-        u32x4 lo, hi;
-        lo[0] = (uint32_t)to16<ODT>(v[0][0]) | ((uint32_t)to16<ODT>(v[0][1]) << 16);
-        lo[1] = (uint32_t)to16<ODT>(v[0][2]);
-        lo[2] = (uint32_t)to16<ODT>(v[1][0]) | ((uint32_t)to16<ODT>(v[1][1]) << 16);
-        lo[3] = (uint32_t)to16<ODT>(v[1][2]);
-        hi[0] = (uint32_t)to16<ODT>(v[2][0]) | ((uint32_t)to16<ODT>(v[2][1]) << 16);
-        hi[1] = (uint32_t)to16<ODT>(v[2][2]);
-        hi[2] = (uint32_t)to16<ODT>(v[3][0]) | ((uint32_t)to16<ODT>(v[3][1]) << 16);
-        hi[3] = (uint32_t)to16<ODT>(v[3][2]);
-        *reinterpret_cast<u32x4*>(o) = lo;
-        *reinterpret_cast<u32x4*>(o + 8) = hi;
+        uint16_t* o = (uint16_t*)a.out + (((int64_t)img * a.hb + y) * a.wb + xq * PX) * 4;
+#pragma unroll
+        for (int i = 0; i < PX; i += 2) {   // two pixels (RGB0 RGB0) per 16-byte store
+            u32x4 q;
+            q[0] = (uint32_t)to16<ODT>(v[i][0]) | ((uint32_t)to16<ODT>(v[i][1]) << 16);
+            q[1] = (uint32_t)to16<ODT>(v[i][2]);
+            q[2] = (uint32_t)to16<ODT>(v[i + 1][0]) | ((uint32_t)to16<ODT>(v[i + 1][1]) << 16);
+            q[3] = (uint32_t)to16<ODT>(v[i + 1][2]);
+            *reinterpret_cast<u32x4*>(o + 8 * (i / 2)) = q;
+        }
     }
 }
 
@@ -144,14 +154,19 @@ static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t
     bool identity = a.c_out == 4 && a.wb % 4 == 0;
     for (int i = 0; i < a.n && identity; ++i) identity = a.geom[i][0] == a.geom[i][2] && a.geom[i][1] == a.geom[i][3];
     if (identity) {   // no resampling anywhere in this launch: interleave-copy kernel (bit-identical results)
-        const int64_t tq = (int64_t)a.n * a.hb * (a.wb / 4);
+        const int px = a.wb % 8 == 0 ? 8 : 4;
+        const int64_t tq = (int64_t)a.n * a.hb * (a.wb / px);
         dim3 gq((unsigned)((tq + 255) / 256)), bq(256);
+#define YMI_LBC(ODT_)                                                                             \
+    if (px == 8) hipLaunchKernelGGL((letterbox_copy_kernel<IDT, ODT_, 8>), gq, bq, 0, s, a);      \
+    else hipLaunchKernelGGL((letterbox_copy_kernel<IDT, ODT_, 4>), gq, bq, 0, s, a);
         switch (out_dtype) {
-            case YMI_F16: hipLaunchKernelGGL((letterbox_copy_kernel<IDT, YMI_F16>), gq, bq, 0, s, a); break;
-            case YMI_BF16: hipLaunchKernelGGL((letterbox_copy_kernel<IDT, YMI_BF16>), gq, bq, 0, s, a); break;
-            case YMI_F32: hipLaunchKernelGGL((letterbox_copy_kernel<IDT, YMI_F32>), gq, bq, 0, s, a); break;
+            case YMI_F16: YMI_LBC(YMI_F16) break;
+            case YMI_BF16: YMI_LBC(YMI_BF16) break;
+            case YMI_F32: YMI_LBC(YMI_F32) break;
             default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
         }
+#undef YMI_LBC
         return check_launch("letterbox_copy_kernel");
     }
     const int64_t total = (int64_t)a.n * a.hb * a.wb;
@@ -248,61 +263,77 @@ __global__ __launch_bounds__(256) void spp_pool_kernel(uint16_t* buf, int n, int
     *reinterpret_cast<u32x4*>(o + 3 * c) = o13;
 }
 
-// LDS cascade form of the same pyramid: one block per (image, 8-channel chunk).  The h x w plane of
-// those 8 channels is staged in LDS as fp32 and three 5x5 max stages are applied back to back, each
-// separable (row pass then column pass): mp9 = mp5(mp5(x)), mp13 = mp5(mp9) -- the SPPF identity of
-// the reference (common.py:196), exact because max is exact.  10 taps per stage instead of a
-// 169-tap window, and the plane is read from HBM once.
+// LDS cascade form of the same pyramid: one block per (image, CPB-channel chunk), CPB = 32 (8 when c % 32 != 0).
+// The h x w plane of those channels is staged in LDS in its storage type and three 5x5 max stages are applied back to
+// back, each separable (row pass then column pass): mp9 = mp5(mp5(x)), mp13 = mp5(mp9) -- the SPPF identity of the
+// reference (common.py:196), exact because max is exact (also in fp16 / bf16: no arithmetic, only selection).
+// 10 taps per stage instead of a 169-tap window, the plane is read from HBM once, and with CPB = 32 every pixel
+// moves as one 64-byte run (the 8-channel form touched 16 bytes of each 2 KiB pixel row per block).
 template <int DT>
-__global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h, int w, int c, int cs) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hw = h * w;
-    float* A = sm;
-    float* B = sm + (size_t)hw * 8;
-    float* Cb = sm + (size_t)hw * 16;
-    const int c8 = c / 8;
-    const int img = blockIdx.x / c8, cc = (blockIdx.x % c8) * 8;
-    uint16_t* base = buf + (int64_t)img * hw * cs + cc;
-    for (int p = threadIdx.x; p < hw; p += 256) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)p * cs);
+__device__ __forceinline__ u32x4 max8(const u32x4& p, const u32x4& q) {
+    u32x4 r;
+    if constexpr (DT == YMI_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) A[p * 8 + e] = from16<DT>((uint16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t pe = p[e], qe = q[e];
+            h2 x, y;
+            __builtin_memcpy(&x, &pe, 4);
+            __builtin_memcpy(&y, &qe, 4);
+            const h2 m = __builtin_elementwise_max(x, y);   // v_pk_max_f16
+            uint32_t me;
+            __builtin_memcpy(&me, &m, 4);
+            r[e] = me;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = bf2f((uint16_t)(p[e] & 0xffff)), a1 = bf2f((uint16_t)(p[e] >> 16));
+            const float b0 = bf2f((uint16_t)(q[e] & 0xffff)), b1 = bf2f((uint16_t)(q[e] >> 16));
+            const uint32_t lo = fmaxf(a0, b0) == a0 ? (p[e] & 0xffff) : (q[e] & 0xffff);
+            const uint32_t hi = fmaxf(a1, b1) == a1 ? (p[e] >> 16) : (q[e] >> 16);
+            r[e] = lo | (hi << 16);
+        }
     }
+    return r;
+}
+
+template <int DT, int G>   // G = 16-byte groups (8 channels) per pixel handled by one block
+__global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h, int w, int c, int cs) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 spp_sm[];
+    const int hw = h * w;
+    u32x4* A = spp_sm;                 // [hw][G]
+    u32x4* B = spp_sm + (size_t)hw * G;
+    u32x4* Cb = spp_sm + (size_t)hw * G * 2;
+    const int cg = c / (8 * G);
+    const int img = blockIdx.x / cg, cc = (blockIdx.x % cg) * 8 * G;
+    uint16_t* base = buf + (int64_t)img * hw * cs + cc;
+    const int sub = threadIdx.x % G;              // channel group of this thread
+    const int p0 = threadIdx.x / G;               // first pixel
+    constexpr int PSTEP = 256 / G;
+    for (int p = p0; p < hw; p += PSTEP) A[p * G + sub] = *reinterpret_cast<const u32x4*>(base + (int64_t)p * cs + sub * 8);
     __syncthreads();
-    float* src = A;
-    float* dst = Cb;
+    u32x4* src = A;
+    u32x4* dst = Cb;
     for (int stage = 0; stage < 3; ++stage) {
-        for (int p = threadIdx.x; p < hw; p += 256) {  // row pass: src -> B
+        for (int p = p0; p < hw; p += PSTEP) {   // row pass: src -> B
             const int y = p / w, x = p - y * w;
             const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 > w - 1 ? w - 1 : x + 2;
-            float m[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-            for (int xx = x0; xx <= x1; ++xx)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], src[(y * w + xx) * 8 + e]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) B[p * 8 + e] = m[e];
+            u32x4 m = src[(y * w + x0) * G + sub];
+            for (int xx = x0 + 1; xx <= x1; ++xx) m = max8<DT>(m, src[(y * w + xx) * G + sub]);
+            B[p * G + sub] = m;
         }
         __syncthreads();
-        for (int p = threadIdx.x; p < hw; p += 256) {  // column pass: B -> dst, and out to HBM
+        for (int p = p0; p < hw; p += PSTEP) {   // column pass: B -> dst, and out to HBM
             const int y = p / w, x = p - y * w;
             const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 > h - 1 ? h - 1 : y + 2;
-            float m[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-            for (int yy = y0; yy <= y1; ++yy)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], B[(yy * w + x) * 8 + e]);
-            u32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (uint32_t)to16<DT>(m[2 * e]) | ((uint32_t)to16<DT>(m[2 * e + 1]) << 16);
-            *reinterpret_cast<u32x4*>(base + (int64_t)p * cs + (stage + 1) * c) = o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dst[p * 8 + e] = m[e];
+            u32x4 m = B[(y0 * w + x) * G + sub];
+            for (int yy = y0 + 1; yy <= y1; ++yy) m = max8<DT>(m, B[(yy * w + x) * G + sub]);
+            *reinterpret_cast<u32x4*>(base + (int64_t)p * cs + (stage + 1) * c + sub * 8) = m;
+            dst[p * G + sub] = m;
         }
         __syncthreads();
-        float* t = src;  // ping-pong A <-> Cb (B is the row-pass scratch)
+        u32x4* t = src;  // ping-pong A <-> Cb (B is the row-pass scratch)
         src = dst;
         dst = t;
     }
@@ -418,17 +449,17 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
     const int64_t total = (int64_t)n * h * w * (c / 8);
     if (total == 0) return YMI_OK;
     YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_spp_pool: dtype must be F16/BF16");
-    const size_t lds = (size_t)h * w * 8 * 4 * 3;
-    if (lds <= 160 * 1024 - 512) {  // whole plane of 8 channels fits the 160 KB LDS three times
-        dim3 g((unsigned)(n * (c / 8))), b(256);
-        if (dtype == YMI_F16) {
-            if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)spp_pool_lds_kernel<YMI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((spp_pool_lds_kernel<YMI_F16>), g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
-        } else {
-            if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)spp_pool_lds_kernel<YMI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((spp_pool_lds_kernel<YMI_BF16>), g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
-        }
-        return check_launch("spp_pool_lds_kernel");
+    const int G = (c % 32 == 0) ? 4 : 1;
+    const size_t lds = (size_t)h * w * G * 16 * 3;
+    if (lds <= 160 * 1024 - 512) {  // the plane of 8*G channels fits the 160 KB LDS three times
+        dim3 g((unsigned)(n * (c / (8 * G)))), b(256);
+        auto launch = [&](auto kfn) -> int {
+            if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kfn, g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
+            return check_launch("spp_pool_lds_kernel");
+        };
+        if (dtype == YMI_F16) return G == 4 ? launch(spp_pool_lds_kernel<YMI_F16, 4>) : launch(spp_pool_lds_kernel<YMI_F16, 1>);
+        return G == 4 ? launch(spp_pool_lds_kernel<YMI_BF16, 4>) : launch(spp_pool_lds_kernel<YMI_BF16, 1>);
     }
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (dtype == YMI_F16) hipLaunchKernelGGL((spp_pool_kernel<YMI_F16>), grid, block, 0, (hipStream_t)stream, (uint16_t*)buf, n, h, w, c, cstride);
