@@ -104,7 +104,7 @@ def test_conv_tiles(dev, tile):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=37, w=29, k=1, s=1, p=0, tile=tile, residual=True)
 
 
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 71, 72, 73, 74, 75, 76, 77])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77])
 def test_conv_software_pipelined_tiles(dev, tile):
     """v2 tiles with the software-pipelined main loop (fragment double-buffering, DMA issue between MFMAs):
     short K (1..2 steps, fewer than the ring depth), long K (3x3, 3x3 stride 2), residual, views, ragged M / cout"""

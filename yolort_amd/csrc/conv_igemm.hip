@@ -527,7 +527,7 @@ struct StoreEpilogue {
 };
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
-__global__ __launch_bounds__(256) void conv_igemm_v2_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs a) {   // >= 2 waves per SIMD: <= 256 VGPR + AGPR
     conv_igemm_v2_body<DT, ODT, BM, BN, WM, WN, STAGES, IS1X1, UTAP, PIPE>(a, StoreEpilogue<DT, ODT>{a});
 }
 
@@ -637,6 +637,10 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         case 63: return launch_v2<DT, ODT, 256, 32, 64, 32, 3, true>(a, is1x1, s);
         case 64: return launch_v2<DT, ODT, 64, 128, 32, 64, 4, true>(a, is1x1, s);
         case 65: return launch_v2<DT, ODT, 128, 64, 64, 32, 4, true>(a, is1x1, s);
+        case 66: return launch_v2<DT, ODT, 256, 128, 128, 64, 3, true>(a, is1x1, s);   // 256-pixel tiles: fewer DMA pieces per MFMA
+        case 68: return launch_v2<DT, ODT, 256, 128, 128, 64, 2, true>(a, is1x1, s);
+        case 69: return launch_v2<DT, ODT, 128, 128, 64, 64, 3, true>(a, is1x1, s);    // 48 KB LDS: 3 blocks / CU
+        case 70: return launch_v2<DT, ODT, 128, 64, 64, 32, 3, true>(a, is1x1, s);
         case 71: return launch_v2<DT, ODT, 128, 128, 64, 64, 2, true>(a, is1x1, s);
         case 72: return launch_v2<DT, ODT, 256, 64, 64, 64, 2, true>(a, is1x1, s);
         case 73: return launch_v2<DT, ODT, 256, 32, 64, 32, 2, true>(a, is1x1, s);

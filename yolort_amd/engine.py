@@ -254,6 +254,7 @@ class Plan:
             cands = [12, 15, 22, 25, 23, 26, 27]
         if d.cin % 32 == 0 and d.kh * d.kw <= 32:
             cands = cands + [t + 50 for t in cands]   # the same tiles with the software-pipelined main loop (61..65, 71..77)
+            cands = cands + ([69, 70] if d.cout_pad > 32 else []) + ([66, 68] if d.cout_pad >= 128 else [])   # 3-stage / 256-pixel tiles
         if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin % 32 == 0 and d.cout_split == 0 and d.k_pad == 9 * d.cin:
             # LDS-halo kernel variants (activation patch resident in LDS across the nine taps)
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
