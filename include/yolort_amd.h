@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 1
+#define YMI_ABI_VERSION 2
 
 /* error codes */
 #define YMI_OK 0
@@ -166,7 +166,18 @@ typedef struct ymi_post_desc {
     void* ws;
     int64_t ws_bytes;
     int32_t cand_cap;
+    int32_t flags; /* YMI_POST_* bits */
 } ymi_post_desc;
+
+/* ymi_post_desc.flags.
+ * By default an image with many candidates is post-processed on a score-ordered PREFIX of them (at least
+ * max(4096, 4 * detections_per_img) records): greedy NMS decisions depend only on higher-scored boxes, so once
+ * the prefix alone yields detections_per_img kept boxes the result equals the full computation exactly.  If a
+ * truncated image ends with fewer kept boxes, bit 1 of status[1] is set and the caller re-runs the batch with
+ * YMI_POST_EXACT_FULL (the Python host does this transparently). */
+#define YMI_POST_EXACT_FULL 1
+#define YMI_STATUS_OVERFLOW_CAPACITY 1 /* status[1] bit 0: candidate capacity exceeded (grow cand_cap) */
+#define YMI_STATUS_PREFIX_SHORT 2      /* status[1] bit 1: prefix too short, re-run with YMI_POST_EXACT_FULL */
 
 int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_cap);
 int ymi_postprocess(const ymi_post_desc* d, void* stream);

@@ -171,6 +171,32 @@ def test_fused_head_decode_equals_unfused(dev, arch, num_classes, dtype):
     assert sum(len(d["scores"]) for d in outs[0]) > 0
 
 
+@pytest.mark.parametrize("k_det", [300, 1500])
+def test_score_prefix_selection_is_exact(dev, k_det):
+    """Crowded images are post-processed on a score-ordered prefix of their candidates (include/yolort_amd.h,
+    YMI_POST_EXACT_FULL): the detections must equal the full computation bit for bit, both when the prefix suffices
+    and when it falls short and the host transparently re-runs the batch on the full set (tests/test_ops_gpu.py forces
+    that case deterministically)."""
+    from yolort_amd.utils.synth import synth_images
+    outs, ncand = [], []
+    x = torch.stack([im for im in synth_images(2, 640, 640, seed=9)]).to(dev).half()
+    for exact in (False, True):
+        m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, score_thresh=0.02, nms_thresh=0.45, detections_per_img=k_det)
+        m.model.post_exact_full = exact
+        outs.append(m.model(x))
+        e = next(iter(m.model._entries.values()))
+        ncand.append(int(e.post.status[0].item()))
+        if not exact:
+            redone = m.model.post_exact_full   # True: the prefix fell short and the host re-ran the batch on the full set
+    print("records processed: prefix", ncand[0], "full", ncand[1], "fallback taken:", redone)
+    assert ncand[1] > 2 * 6144, "the test needs crowded images"
+    if not redone:
+        assert ncand[0] < ncand[1], "the prefix selection did not cut anything"
+    for a, b in zip(*outs):
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), f"prefix / full post-process disagree on {k}"
+
+
 def test_mixed_sizes_and_yolo_forward(dev):
     """dynamic-shape letterbox batch + YOLO.forward on a pre-batched tensor (no rescale)."""
     from oracle import yolov5_oracle as O

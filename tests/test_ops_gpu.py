@@ -325,6 +325,39 @@ def test_postprocess_vs_oracle(dev):
             np.testing.assert_allclose(d["boxes"].cpu().numpy(), r["boxes"].numpy(), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("aw,expect_short", [(30.0, False), (400.0, True)])
+def test_postprocess_score_prefix_vs_oracle(dev, aw, expect_short):
+    """A crowded image (> 6144 candidates) is cut to a score-ordered prefix before sort / NMS.  Small anchors: the
+    prefix alone yields 300 survivors and the result must equal the oracle's full computation.  Huge anchors: nearly
+    everything is suppressed, the prefix falls short (YMI_STATUS_PREFIX_SHORT) and the exact full pass must follow."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd import _lib
+    from yolort_amd.engine import Plan, View
+    from yolort_amd.ops import postprocess_logits
+    g = torch.Generator().manual_seed(31)
+    nc = 4
+    heads = [torch.randn(2, 3, 48, 48, nc + 5, generator=g)]
+    heads[0][..., :4] *= 0.05                      # boxes ~ anchor sized, centred on their cells
+    heads[0][1] -= 6.0                             # second image: almost nothing passes
+    heads[0][0, ..., 4:] += 3.0                    # first image: nearly every (anchor, class) pair passes
+    strides, anchors = [8], [[aw, aw, 1.1 * aw, 0.9 * aw, 0.9 * aw, 1.1 * aw]]
+    ref = O.postprocess(O.decode(heads, strides, anchors), 0.3, 0.45, 300)
+    got = postprocess_logits([h.to(dev) for h in heads], strides, anchors, nc, 0.3, 0.45, 300, cand_cap=2 * 32768)
+    for r, d in zip(ref, got):
+        np.testing.assert_array_equal(d["labels"].cpu().numpy(), r["labels"].numpy())
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), r["scores"].numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(d["boxes"].cpu().numpy(), r["boxes"].numpy(), rtol=1e-5, atol=1e-3)
+    # the raw status of a single default pass shows which way it went
+    t = torch.zeros(2, 48, 48, 28, device=dev)
+    t[..., :27] = heads[0].to(dev).permute(0, 2, 3, 1, 4).reshape(2, 48, 48, 27)
+    plan = Plan(dev, torch.float16)
+    pb = plan.postprocess([View(t.view(-1), 0, 2, 48, 48, 27, 28)], strides, anchors, nc, 0.3, 0.45, 300, 2 * 32768)
+    plan.run()
+    st = pb.status.cpu().tolist()
+    assert st[0] < 3 * 48 * 48 * nc, "the first image should have been cut to a prefix"
+    assert bool(st[1] & 2) == expect_short and not st[1] & 1
+
+
 def test_postprocess_overflow_is_reported_and_recovered(dev):
     from oracle import yolov5_oracle as O
     from yolort_amd.ops import postprocess_logits

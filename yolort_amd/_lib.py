@@ -38,6 +38,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 2   # include/yolort_amd.h YMI_ABI_VERSION
+POST_EXACT_FULL = 1
+
+
 class PostDesc(C.Structure):
     _fields_ = [
         ("logits", C.c_void_p * MAX_LEVELS),
@@ -52,6 +56,7 @@ class PostDesc(C.Structure):
         ("status", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("cand_cap", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -108,8 +113,8 @@ def load(require_gpu: bool = False) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.ymi_abi_version() != 1:
-            raise YmiError(f"ABI version mismatch: library reports {lib.ymi_abi_version()}, binding expects 1")
+        if lib.ymi_abi_version() != ABI_VERSION:
+            raise YmiError(f"ABI version mismatch: library reports {lib.ymi_abi_version()}, binding expects {ABI_VERSION}")
         _lib = lib
     if require_gpu:
         if not torch.cuda.is_available():

@@ -22,7 +22,7 @@ constexpr int HPIX = 192;                    // patch pixels per LDS buffer (180
 constexpr int HBM = HTH * HTW;               // 128 output pixels per block
 
 template <int DT, int ODT, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     static_assert((HBM / WM) * (BN / WN) == 4, "4 waves per block");
     static_assert(STAGES == 2 || STAGES == 3, "weight ring depth");
     constexpr int TM = WM / 32, TN = WN / 32;

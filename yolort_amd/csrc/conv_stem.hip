@@ -17,7 +17,7 @@ constexpr int SPH = 2 * STH + 4, SPW = STW + 2;  // input patch: 20 rows x 34 su
 constexpr int SPIECES = 11;                      // ceil(20*34 / 64) DMA pieces of 64 super-pixels (1 KiB)
 
 template <int DT, int ODT, int TN>
-__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     typedef typename Mfma<DT>::frag frag;
     __shared__ __attribute__((aligned(16))) uint16_t patch[12 * 512];   // 12 KiB (680 super-pixels used)
 

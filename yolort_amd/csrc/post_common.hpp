@@ -21,6 +21,7 @@ struct Workspace {
     int* img_count;       // (n) candidates appended per image (per-image sort path)
     uint64_t* p_hi;       // per-class order P of the per-image sort path (cand_cap each)
     uint32_t* p_lo;
+    int* sel_count;       // (2n) per-image sort path: records kept by the score-prefix selection, then [n..2n) truncated flags
     int64_t total;
 };
 
@@ -46,6 +47,7 @@ inline Workspace carve(void* ws, int n, int total_anchors, int cand_cap) {
     w.img_count = (int*)take((int64_t)(n > 0 ? n : 1) * 4);
     w.p_hi = (uint64_t*)take((int64_t)cand_cap * 8);
     w.p_lo = (uint32_t*)take((int64_t)cand_cap * 4);
+    w.sel_count = (int*)take((int64_t)(n > 0 ? n : 1) * 8);
     w.total = off;
     return w;
 }

@@ -349,20 +349,108 @@ __device__ void sort_runs(uint64_t* keys, int n, uint64_t* lds_key, int lds_keys
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void sort_image_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, int cap_img, int n_img,
+// Score-prefix selection (per-image path).  Greedy NMS decides each box from higher-scored boxes only, and the
+// output keeps the K best survivors: if a score-ordered prefix of an image's candidates already yields K survivors,
+// candidates behind it cannot change the result.  For an image with more than 1.5 * sel_t records this kernel keeps
+// the records of the best linear score bins (1/4096 wide) that together hold >= sel_t records, compacts them to the
+// front of the image's region and flags the image as truncated; gather_topk_kernel raises YMI_STATUS_PREFIX_SHORT
+// if such an image ends with fewer than K survivors (the host then re-runs with YMI_POST_EXACT_FULL).
+constexpr int SEL_BINS = 4096;
+
+__device__ __forceinline__ int score_bin(uint64_t hi) {
+    const float s = __uint_as_float(~(uint32_t)hi);
+    const int b = (int)((1.0f - s) * (float)SEL_BINS);
+    return b < 0 ? 0 : (b >= SEL_BINS ? SEL_BINS - 1 : b);
+}
+
+__global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, int cap_img, int n_img, int sel_t,
+                                                             int* sel_count) {
+    __shared__ int hist[SEL_BINS];
+    __shared__ int s_bstar, s_nsel, s_fill;
+    const int img = blockIdx.x;
+    const int raw = img_count[img];
+    const int n_i = raw < cap_img ? raw : cap_img;
+    if (sel_t <= 0 || n_i <= sel_t + sel_t / 2) {
+        if (threadIdx.x == 0) { sel_count[img] = n_i; sel_count[n_img + img] = 0; }
+        return;
+    }
+    uint64_t* hi = in_hi + (int64_t)img * cap_img;
+    uint32_t* lo = in_lo + (int64_t)img * cap_img;
+    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_i; i += blockDim.x) atomicAdd(&hist[score_bin(hi[i])], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {   // first wave: lane l owns bins [64 l, 64 l + 64)
+        const int lane = threadIdx.x;
+        int sum = 0;
+        for (int b = 0; b < 64; ++b) sum += hist[lane * 64 + b];
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        const int excl = incl - sum;
+        if (excl < sel_t && incl >= sel_t) {   // exactly one lane (n_i > sel_t)
+            int c = excl, b = lane * 64;
+            for (; b < lane * 64 + 64; ++b) {
+                c += hist[b];
+                if (c >= sel_t) break;
+            }
+            s_bstar = b;
+            s_nsel = c;
+        }
+        if (lane == 0) s_fill = 0;
+    }
+    __syncthreads();
+    const int bstar = s_bstar, nsel = s_nsel;
+    if (nsel >= n_i) {   // the best bins hold everything: nothing to cut
+        if (threadIdx.x == 0) { sel_count[img] = n_i; sel_count[n_img + img] = 0; }
+        return;
+    }
+    // in-place compaction: a chunk is read completely before any of its survivors is written, and survivors only move
+    // to positions at or before indices already read
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int c0 = 0; c0 < n_i; c0 += blockDim.x) {
+        const int i = c0 + threadIdx.x;
+        uint64_t h = 0;
+        uint32_t l = 0;
+        bool take = false;
+        if (i < n_i) {
+            h = hi[i];
+            l = lo[i];
+            take = score_bin(h) <= bstar;
+        }
+        __syncthreads();
+        const uint64_t m = __ballot(take);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_fill, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (take) {
+            const int pos = base + __popcll(m & lt);
+            hi[pos] = h;
+            lo[pos] = l;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sel_count[img] = nsel; sel_count[n_img + img] = 1; }
+}
+
+__global__ __launch_bounds__(1024) void sort_image_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, const int* sel_count, int cap_img, int n_img,
                                                           int label_bits, int lds_keys, uint64_t* ghi, uint32_t* glo, uint64_t* phi, uint32_t* plo,
                                                           uint8_t* keep, int* status) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_key[];
     __shared__ int s_off;
     const int img = blockIdx.x;
     const int raw = img_count[img];
-    const int n_i = raw < cap_img ? raw : cap_img;
+    const int n_i = sel_count[img];   // records that take part (== min(raw, cap_img) unless the prefix selection cut the image)
     if (threadIdx.x == 0) {
         int off = 0;
-        for (int j = 0; j < img; ++j) { const int c = img_count[j]; off += c < cap_img ? c : cap_img; }
+        for (int j = 0; j < img; ++j) off += sel_count[j];
         s_off = off;
         atomicAdd(&status[ST_NCAND], n_i);
-        if (raw > cap_img) { status[ST_OVERFLOW] = 1; atomicMax(&status[ST_RSV], raw); }
+        if (raw > cap_img) { atomicOr(&status[ST_OVERFLOW], YMI_STATUS_OVERFLOW_CAPACITY); atomicMax(&status[ST_RSV], raw); }
     }
     const int64_t base = (int64_t)img * cap_img;
     uint64_t* keys = in_hi + base;      // this image's region doubles as key scratch (u64 per record)
@@ -514,6 +602,8 @@ struct GatherArgs {
     const float* boxes_all;
     const float* rescale;
     const int* status;
+    const int* truncated;   // per image: 1 = only a score prefix of its candidates was processed (NULL: never)
+    int* status_rw;
     int cap, total_anchors, label_bits, K;
     float* out_boxes;
     float* out_scores;
@@ -574,7 +664,11 @@ __global__ __launch_bounds__(256) void gather_topk_kernel(const GatherArgs a) {
         if (threadIdx.x == 0) s_taken = taken + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.out_count[img] = s_taken < a.K ? s_taken : a.K;
+    if (threadIdx.x == 0) {
+        a.out_count[img] = s_taken < a.K ? s_taken : a.K;
+        // a truncated image must reach K survivors on its prefix alone, else the cut may have mattered
+        if (a.truncated != nullptr && a.truncated[img] != 0 && s_taken < a.K) atomicOr(&a.status_rw[ST_OVERFLOW], YMI_STATUS_PREFIX_SHORT);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -598,7 +692,8 @@ static int radix_pass(const Workspace& w, SortState& st, int* status, int cap, i
 
 // segments -> class-aware NMS -> top-k gather, given G (arrays w.hi/lo[g]) and the per-class order P
 static int nms_gather(const Workspace& w, int g, const uint64_t* phi, const uint32_t* plo, int* status, int cap, int n_img, int label_bits, int total_anchors,
-                      float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count, hipStream_t s) {
+                      float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count, hipStream_t s,
+                      const int* truncated = nullptr) {
     const int nthr_blocks = cdiv(cap, 256);
     uint32_t* seg_start = w.seg_start;
     float* kept_box = w.kept_box;
@@ -607,6 +702,7 @@ static int nms_gather(const Workspace& w, int g, const uint64_t* phi, const uint
                        seg_start, kept_box, w.keep, nms_thresh);
     GatherArgs ga;
     ga.ghi = w.hi[g]; ga.glo = w.lo[g]; ga.keep = w.keep; ga.boxes_all = w.boxes_all; ga.rescale = rescale; ga.status = status;
+    ga.truncated = truncated; ga.status_rw = status;
     ga.cap = cap; ga.total_anchors = total_anchors; ga.label_bits = label_bits; ga.K = K;
     ga.out_boxes = out_boxes; ga.out_scores = out_scores; ga.out_labels = out_labels; ga.out_count = out_count;
     hipLaunchKernelGGL(gather_topk_kernel, dim3(n_img), dim3(256), 0, s, ga);
@@ -715,15 +811,21 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
     if (rc != YMI_OK) return rc;
     if (L.per_image) {
         const int cap_img = L.cap_img;
-        const int lds_keys = cap_img < IMG_SORT_MAX ? cap_img : IMG_SORT_MAX;
+        const bool exact_full = (d->flags & YMI_POST_EXACT_FULL) != 0;
+        const int sel_t = exact_full ? 0 : (4 * d->detections_per_img > 4096 ? 4 * d->detections_per_img : 4096);
+        hipLaunchKernelGGL(select_prefix_kernel, dim3(d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, sel_t, w.sel_count);
+        // LDS run length of the sort: with the prefix selection images rarely exceed 8192 records (longer ones take the
+        // multi-run merge path), and 64 KiB instead of 128 leaves room for a convolution block on the same CU
+        const int run_max = exact_full ? IMG_SORT_MAX : IMG_SORT_MAX / 2;
+        const int lds_keys = cap_img < run_max ? cap_img : run_max;
         const size_t lds = (size_t)lds_keys * 8;
         if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)sort_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // the producers wrote arrays [0] (per-image regions); G goes to arrays [1] (compact), P to its own pair
-        hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, L.label_bits, lds_keys, w.hi[1], w.lo[1],
-                           w.p_hi, w.p_lo, w.keep, d->status);
-        if ((rc = check_launch("sort_image")) != YMI_OK) return rc;
+        hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, w.sel_count, cap_img, d->n, L.label_bits, lds_keys,
+                           w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);
+        if ((rc = check_launch("select_prefix/sort_image")) != YMI_OK) return rc;
         return nms_gather(w, 1, w.p_hi, w.p_lo, d->status, d->cand_cap, d->n, L.label_bits, L.total_anchors, d->nms_thresh, d->detections_per_img, d->rescale,
-                          d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);
+                          d->out_boxes, d->out_scores, d->out_labels, d->out_count, s, w.sel_count + d->n);
     }
     hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(64), 0, s, d->status, d->cand_cap);
     rc = check_launch("finalize_count");

@@ -305,7 +305,7 @@ class Plan:
 
     def post_desc(self, levels: Sequence[Tuple[int, int]], n: int, strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
                   score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None,
-                  logits: Optional[Sequence[View]] = None) -> Tuple["PostBuffers", PostDesc]:
+                  logits: Optional[Sequence[View]] = None, flags: int = 0) -> Tuple["PostBuffers", PostDesc]:
         """descriptor + output slab + workspace of one post-process; `levels` = [(h, w)] per pyramid level"""
         total_anchors = sum(3 * h * w for h, w in levels)
         pb = PostBuffers(self, n, detections_per_img, total_anchors, cand_cap, rescale)
@@ -326,15 +326,17 @@ class Plan:
         d.out_boxes, d.out_scores, d.out_labels, d.out_count = pb.boxes.data_ptr(), pb.scores.data_ptr(), pb.labels.data_ptr(), pb.count.data_ptr()
         d.status = pb.status.data_ptr()
         d.ws, d.ws_bytes, d.cand_cap = pb.ws.data_ptr(), pb.ws.numel(), cand_cap
+        d.flags = flags
         pb.total_anchors = total_anchors
         self.keep.extend([pb, d])
         return pb, d
 
     def postprocess(self, logits: Sequence[View], strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
-                    score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None) -> "PostBuffers":
+                    score_thresh: float, nms_thresh: float, detections_per_img: int, cand_cap: int, rescale: Optional[Tensor] = None,
+                    flags: int = 0) -> "PostBuffers":
         """decode of stored fp32 logits + sort + NMS + top-k as ONE op (the unfused form)"""
         pb, d = self.post_desc([(v.h, v.w) for v in logits], logits[0].n, strides, anchors, num_classes, score_thresh, nms_thresh, detections_per_img,
-                               cand_cap, rescale, logits=logits)
+                               cand_cap, rescale, logits=logits, flags=flags)
         self._record(self.lib.ymi_plan_add_postprocess(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0,
                      bytes=float(sum(v.n * v.h * v.w * 3 * (num_classes + 5) * 4 for v in logits)), shape=f"A={pb.total_anchors}")
         return pb

@@ -14,7 +14,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
-from .._lib import YmiError
+from .._lib import POST_EXACT_FULL, YmiError
 from ..engine import Plan, View
 from ..hipmodule import compute_dtype_of, nchw_to_view, view_to_nchw, weights_signature
 from ..ops import slab_to_list
@@ -65,6 +65,10 @@ class PendingDetections:
         e = self.entry
         self.event.synchronize()
         host = e.result_host.tolist()
+        if host[1] & 2 and not host[1] & 1:   # the score prefix of a crowded image gave < detections_per_img survivors: exact full pass
+            if os.environ.get("YOLORT_AMD_VERBOSE"):
+                print("[yolort_amd] score-prefix selection fell short: re-running with the full candidate set", flush=True)
+            return self.owner._redo_exact_full(e, self.rows)
         if host[1] != 0:   # candidate capacity exceeded (nothing truncated): grow, rebuild, redo synchronously
             n = e.x.n
             per_image = host[3] if host[3] > 0 else (host[0] + n - 1) // n   # status[3]: largest per-image count (per-image sort path)
@@ -113,6 +117,8 @@ class YOLO(nn.Module):
         # decode + threshold inside the head convolution's epilogue (the fp32 logits never reach memory); False keeps the
         # logits as plan buffers (`entry.logits`) and decodes them in the post-process op -- identical detections
         self.fuse_head_decode = os.environ.get("YOLORT_AMD_FUSED_HEAD", "1") != "0"
+        # True once a batch needed the full candidate set (include/yolort_amd.h YMI_POST_EXACT_FULL); sticky for this model
+        self.post_exact_full = os.environ.get("YOLORT_AMD_POST_EXACT_FULL", "0") == "1"
         self.pipeline_depth = 4   # plan instances per shape: later batches run while batch i is post-processed / collected
         self._has_warned = False
         # measurement hook (bench.py): (n_ops, starts, ends) -> HIP events around ops [0, n_ops) of every run
@@ -126,7 +132,7 @@ class YOLO(nn.Module):
         cdt = compute_dtype_of(self)
         pp = self.post_process
         post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
-        key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode)
+        key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode, self.post_exact_full)
         ring = self._ring.get(key)
         if ring is not None:
             self._ring_pos = (self._ring_pos + 1) % len(ring)
@@ -154,14 +160,15 @@ class YOLO(nn.Module):
             ag = self.anchor_generator
             strides = [float(s) for s in ag.strides]
             args = (self.num_classes, float(pp.score_thresh), float(pp.nms_thresh), int(pp.detections_per_img), self.cand_cap_per_image * n)
+            flags = POST_EXACT_FULL if self.post_exact_full else 0
             if self.fuse_head_decode and self.head.can_fuse_decode(plan, feats):
-                post, pd = plan.post_desc([(f.h, f.w) for f in feats], n, strides, ag.anchor_grids, *args, rescale=rescale)
+                post, pd = plan.post_desc([(f.h, f.w) for f in feats], n, strides, ag.anchor_grids, *args, rescale=rescale, flags=flags)
                 plan.post_begin(pd)
                 self.head.emit_fused(plan, feats, pd)
                 plan.post_finish(pd, post.total_anchors)
             else:
                 logits = self.head.emit(plan, feats)
-                post = plan.postprocess(logits, strides, ag.anchor_grids, *args, rescale=rescale)
+                post = plan.postprocess(logits, strides, ag.anchor_grids, *args, rescale=rescale, flags=flags)
         return _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
 
     def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> PendingDetections:
@@ -219,6 +226,15 @@ class YOLO(nn.Module):
         if needed_per_image > cap_eff or e.post.cand_cap >= self.cand_cap_per_image * e.x.n:
             want = max(int(needed_per_image * 1.25) + 1024, 2 * cap_eff)
             self.cand_cap_per_image = 1 << (want - 1).bit_length()
+        x_old = e.x
+        torch.cuda.synchronize()
+        e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
+        with torch.cuda.stream(e2.main_stream):
+            e2.x.base.copy_(x_old.base)
+            return self._submit_entry(e2, rescale_rows).result()
+
+    def _redo_exact_full(self, e: _PlanEntry, rescale_rows) -> List[Dict[str, Tensor]]:
+        self.post_exact_full = True
         x_old = e.x
         torch.cuda.synchronize()
         e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)

@@ -59,14 +59,18 @@ def postprocess_logits(head_outputs: Sequence[Tensor], strides: Sequence[float],
         nhwc[..., : 3 * k] = ho.to(torch.float32).permute(0, 2, 3, 1, 4).reshape(n, ho.shape[2], ho.shape[3], 3 * k)
         plan_inputs.append(nhwc)
     cap = cand_cap or max(4096, 2048 * n)
+    flags = 0
     while True:
         plan = Plan(h0.device, torch.float16)
         views = [View(t.view(-1), 0, n, t.shape[1], t.shape[2], 3 * k, t.shape[3]) for t in plan_inputs]
-        pb = plan.postprocess(views, strides, anchors, num_classes, score_thresh, nms_thresh, detections_per_img, cap)
+        pb = plan.postprocess(views, strides, anchors, num_classes, score_thresh, nms_thresh, detections_per_img, cap, flags=flags)
         plan.run()
         st = pb.status.cpu().tolist()
         if st[1] == 0:
             break
+        if not st[1] & 1:   # YMI_STATUS_PREFIX_SHORT only: the score prefix of a crowded image was too short, take everything
+            flags = _lib.POST_EXACT_FULL
+            continue
         need = max(st[0], st[3] * n)     # st[3]: largest per-image count when the per-image sort path overflowed
         cap = max(int(need * 1.25) + 1024, 2 * cap)  # nothing is truncated silently: grow and redo
         cap = n * (1 << ((cap + n - 1) // n - 1).bit_length())   # per-image regions are powers of two
