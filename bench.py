@@ -203,6 +203,15 @@ def main():
         conv_s = conv_ms * 1e-3
         achieved = bytes_step / conv_s / 1e9 if conv_s > 0 else 0.0
         ips = world * args.batch * args.steps / elapsed
+        # HBM traffic of the conv launches from the committed PMC passes (rocprofv3 cannot run inside this process):
+        # per launch like `achieved`; only quoted for the workload it was measured on
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv_traffic.json")
+        if os.path.exists(tpath) and args.arch == "yolov5_darknet_pan_s_r60" and args.batch == 32 and args.size == 640 and args.dtype == "fp16":
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = {"bytes_per_launch": round((tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6 / max(n_conv, 1)),
+                       "bytes_per_step": round((tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6), "source": tj["source"], "correction": tj["correction"]}
         out = {
             "metric": "images/sec at 640x640 (bs=32) yolov5s",
             "value": round(ips, 2),
@@ -222,7 +231,7 @@ def main():
                        "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                        "candidates_per_step_rank0": int(e.post.status[0].item())},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
-                         "traffic": None, "kernel": "conv_igemm_kernel (all conv launches of one step)", "launches_per_step": n_conv,
+                         "traffic": traffic, "kernel": "conv_igemm_kernel (all conv launches of one step)", "launches_per_step": n_conv,
                          "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2), "conv_ms_per_step": round(conv_ms, 4),
                          "algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_step": flops_step,
                          "tflops": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0,

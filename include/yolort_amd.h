@@ -179,6 +179,14 @@ typedef struct ymi_post_desc {
 #define YMI_STATUS_OVERFLOW_CAPACITY 1 /* status[1] bit 0: candidate capacity exceeded (grow cand_cap) */
 #define YMI_STATUS_PREFIX_SHORT 2      /* status[1] bit 1: prefix too short, re-run with YMI_POST_EXACT_FULL */
 
+/* Stem convolution fed straight from planar images (fixed-size streams): when every image of the batch already is the
+ * (3, H, W) canvas -- the reference's resize is then the identity and batch_images pads nothing (transform.py:53-97,
+ * 297-330) -- the letterbox pass and its NHWC4 round trip are skipped.  `d` is the stem in its super-pixel form exactly
+ * as for ymi_conv2d (cin 8, 6x3, stride (2,1), pad (2,1), h = H, w_in = W/2; x is ignored), imgs[i] are device pointers
+ * to contiguous (3, H, W) images of dtype d->dtype (16-byte aligned, W % 8 == 0).  Output is bit-identical to
+ * ymi_letterbox + ymi_conv2d.  Replaces yolort/models/darknetv6.py:81 + common.py:69-70 on that input. */
+int ymi_conv_stem_planar(const ymi_conv_desc* d, const void* const* imgs, int n_imgs, void* stream);
+
 int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_cap);
 int ymi_postprocess(const ymi_post_desc* d, void* stream);
 

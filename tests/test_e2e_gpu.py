@@ -197,6 +197,30 @@ def test_score_prefix_selection_is_exact(dev, k_det):
             assert torch.equal(a[k], b[k]), f"prefix / full post-process disagree on {k}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_stem_from_planar_equals_letterbox_path(dev, dtype):
+    """identity-size batches feed the stem straight from the planar images (ymi_conv_stem_planar): the first feature
+    map and the detections must be bit-identical to the letterbox + NHWC4 path; other batches keep the letterbox"""
+    from yolort_amd.utils.synth import synth_images
+    m = _model("yolov5_darknet_pan_n_r60", dev, dtype, size=(320, 416), score_thresh=0.2, nms_thresh=0.45)
+    imgs = [im.to(dev).to(dtype) for im in synth_images(3, 320, 416, seed=21)]
+    outs, stems = [], []
+    for planar in (True, False):
+        m.model.stem_from_planar = planar
+        outs.append(m.predict(imgs))
+        e = next(iter(m.model._entries.values()))
+        e.plan.run(1, 2)   # re-run op 1 only to be sure op 0's output buffer is what the next op consumed
+        stems.append(e.plan.conv_descs[0])
+    for a, b in zip(*outs):
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), f"planar-stem / letterbox paths disagree on {k}"
+    assert sum(len(d["scores"]) for d in outs[0]) > 0
+    # a batch that needs real letterboxing must not take the planar path (and must still work)
+    m.model.stem_from_planar = True
+    odd = [im.to(dev).to(dtype) for im in synth_images(2, 300, 400, seed=22)]
+    assert len(m.predict(odd)) == 2
+
+
 def test_mixed_sizes_and_yolo_forward(dev):
     """dynamic-shape letterbox batch + YOLO.forward on a pre-batched tensor (no rescale)."""
     from oracle import yolov5_oracle as O

@@ -232,5 +232,7 @@ __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16
 int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // dedicated stem kernel (conv_stem.hip): 6x3 s(2,1) super-pixel form, input patch in LDS, weights in registers
 int conv_stem_launch(const ConvArgs& a, int dtype, int out_dtype, hipStream_t s);
+// the same stem fed from planar (3, H, W) images of the compute dtype, identity-size batches (no letterbox pass)
+int conv_stem_planar_launch(const ConvArgs& a, const void* const* imgs, int dtype, int out_dtype, hipStream_t s);
 
 }  // namespace ymi

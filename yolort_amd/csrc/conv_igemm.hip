@@ -792,6 +792,23 @@ extern "C" int ymi_debug_stamps(unsigned long long* out, int n) {
 #endif
 
 extern "C" int ymi_conv2d(const ymi_conv_desc* d, void* stream) { return ymi::conv2d_launch(d, (hipStream_t)stream); }
+extern "C" int ymi_conv_stem_planar(const ymi_conv_desc* d, const void* const* imgs, int n_imgs, void* stream) {
+    using namespace ymi;
+    YMI_REQUIRE(d != nullptr && imgs != nullptr, "ymi_conv_stem_planar: null argument");
+    YMI_REQUIRE(d->w && d->bias && d->y && d->zeros, "ymi_conv_stem_planar: null buffer (w, bias, y and the zero page are required)");
+    YMI_REQUIRE(n_imgs == d->n && n_imgs >= 1, "ymi_conv_stem_planar: %d images for a descriptor of batch %d", n_imgs, d->n);
+    YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16, "ymi_conv_stem_planar: dtype must be F16 or BF16");
+    YMI_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == YMI_F32, "ymi_conv_stem_planar: out_dtype must equal dtype or be F32");
+    YMI_REQUIRE(d->ho == (d->h + 2 * d->ph - d->kh) / d->sh + 1 && d->wo == (d->w_in + 2 * d->pw - d->kw) / d->sw + 1, "ymi_conv_stem_planar: inconsistent output size");
+    YMI_REQUIRE(d->y_cstride % 8 == 0 || d->out_dtype == YMI_F32, "ymi_conv_stem_planar: y_cstride must be a multiple of 8");
+    for (int i = 0; i < n_imgs; ++i) YMI_REQUIRE(imgs[i] != nullptr && ((uintptr_t)imgs[i] & 15) == 0, "ymi_conv_stem_planar: image %d is null or not 16-byte aligned", i);
+    ymi_conv_desc dd = *d;
+    dd.x = d->zeros;   // not read; keeps the zero-page offset check of the shared argument builder trivially true
+    ConvArgs a;
+    { const int rc_args = fill_conv_args(&dd, a); if (rc_args != YMI_OK) return rc_args; }
+    return conv_stem_planar_launch(a, imgs, d->dtype, d->out_dtype, (hipStream_t)stream);
+}
+
 extern "C" int ymi_conv_head_decode(const ymi_conv_desc* conv, const ymi_post_desc* post, int level, void* stream) {
     return ymi::conv_head_decode_launch(conv, post, level, (hipStream_t)stream);
 }

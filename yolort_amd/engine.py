@@ -140,6 +140,7 @@ class Plan:
         self.stream: Optional[torch.cuda.Stream] = None
         # zero page for the pipelined conv kernel's out-of-range operand chunks (see yolort_amd.h)
         self.zeros = torch.zeros(1024, device=device, dtype=torch.uint8)
+        self.conv_descs: Dict[int, ConvDesc] = {}
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
         # per-shape tile selection by measurement at plan-build time ("measure, don't guess"): each conv is
         # timed once per candidate tile on its real buffers with HIP events; winners are cached per shape
@@ -227,6 +228,7 @@ class Plan:
         if out2 is not None and (out2.n, out2.h, out2.w, out2.c) != (x.n, ho, wo, pc.cout - split):
             raise YmiError(f"{name}: second output view has the wrong shape")
         d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
+        self.conv_descs[self.num_ops] = d   # op index -> descriptor (the fused stem path re-issues op 0 from planar images)
         if self.autotune and tile == 0 and d.zeros:
             d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split))
         esz = 2
@@ -361,6 +363,22 @@ class Plan:
 
     def post_finish(self, d: PostDesc, total_anchors: int) -> None:
         self._record(self.lib.ymi_plan_add_post_finish(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0, bytes=0.0, shape=f"A={total_anchors}")
+
+    def stem_from_planar(self, images: Sequence[Tensor], stream: Optional[torch.cuda.Stream] = None) -> None:
+        """op 0 (the stem conv in super-pixel form) computed straight from planar (3, H, W) images of the compute dtype:
+        identity-size batches skip the letterbox pass and its NHWC4 round trip (ymi_conv_stem_planar)"""
+        d = self.conv_descs[0]
+        ptrs = (C.c_void_p * len(images))(*[im.data_ptr() for im in images])
+        check(self.lib.ymi_conv_stem_planar(C.byref(d), ptrs, len(images), _lib.stream_ptr(stream)), "ymi_conv_stem_planar")
+
+    def stem_planar_ok(self, images: Sequence[Tensor], canvas_hw: Tuple[int, int]) -> bool:
+        d = self.conv_descs.get(0)
+        if d is None or not d.zeros or not (d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.cout_pad <= 64 and not d.res):
+            return False
+        hb, wb = canvas_hw
+        if wb % 8 or d.h != hb or d.w_in * 2 != wb or len(images) != d.n:
+            return False
+        return all(im.dtype == self.dtype and tuple(im.shape) == (3, hb, wb) and im.is_contiguous() and im.data_ptr() % 16 == 0 for im in images)
 
     # ---- execution ----
     @property

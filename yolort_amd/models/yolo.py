@@ -117,6 +117,8 @@ class YOLO(nn.Module):
         # decode + threshold inside the head convolution's epilogue (the fp32 logits never reach memory); False keeps the
         # logits as plan buffers (`entry.logits`) and decodes them in the post-process op -- identical detections
         self.fuse_head_decode = os.environ.get("YOLORT_AMD_FUSED_HEAD", "1") != "0"
+        # identity-size batches of compute-dtype planar images feed the stem directly (no letterbox pass); see YOLOv5.forward_async
+        self.stem_from_planar = os.environ.get("YOLORT_AMD_STEM_PLANAR", "1") != "0"
         # True once a batch needed the full candidate set (include/yolort_amd.h YMI_POST_EXACT_FULL); sticky for this model
         self.post_exact_full = os.environ.get("YOLORT_AMD_POST_EXACT_FULL", "0") == "1"
         self.pipeline_depth = 4   # plan instances per shape: later batches run while batch i is post-processed / collected
@@ -171,7 +173,7 @@ class YOLO(nn.Module):
                 post = plan.postprocess(logits, strides, ag.anchor_grids, *args, rescale=rescale, flags=flags)
         return _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
 
-    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> PendingDetections:
+    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]], first_op: int = 0, ev0=None) -> PendingDetections:
         """input view already filled on the current stream; enqueues the plan and returns a handle.
         Conv stack on the current stream, post-process + result copy on the entry's side stream, so
         the next batch's convolutions overlap this batch's sort/NMS (few, long-running waves)."""
@@ -189,14 +191,16 @@ class YOLO(nn.Module):
         e.rescale.copy_(e.rescale_host, non_blocking=True)
         if self.bracket is not None:
             _, starts, ends = self.bracket
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record(main)
-            e.plan.run(0, e.n_conv_ops, graph=self.use_graph, stream=main)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            if ev0 is None:   # the caller already started the bracket when it issued op 0 itself (stem from planar images)
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(main)
+            e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph and first_op == 0, stream=main)
             ev1.record(main)
             starts.append(ev0)
             ends.append(ev1)
         else:
-            e.plan.run(0, e.n_conv_ops, graph=self.use_graph, stream=main)
+            e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph and first_op == 0, stream=main)
         side = e.post_stream
         side.wait_stream(main)
         if os.environ.get("YOLORT_AMD_DEBUG_SKIP_POST", "0") != "1":   # tuning aid: upper bound without sort/NMS

@@ -65,13 +65,27 @@ class YOLOv5(nn.Module):
             raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
         e = model._acquire(len(images), hb, wb, images[0].device)
         with torch.cuda.stream(e.main_stream):
-            self.transform.letterbox_into(images, e.x, sizes, pads)
+            # fixed-size stream: every image already is the canvas (resize = identity, no padding) in the compute dtype ->
+            # the stem reads the planar images itself, the letterbox pass and its NHWC4 copy are skipped (bit-identical)
+            planar = (model.stem_from_planar and not model.use_graph and all(o == (hb, wb) for o in original) and all(s_ == (hb, wb) for s_ in sizes)
+                      and e.plan.stem_planar_ok(images, (hb, wb)))
+            ev0 = None
+            if planar:
+                for im in images:
+                    im.record_stream(e.main_stream)
+                if model.bracket is not None:   # measurement hook: the conv bracket starts with the stem
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record(torch.cuda.current_stream())
+                e.plan.stem_from_planar(images)
+            else:
+                self.transform.letterbox_into(images, e.x, sizes, pads)
+            first_op = 1 if planar else 0
             rows = [rescale_params((hb, wb), o) for o in original]
             if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
-                pend = model._submit_entry(e, None)
+                pend = model._submit_entry(e, None, first_op, ev0)
                 pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
                 return pend
-            return model._submit_entry(e, rows)
+            return model._submit_entry(e, rows, first_op, ev0)
 
     @torch.no_grad()
     def predict(self, x: Any, image_loader: Optional[Callable] = None) -> List[Dict[str, Tensor]]:
