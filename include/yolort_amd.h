@@ -103,6 +103,10 @@ typedef struct ymi_conv_desc {
      * reference common.py:172-173).  cout_split == 0 disables; must be a multiple of 8. */
     void* y2;
     int32_t y2_cstride, cout_split;
+    /* y2_mode 0: channel split as above.  y2_mode 1 (cout_split must be 0, cout % 32 == 0, 16-bit output): y2 is an
+     * (n, 2*ho, 2*wo) view that receives ALL output channels nearest-neighbour upsampled x2, in addition to y --
+     * the nn.Upsample(scale_factor=2) of path_aggregation_network.py:221-223 folded into its producer's epilogue. */
+    int32_t y2_mode, reserved0;
     /* >= 256 readable zero bytes in device memory within +-4 GiB of x (e.g. the tail of x's own
      * buffer): source of out-of-image / out-of-range activation chunks for the direct-to-LDS loads of
      * the pipelined kernel, which also requires the packed weight ROWS to be zero-padded to a

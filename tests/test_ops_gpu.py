@@ -116,6 +116,35 @@ def test_conv_software_pipelined_tiles(dev, tile):
     _run_conv(dev, torch.float16, n=3, cin=256, cout=64, h=20, w=20, k=1, s=1, p=0, tile=tile, seed=tile + 5)           # 8 steps
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tile", [0, 61, 75, 77])
+def test_conv_upsampled_second_output(dev, dtype, tile):
+    """y2_mode 1: one launch writes the conv output and its nearest x2 upsample (into a channel slice of a wider buffer):
+    both must equal the plain conv followed by the upsample kernel, bit for bit"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(3, 96, 13, 11, generator=g).to(dtype).float()
+    wt = (torch.randn(64, 96, 1, 1, generator=g) / 10).to(dtype).float()
+    b = torch.randn(64, generator=g) * 0.1
+    plan = engine.Plan(dev, dtype)
+    xv = plan.alloc(3, 13, 11, 96)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, dtype))
+    pc = engine.PackedConv(wt, b, None, dtype, dev)
+    y_ref = plan.conv(xv, pc, 1, 0, tile=tile)
+    up_ref = plan.alloc(3, 26, 22, 64)
+    plan.upsample2x(y_ref, up_ref)
+    y = plan.alloc(3, 13, 11, 64)
+    cat = plan.alloc(3, 26, 22, 160, zero=True)
+    plan.conv(xv, pc, 1, 0, out=y, up2_out=cat.slice_c(32, 64), tile=tile)
+    plan.run()
+    assert torch.equal(y.as_tensor(), y_ref.as_tensor())
+    got = cat.as_tensor()
+    assert torch.equal(got[..., 32:96], up_ref.as_tensor())
+    assert got[..., :32].abs().max().item() == 0 and got[..., 96:].abs().max().item() == 0
+    ref = torch.nn.functional.silu(torch.nn.functional.conv2d(x, wt, b))
+    assert (y.as_tensor().float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < (3e-2 if dtype == torch.bfloat16 else 1e-2)
+
+
 def test_conv_views_and_residual(dev):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=20, w=20, k=3, s=1, p=1, residual=True, x_cs_extra=64, y_cs_extra=128)
     _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)

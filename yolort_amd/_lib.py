@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32), ("k_pad", C.c_int32),
         ("act", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
         ("y2", C.c_void_p), ("y2_cstride", C.c_int32), ("cout_split", C.c_int32),
+        ("y2_mode", C.c_int32), ("reserved0", C.c_int32),
         ("zeros", C.c_void_p),
     ]
 

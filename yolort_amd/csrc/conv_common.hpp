@@ -41,6 +41,7 @@ struct ConvArgs {
     int nblk_m, nblk_n;
     void* y2;      // second output view for couts >= split (0 = off)
     int y2_cs, split;
+    int up2;       // 1: y2 is an (n, 2ho, 2wo) view receiving every output channel nearest-upsampled x2 (split == 0)
     const uint16_t* zeros;
     int x_zero_off;    // (zeros - x) in elements: out-of-range activation chunks read x + x_zero_off
     int kh, kw;
@@ -123,7 +124,8 @@ __device__ __forceinline__ void load_residual(const ConvArgs& a, int64_t m, bool
 
 // activation (+ residual) + conversion + store of one 32x32 sub-tile; cbase (first cout of the sub-tile) is wave-uniform
 template <int DT, int ODT, bool RES>
-__device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& acc, int64_t m, bool m_ok, int cbase, int hi, const u32x2 (&r)[4]) {
+__device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& acc, int64_t m, bool m_ok, int cbase, int hi, const u32x2 (&r)[4],
+                                               int64_t m_up = 0) {
     float v[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -178,6 +180,14 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
                     else yp = reinterpret_cast<uint16_t*>(a.y) + m * a.y_cs + co;
                     u32x4 o = {ax, ay, bx, by};
                     *reinterpret_cast<u32x4*>(yp) = o;
+                    if (a.up2) {   // the same 8 channels to the 2x2 pixels of the upsampled view (wave-uniform flag)
+                        uint16_t* up = reinterpret_cast<uint16_t*>(a.y2) + m_up * a.y2_cs + co;
+                        const int64_t row = (int64_t)2 * a.wo * a.y2_cs;
+                        *reinterpret_cast<u32x4*>(up) = o;
+                        *reinterpret_cast<u32x4*>(up + a.y2_cs) = o;
+                        *reinterpret_cast<u32x4*>(up + row) = o;
+                        *reinterpret_cast<u32x4*>(up + row + a.y2_cs) = o;
+                    }
                 }
             }
         } else if (m_ok) {
@@ -202,10 +212,21 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
 // whole wave tile: TM pixel groups x TN cout groups.  pix(j, m, m_ok) yields the output pixel index of this lane in group j.
 template <int DT, int ODT, int TN, int TM, class PixFn>
 __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int hi, PixFn&& pix) {
-    int64_t m[TM];
+    int64_t m[TM], m_up[TM];
     bool m_ok[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) pix(j, m[j], m_ok[j]);
+    for (int j = 0; j < TM; ++j) {
+        pix(j, m[j], m_ok[j]);
+        m_up[j] = 0;
+        if (a.up2) {   // pixel (img, oy, ox) -> top-left of its 2x2 block in the (n, 2ho, 2wo) view
+            const int mm = m_ok[j] ? (int)m[j] : 0;
+            const int hw = a.ho * a.wo;
+            const int img = fast_div(mm, hw, a.magic_hw);
+            const int rem = mm - img * hw;
+            const int oy = fast_div(rem, a.wo, a.magic_w), ox = rem - oy * a.wo;
+            m_up[j] = ((int64_t)img * 2 * a.ho + 2 * oy) * (2 * a.wo) + 2 * ox;
+        }
+    }
     if (a.res != nullptr) {   // wave-uniform
         u32x2 rv[TM][TN][4];
 #pragma unroll
@@ -217,14 +238,14 @@ __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16
         for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, true>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, rv[j][i]);
+                if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, true>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, rv[j][i], m_up[j]);
     } else {
         const u32x2 none[4] = {};
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, false>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, none);
+                if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, false>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, none, m_up[j]);
     }
 }
 

@@ -666,6 +666,7 @@ static int fill_conv_args(const ymi_conv_desc* d, ConvArgs& a) {
     a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw; a.k_pad = d->k_pad; a.act = d->act;
     a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
     a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
+    a.up2 = d->y2_mode == 1 ? 1 : 0;
     a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
     auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
     a.magic_hw = magic(d->ho * d->wo);
@@ -701,6 +702,13 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     YMI_REQUIRE(a.split == 0 || (d->y2 != nullptr && a.split % 8 == 0 && a.split < d->cout && d->res == nullptr && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0),
                 "ymi_conv2d: invalid second-output configuration");
     YMI_REQUIRE(a.split == 0 || a.zeros != nullptr, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");
+    YMI_REQUIRE(d->y2_mode == 0 || d->y2_mode == 1, "ymi_conv2d: unknown y2_mode %d", d->y2_mode);
+    YMI_REQUIRE(d->y2_mode == 0 || (d->y2 != nullptr && a.split == 0 && d->cout % 32 == 0 && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0 && a.zeros != nullptr),
+                "ymi_conv2d: the upsampled second output needs y2, cout_split == 0, cout %% 32 == 0, a 16-bit output, y2_cstride %% 8 == 0 and desc.zeros");
+    if (d->y2_mode == 1) {
+        YMI_REQUIRE(d->tile >= 0, "ymi_conv2d: the upsampled second output is not available in the register-staged kernel");
+        YMI_REQUIRE((int64_t)d->n * 4 * d->ho * d->wo < ((int64_t)1 << 31), "ymi_conv2d: upsampled view too large");
+    }
     if (a.zeros != nullptr) {
         // 32-bit element offsets inside the pipelined kernel
         YMI_REQUIRE((int64_t)d->n * d->h * d->w_in * d->x_cstride < ((int64_t)1 << 31) && (int64_t)d->cout_pad * d->k_pad < ((int64_t)1 << 31),

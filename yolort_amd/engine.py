@@ -178,7 +178,7 @@ class Plan:
 
     # ---- ops ----
     def conv_desc(self, x: View, pc: PackedConv, stride: Tuple[int, int], pad: Tuple[int, int], act: int, y: View, res: Optional[View], tile: int = 0,
-                  y2: Optional[View] = None, split: int = 0) -> ConvDesc:
+                  y2: Optional[View] = None, split: int = 0, up2: bool = False) -> ConvDesc:
         d = ConvDesc()
         d.x, d.w, d.bias = x.ptr, pc.w.data_ptr(), pc.bias.data_ptr()
         is1x1 = pc.kh == 1 and pc.kw == 1 and stride == (1, 1) and pad == (0, 0)
@@ -193,6 +193,7 @@ class Plan:
         d.act, d.dtype, d.out_dtype, d.tile = act, dtype_code(pc.dtype), dtype_code(y.dtype), tile
         d.y2 = None if y2 is None else y2.ptr
         d.y2_cstride, d.cout_split = (0, 0) if y2 is None else (y2.cs, split)
+        d.y2_mode = 1 if (up2 and y2 is not None) else 0
         has_tail = x.tail >= 0
         if y2 is not None and not has_tail:
             raise YmiError("second-output convs need a plan-allocated input (zero tail)")
@@ -205,9 +206,11 @@ class Plan:
 
     def conv(self, x: View, pc: PackedConv, stride: int | Tuple[int, int] = 1, pad: int | Tuple[int, int] = 0, act: int = ACT_SILU,
              out: Optional[View] = None, res: Optional[View] = None, out_dtype: Optional[torch.dtype] = None, name: str = "conv", tile: int = 0,
-             out2: Optional[View] = None, split: int = 0) -> View:
+             out2: Optional[View] = None, split: int = 0, up2_out: Optional[View] = None) -> View:
         """`out2`/`split`: output channels [split, cout) are written to view `out2` instead of `out`
-        (one launch feeding two consumers of the same input, e.g. C3.cv1 + C3.cv2)."""
+        (one launch feeding two consumers of the same input, e.g. C3.cv1 + C3.cv2).
+        `up2_out`: an (n, 2ho, 2wo, cout) view that additionally receives the whole output nearest-upsampled x2
+        (the PAN's nn.Upsample folded into its producer; needs cout % 32 == 0)."""
         s = (stride, stride) if isinstance(stride, int) else tuple(stride)
         p = (pad, pad) if isinstance(pad, int) else tuple(pad)
         if pc.stem_superpixel:
@@ -227,10 +230,15 @@ class Plan:
             raise YmiError(f"{name}: output view {(out.n, out.h, out.w, out.c)} != expected {(x.n, ho, wo, c_first)}")
         if out2 is not None and (out2.n, out2.h, out2.w, out2.c) != (x.n, ho, wo, pc.cout - split):
             raise YmiError(f"{name}: second output view has the wrong shape")
-        d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
+        if up2_out is not None:
+            if out2 is not None or pc.cout % 32 or (up2_out.n, up2_out.h, up2_out.w, up2_out.c) != (x.n, 2 * ho, 2 * wo, pc.cout) or out.dtype != self.dtype:
+                raise YmiError(f"{name}: the upsampled second output needs cout % 32 == 0, an (n, 2ho, 2wo, cout) view and no channel split")
+            d = self.conv_desc(x, pc, s, p, act, out, res, tile, up2_out, 0, up2=True)
+        else:
+            d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
         self.conv_descs[self.num_ops] = d   # op index -> descriptor (the fused stem path re-issues op 0 from planar images)
         if self.autotune and tile == 0 and d.zeros:
-            d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split))
+            d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None))
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its

@@ -82,14 +82,19 @@ class PathAggregationNetwork(HipModule):
             c_t = conv.conv.out_channels
             c_down = self.layer_blocks[2 * idx + 1].conv.out_channels
             bu_cat[idx] = plan.alloc(n, feats[level].h, feats[level].w, c_down + c_t)
-            top = conv.emit(plan, last, out=bu_cat[idx].slice_c(c_down, c_t), name=f"{name}.inner_blocks.{3 * t + 1}")
             tap = feats[level - 1]
             if td_cat is not None and t in td_cat:
                 cat = td_cat[t]
             else:
                 cat = plan.alloc(n, tap.h, tap.w, c_t + tap.c)
                 plan.copy(tap, cat.slice_c(c_t, tap.c), name=f"{name}.cat_tap.{t}")
-            plan.upsample2x(top, cat.slice_c(0, c_t), name=f"{name}.inner_blocks.{3 * t + 2}")
+            # nn.Upsample(scale_factor=2) (reference :221-223): folded into the 1x1 conv's epilogue when its channel count
+            # allows (the conv writes its output AND the four upsampled copies), else a separate kernel
+            fold = c_t % 32 == 0 and not plan.use_v1 and (cat.h, cat.w) == (2 * feats[level].h, 2 * feats[level].w)
+            top = conv.emit(plan, last, out=bu_cat[idx].slice_c(c_down, c_t), name=f"{name}.inner_blocks.{3 * t + 1}",
+                            up2_out=cat.slice_c(0, c_t) if fold else None)
+            if not fold:
+                plan.upsample2x(top, cat.slice_c(0, c_t), name=f"{name}.inner_blocks.{3 * t + 2}")
             last = cat
         results = [self.layer_blocks[0].emit(plan, last, name=f"{name}.layer_blocks.0")]  # reference :230-231
         for idx in range(nf - 1):  # reference :233-237

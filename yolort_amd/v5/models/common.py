@@ -62,10 +62,10 @@ class Conv(HipModule):
         self._packed[key] = (sig, pc)
         return pc
 
-    def emit(self, plan: Plan, x: View, out: Optional[View] = None, res: Optional[View] = None, name: str = "conv") -> View:
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, res: Optional[View] = None, name: str = "conv", up2_out: Optional[View] = None) -> View:
         pc = self.packed(plan.dtype, plan.device, x.c)
         act = ACT_SILU if isinstance(self.act, nn.SiLU) else ACT_NONE
-        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act, out=out, res=res, name=name)
+        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act, out=out, res=res, name=name, up2_out=up2_out)
 
 
 class Bottleneck(HipModule):
