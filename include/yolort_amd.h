@@ -107,6 +107,16 @@ typedef struct ymi_conv_desc {
      * (n, 2*ho, 2*wo) view that receives ALL output channels nearest-neighbour upsampled x2, in addition to y --
      * the nn.Upsample(scale_factor=2) of path_aggregation_network.py:221-223 folded into its producer's epilogue. */
     int32_t y2_mode, reserved0;
+    /* optional CHAINED 1x1 convolution (Bottleneck.cv1 after C3.cv1, reference common.py:115,172): with K1 = cout_split
+     * (or cout when there is no split) a second fused conv t = SiLU(chain_w * y[:, 0:K1] + chain_bias) is evaluated in
+     * the epilogue from the freshly rounded outputs still in registers -- one launch instead of two and no re-read of y.
+     * chain_w: packed [round_up(chain_cout,128)][K1] like w (K1 % 32 == 0, K1 <= 64), chain_bias fp32 [chain_cout],
+     * chain_y an (n, ho, wo) view of chain_cout channels (chain_cout % 32 == 0, <= 128).  Needs act SILU, a 16-bit
+     * output and a tile whose cout width equals K1 (auto tile selection takes care of it); NULL disables. */
+    const void* chain_w;
+    const float* chain_bias;
+    void* chain_y;
+    int32_t chain_cout, chain_y_cstride;
     /* >= 256 readable zero bytes in device memory within +-4 GiB of x (e.g. the tail of x's own
      * buffer): source of out-of-image / out-of-range activation chunks for the direct-to-LDS loads of
      * the pipelined kernel, which also requires the packed weight ROWS to be zero-padded to a

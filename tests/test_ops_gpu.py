@@ -145,6 +145,39 @@ def test_conv_upsampled_second_output(dev, dtype, tile):
     assert (y.as_tensor().float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < (3e-2 if dtype == torch.bfloat16 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("c_,tile", [(32, 0), (32, 63), (32, 76), (32, 13), (64, 0), (64, 62), (64, 72), (64, 12)])
+def test_conv_chained_1x1(dev, dtype, c_, tile):
+    """chain_w: C3.cv1+cv2 (split output) with the first Bottleneck's 1x1 evaluated in the same launch from the rounded
+    outputs in registers -- all three outputs must equal the two-launch form bit for bit"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(51 + c_)
+    n, h, w, cin = 2, 19, 23, 64
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+    w1 = (torch.randn(2 * c_, cin, 1, 1, generator=g) / 8).to(dtype).float()
+    b1 = torch.randn(2 * c_, generator=g) * 0.1
+    w2 = (torch.randn(c_, c_, 1, 1, generator=g) / c_ ** 0.5).to(dtype).float()
+    b2 = torch.randn(c_, generator=g) * 0.1
+    plan = engine.Plan(dev, dtype)
+    xv = plan.alloc(n, h, w, cin)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, dtype))
+    pc1 = engine.PackedConv(w1, b1, None, dtype, dev)
+    pc2 = engine.PackedConv(w2, b2, None, dtype, dev)
+    # reference form: two launches
+    y_r, cat_r = plan.alloc(n, h, w, c_), plan.alloc(n, h, w, 2 * c_, zero=True)
+    plan.conv(xv, pc1, 1, 0, out=y_r, out2=cat_r.slice_c(c_, c_), split=c_)
+    t_r = plan.conv(y_r, pc2, 1, 0)
+    # chained form
+    y, cat, t = plan.alloc(n, h, w, c_), plan.alloc(n, h, w, 2 * c_, zero=True), plan.alloc(n, h, w, c_)
+    plan.conv(xv, pc1, 1, 0, out=y, out2=cat.slice_c(c_, c_), split=c_, chain=(pc2, t), tile=tile)
+    plan.run()
+    assert torch.equal(y.as_tensor(), y_r.as_tensor())
+    assert torch.equal(cat.as_tensor(), cat_r.as_tensor())
+    assert torch.equal(t.as_tensor(), t_r.as_tensor())
+    ref = torch.nn.functional.silu(torch.nn.functional.conv2d(torch.nn.functional.silu(torch.nn.functional.conv2d(x, w1[:c_], b1[:c_])).to(dtype).float(), w2, b2))
+    assert (t.as_tensor().float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < (6e-2 if dtype == torch.bfloat16 else 1e-2)
+
+
 def test_conv_views_and_residual(dev):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=20, w=20, k=3, s=1, p=1, residual=True, x_cs_extra=64, y_cs_extra=128)
     _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)

@@ -41,6 +41,10 @@ struct ConvArgs {
     int nblk_m, nblk_n;
     void* y2;      // second output view for couts >= split (0 = off)
     int y2_cs, split;
+    const uint16_t* chain_w;   // chained 1x1 conv on the first chain_k output channels (see ymi_conv_desc.chain_w); NULL = off
+    const float* chain_bias;
+    void* chain_y;
+    int chain_k, chain_cout, chain_y_cs;
     int up2;       // 1: y2 is an (n, 2ho, 2wo) view receiving every output channel nearest-upsampled x2 (split == 0)
     const uint16_t* zeros;
     int x_zero_off;    // (zeros - x) in elements: out-of-range activation chunks read x + x_zero_off
@@ -125,7 +129,7 @@ __device__ __forceinline__ void load_residual(const ConvArgs& a, int64_t m, bool
 // activation (+ residual) + conversion + store of one 32x32 sub-tile; cbase (first cout of the sub-tile) is wave-uniform
 template <int DT, int ODT, bool RES>
 __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& acc, int64_t m, bool m_ok, int cbase, int hi, const u32x2 (&r)[4],
-                                               int64_t m_up = 0) {
+                                               int64_t m_up = 0, u32x4* frag_out = nullptr) {
     float v[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -173,6 +177,10 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
                 auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                 ax = rx[0]; bx = rx[1];
                 ay = ry[0]; by = ry[1];
+                if (frag_out != nullptr) {   // compile-time known at every call site: the rounded outputs double as MFMA operands
+                    u32x4 f = {ax, ay, bx, by};
+                    frag_out[g >> 1] = f;
+                }
                 if (m_ok) {
                     const int co = cbase + (g + hi) * 8;
                     uint16_t* yp;
@@ -246,6 +254,53 @@ __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16
 #pragma unroll
             for (int i = 0; i < TN; ++i)
                 if (cbase0 + i * 32 < a.cout) finish_subtile<DT, ODT, false>(a, acc[i][j], m[j], m_ok[j], cbase0 + i * 32, hi, none, m_up[j]);
+    }
+}
+
+// Wave tile with a CHAINED 1x1 convolution (ymi_conv_desc.chain_w): the wave owns pixel groups j and ALL chain_k = 32*TN
+// output channels of the first conv; its rounded, lane-swapped 16-byte output packets are exactly the activation
+// fragments of v_mfma_f32_32x32x16 (lanes < 32: channels 16s..16s+7, lanes >= 32: 16s+8..16s+15 of pixel lane & 31), so
+// the second GEMM runs from registers; its weight fragments come straight from global memory (L2 resident, <= 16 KB).
+template <int DT, int TN, int TM, class PixFn>
+__device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int hi, int lane, PixFn&& pix) {
+    typedef typename Mfma<DT>::frag frag;
+    int64_t m[TM];
+    bool m_ok[TM];
+    u32x4 fr[TM][TN][2];
+    const u32x2 none[4] = {};
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        pix(j, m[j], m_ok[j]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) finish_subtile<DT, DT, false>(a, acc[i][j], m[j], m_ok[j], i * 32, hi, none, 0, fr[j][i]);
+    }
+    ConvArgs a2 = a;   // output side of the chained conv
+    a2.y = a.chain_y; a2.y_cs = a.chain_y_cs; a2.cout = a.chain_cout; a2.cout_pad = a.chain_cout; a2.split = 0; a2.up2 = 0; a2.res = nullptr;
+    const int tn2 = a.chain_cout >> 5;   // 1..4 (wave-uniform)
+    for (int i2 = 0; i2 < tn2; ++i2) {
+        // weight fragments of cout rows i2*32 + (lane & 31), all 2*TN k16-steps
+        frag wf[2 * TN];
+        const uint16_t* wr = a.chain_w + (int64_t)(i2 * 32 + (lane & 31)) * a.chain_k + 8 * hi;
+#pragma unroll
+        for (int s2 = 0; s2 < 2 * TN; ++s2) wf[s2] = *reinterpret_cast<const frag*>(wr + 16 * s2);
+        f32x4 b2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b2[g] = *reinterpret_cast<const f32x4*>(a.chain_bias + i2 * 32 + g * 8 + hi * 4);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            f32x16 acc2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[g * 4 + e] = b2[g][e];
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * TN; ++s2) {
+                frag xf;
+                __builtin_memcpy(&xf, &fr[j][s2 >> 1][s2 & 1], 16);
+                acc2 = Mfma<DT>::run(wf[s2], xf, acc2);
+            }
+            finish_subtile<DT, DT, false>(a2, acc2, m[j], m_ok[j], i2 * 32, hi, none);
+        }
     }
 }
 

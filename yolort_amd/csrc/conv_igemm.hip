@@ -519,10 +519,17 @@ struct StoreEpilogue {
     const ConvArgs& a;
     template <int TN, int TM>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[TN][TM], int mbase, int cbase0, int lane, int, uint16_t*) const {
-        finish_wave_tile<DT, ODT, TN, TM>(a, acc, cbase0, lane >> 5, [&](int j, int64_t& m, bool& ok) {
+        auto pix = [&](int j, int64_t& m, bool& ok) {
             m = mbase + j * 32 + (lane & 31);
             ok = m < a.M;
-        });
+        };
+        if constexpr (ODT == DT && TN <= 2) {   // chained 1x1 (launch checks: this wave tile spans exactly the chain's K channels)
+            if (a.chain_w != nullptr && cbase0 == 0) {
+                finish_wave_tile_chain<DT, TN, TM>(a, acc, lane >> 5, lane, pix);
+                return;
+            }
+        }
+        finish_wave_tile<DT, ODT, TN, TM>(a, acc, cbase0, lane >> 5, pix);
     }
 };
 
@@ -564,6 +571,10 @@ static int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, BM);
     a.nblk_n = cdiv(a.cout_pad, BN);
+    if (a.chain_w != nullptr && !(BN == WN && BN == a.chain_k && BN <= 64)) {
+        set_error("ymi_conv2d: this tile does not fit the chained 1x1 convolution (its cout width must equal %d)", a.chain_k);
+        return YMI_EINVAL;
+    }
     const bool utap = (a.cin % 32 == 0) && (a.kh * a.kw <= 32);
     const size_t lds = (size_t)STAGES * (BM + BN) * 64 + ((is1x1 || utap) ? 0 : (size_t)a.k_pad) + 16;
     dim3 grid(a.nblk_m * a.nblk_n);
@@ -598,6 +609,11 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile >= 0x100) { a.debug = tile >> 8; tile &= 0xff; }
     const bool force_v1 = tile < 0;
     if (force_v1) tile = -tile == 100 ? 0 : -tile;   // negative tile ids force the register-staged kernel (-100 = auto)
+    if (a.chain_w != nullptr && (force_v1 || (tile >= 1 && tile <= 5 && a.zeros == nullptr) || (tile >= 31 && tile <= 41))) {
+        set_error("ymi_conv2d: the chained 1x1 convolution needs the pipelined implicit-GEMM kernel");
+        return YMI_EINVAL;
+    }
+    if (tile == 0 && a.chain_w != nullptr) tile = a.chain_k == 32 ? 3 : 2;   // 256x32 / 256x64: cout width == chain K, four waves along the pixels
     if (tile == 0) {
         const int cp = a.cout_pad;
         if (cp <= 32) tile = 3;
@@ -667,6 +683,8 @@ static int fill_conv_args(const ymi_conv_desc* d, ConvArgs& a) {
     a.M = d->n * d->ho * d->wo; a.nblk_m = 0; a.nblk_n = 0;
     a.y2 = d->y2; a.y2_cs = d->y2_cstride; a.split = d->cout_split; a.zeros = (const uint16_t*)d->zeros;
     a.up2 = d->y2_mode == 1 ? 1 : 0;
+    a.chain_w = (const uint16_t*)d->chain_w; a.chain_bias = d->chain_bias; a.chain_y = d->chain_y;
+    a.chain_cout = d->chain_cout; a.chain_y_cs = d->chain_y_cstride; a.chain_k = d->cout_split > 0 ? d->cout_split : d->cout;
     a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
     auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
     a.magic_hw = magic(d->ho * d->wo);
@@ -703,6 +721,12 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
                 "ymi_conv2d: invalid second-output configuration");
     YMI_REQUIRE(a.split == 0 || a.zeros != nullptr, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");
     YMI_REQUIRE(d->y2_mode == 0 || d->y2_mode == 1, "ymi_conv2d: unknown y2_mode %d", d->y2_mode);
+    if (d->chain_w != nullptr) {
+        const int k1 = d->cout_split > 0 ? d->cout_split : d->cout;
+        YMI_REQUIRE(d->chain_bias && d->chain_y && (k1 == 32 || k1 == 64) && d->chain_cout % 32 == 0 && d->chain_cout >= 32 && d->chain_cout <= 128 &&
+                        d->chain_y_cstride % 8 == 0 && d->act == YMI_ACT_SILU && d->out_dtype == d->dtype && d->res == nullptr && d->y2_mode == 0 && a.zeros != nullptr,
+                    "ymi_conv2d: chained 1x1 needs chain_bias / chain_y, K1 in {32, 64}, chain_cout %% 32 == 0 (<= 128), SiLU, a 16-bit output, no residual, desc.zeros");
+    }
     YMI_REQUIRE(d->y2_mode == 0 || (d->y2 != nullptr && a.split == 0 && d->cout % 32 == 0 && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0 && a.zeros != nullptr),
                 "ymi_conv2d: the upsampled second output needs y2, cout_split == 0, cout %% 32 == 0, a 16-bit output, y2_cstride %% 8 == 0 and desc.zeros");
     if (d->y2_mode == 1) {

@@ -141,6 +141,7 @@ class Plan:
         # zero page for the pipelined conv kernel's out-of-range operand chunks (see yolort_amd.h)
         self.zeros = torch.zeros(1024, device=device, dtype=torch.uint8)
         self.conv_descs: Dict[int, ConvDesc] = {}
+        self.chain_1x1 = os.environ.get("YOLORT_AMD_CHAIN", "1") != "0"   # Bottleneck.cv1 chained into C3.cv1+cv2's launch
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
         # per-shape tile selection by measurement at plan-build time ("measure, don't guess"): each conv is
         # timed once per candidate tile on its real buffers with HIP events; winners are cached per shape
@@ -206,11 +207,14 @@ class Plan:
 
     def conv(self, x: View, pc: PackedConv, stride: int | Tuple[int, int] = 1, pad: int | Tuple[int, int] = 0, act: int = ACT_SILU,
              out: Optional[View] = None, res: Optional[View] = None, out_dtype: Optional[torch.dtype] = None, name: str = "conv", tile: int = 0,
-             out2: Optional[View] = None, split: int = 0, up2_out: Optional[View] = None) -> View:
+             out2: Optional[View] = None, split: int = 0, up2_out: Optional[View] = None,
+             chain: Optional[Tuple[PackedConv, View]] = None) -> View:
         """`out2`/`split`: output channels [split, cout) are written to view `out2` instead of `out`
         (one launch feeding two consumers of the same input, e.g. C3.cv1 + C3.cv2).
         `up2_out`: an (n, 2ho, 2wo, cout) view that additionally receives the whole output nearest-upsampled x2
-        (the PAN's nn.Upsample folded into its producer; needs cout % 32 == 0)."""
+        (the PAN's nn.Upsample folded into its producer; needs cout % 32 == 0).
+        `chain` = (packed 1x1 conv, output view): a second conv on the first `split` (or all) output channels, evaluated in
+        this launch's epilogue from registers (Bottleneck.cv1 chained to C3.cv1; K in {32, 64})."""
         s = (stride, stride) if isinstance(stride, int) else tuple(stride)
         p = (pad, pad) if isinstance(pad, int) else tuple(pad)
         if pc.stem_superpixel:
@@ -236,17 +240,30 @@ class Plan:
             d = self.conv_desc(x, pc, s, p, act, out, res, tile, up2_out, 0, up2=True)
         else:
             d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
+        if chain is not None:
+            pc2, tv = chain
+            k1 = split if out2 is not None else pc.cout
+            if pc2.kh != 1 or pc2.kw != 1 or pc2.cin != k1 or pc2.k_pad != k1 or (tv.n, tv.h, tv.w, tv.c) != (x.n, ho, wo, pc2.cout) or up2_out is not None:
+                raise YmiError(f"{name}: chained conv must be a 1x1 over the first {k1} output channels with a matching output view")
+            d.chain_w, d.chain_bias, d.chain_y = pc2.w.data_ptr(), pc2.bias.data_ptr(), tv.ptr
+            d.chain_cout, d.chain_y_cstride = pc2.cout, tv.cs
+            self.keep.append(pc2)
         self.conv_descs[self.num_ops] = d   # op index -> descriptor (the fused stem path re-issues op 0 from planar images)
         if self.autotune and tile == 0 and d.zeros:
-            d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None))
+            d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None, chain is not None))
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
         # output once; a fused cv1+cv2 launch stands for two reference convs, so its input counts twice.
         ref_reads = 2 if out2 is not None else 1
+        chain_flops = chain_bytes = 0.0
+        if chain is not None:   # the chained conv is a reference conv of its own: reads its input once, writes its output once
+            chain_flops = 2.0 * x.n * ho * wo * chain[0].cout * chain[0].k_real
+            chain_bytes = float(x.n * ho * wo * (chain[0].cin + chain[0].cout) * esz + chain[0].cout * chain[0].k * esz)
         self._record(self.lib.ymi_plan_add_conv(self.handle, C.byref(d)), name, kind="conv",
-                     flops=flops, bytes=float(ref_reads * x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz),
-                     ref_convs=ref_reads, tile=int(d.tile),
+                     flops=flops + chain_flops,
+                     bytes=float(ref_reads * x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz) + chain_bytes,
+                     ref_convs=ref_reads + (1 if chain is not None else 0), tile=int(d.tile),
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
 

@@ -78,8 +78,9 @@ class Bottleneck(HipModule):
         self.cv2 = Conv(c_, c2, 3, 1, g=g, version=version)
         self.add = shortcut and c1 == c2
 
-    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck") -> View:
-        y = self.cv1.emit(plan, x, name=name + ".cv1")
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck", t: Optional[View] = None) -> View:
+        """`t`: cv1's output when the producer of x already computed it (chained 1x1, see C3.emit)"""
+        y = t if t is not None else self.cv1.emit(plan, x, name=name + ".cv1")
         return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + ".cv2")
 
 
@@ -116,13 +117,23 @@ class C3(HipModule):
         cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
         nb = len(self.m)
         fuse = (not plan.use_v1) and c_ % 8 == 0 and nb >= 1 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
+        t0 = None
         if fuse:
             y = plan.alloc(x.n, x.h, x.w, c_)
-            plan.conv(x, self.packed_pair(plan.dtype, plan.device, x.c), 1, 0, ACT_SILU, out=y, out2=cat.slice_c(c_, c_), split=c_, name=name + ".cv1+cv2")
+            b0 = self.m[0]
+            # the first Bottleneck's 1x1 (cv1) rides in the same launch: its input is this conv's freshly rounded output
+            chain_ok = (plan.chain_1x1 and c_ in (32, 64) and isinstance(b0, Bottleneck) and isinstance(b0.cv1.act, nn.SiLU) and b0.cv1.conv.kernel_size == (1, 1)
+                        and b0.cv1.conv.out_channels % 32 == 0 and b0.cv1.conv.out_channels <= 128)
+            chain = None
+            if chain_ok:
+                t0 = plan.alloc(x.n, x.h, x.w, b0.cv1.conv.out_channels)
+                chain = (b0.cv1.packed(plan.dtype, plan.device, c_), t0)
+            plan.conv(x, self.packed_pair(plan.dtype, plan.device, x.c), 1, 0, ACT_SILU, out=y, out2=cat.slice_c(c_, c_), split=c_,
+                      name=name + (".cv1+cv2+m.0.cv1" if chain_ok else ".cv1+cv2"), chain=chain)
         else:
             y = self.cv1.emit(plan, x, out=cat.slice_c(0, c_) if nb == 0 else None, name=name + ".cv1")
         for j, b in enumerate(self.m):
-            y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}")
+            y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}", **({"t": t0} if (j == 0 and t0 is not None) else {}))
         if not fuse:
             self.cv2.emit(plan, x, out=cat.slice_c(c_, c_), name=name + ".cv2")
         return self.cv3.emit(plan, cat, out=out, name=name + ".cv3")
