@@ -221,6 +221,10 @@ int ymi_post_finish(const ymi_post_desc* d, void* stream);
  * packed per anchor: anchor q's K = num_classes + 5 outputs occupy rows q*RA .. q*RA+K-1, RA = round_up(K, 32)
  * (<= 128), remaining rows zero; cout = cout_pad = 3*RA. */
 int ymi_conv_head_decode(const ymi_conv_desc* conv, const ymi_post_desc* post, int level, void* stream);
+/* the heads of ALL pyramid levels in one launch (convs[l] = level l, same dtype and class count): the levels are
+ * independent and the coarse ones have few blocks, so one grouped launch fills the chip where three back-to-back
+ * launches leave it mostly idle.  Same records as the per-level calls. */
+int ymi_conv_head_decode_group(const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* post, void* stream);
 
 /* Stand-alone class-aware NMS on caller-provided candidates of ONE image (kept indices in
  * score-descending stable order, like torchvision.ops.batched_nms called at box_head.py:422).
@@ -247,6 +251,7 @@ int ymi_plan_add_copy_view(ymi_plan* p, const void* x, int x_cstride, int npix, 
 int ymi_plan_add_postprocess(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_add_post_begin(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_add_head_decode(ymi_plan* p, const ymi_conv_desc* conv, const ymi_post_desc* d, int level);
+int ymi_plan_add_head_decode_group(ymi_plan* p, const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* d);
 int ymi_plan_add_post_finish(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_num_ops(const ymi_plan* p);
 /* runs ops [first, last) on stream (last < 0 = all); use_graph != 0 replays a captured hipGraph */

@@ -79,6 +79,7 @@ _SIGS = {
     "ymi_postprocess": (C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
     "ymi_post_begin": (C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
     "ymi_post_finish": (C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
+    "ymi_conv_head_decode_group": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(PostDesc), C.c_void_p]),
     "ymi_conv_head_decode": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(PostDesc), C.c_int, C.c_void_p]),
     "ymi_nms_ws_bytes": (C.c_int64, [C.c_int]),
     "ymi_batched_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -91,6 +92,7 @@ _SIGS = {
     "ymi_plan_add_postprocess": (C.c_int, [C.c_void_p, C.POINTER(PostDesc)]),
     "ymi_plan_add_post_begin": (C.c_int, [C.c_void_p, C.POINTER(PostDesc)]),
     "ymi_plan_add_head_decode": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.POINTER(PostDesc), C.c_int]),
+    "ymi_plan_add_head_decode_group": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_int, C.POINTER(PostDesc)]),
     "ymi_plan_add_post_finish": (C.c_int, [C.c_void_p, C.POINTER(PostDesc)]),
     "ymi_plan_num_ops": (C.c_int, [C.c_void_p]),
     "ymi_plan_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -23,12 +23,14 @@ int postprocess_launch(const ymi_post_desc* d, hipStream_t s);
 int post_begin_launch(const ymi_post_desc* d, hipStream_t s);
 int post_finish_launch(const ymi_post_desc* d, hipStream_t s);
 int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s);
+int conv_head_decode_group_launch(const ymi_conv_desc* descs, int n_levels, const ymi_post_desc* post, hipStream_t s);
 
-enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_POST_FINISH };
+enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_HEAD_GROUP, OP_POST_FINISH };
 
 struct Op {
     OpKind kind;
     ymi_conv_desc conv;
+    ymi_conv_desc convs[YMI_MAX_LEVELS];   // OP_HEAD_GROUP: one head per pyramid level
     ymi_post_desc post;
     // generic small-op arguments
     const void* x;
@@ -45,6 +47,7 @@ static int run_op(const Op& op, hipStream_t s) {
         case OP_POST: return postprocess_launch(&op.post, s);
         case OP_POST_BEGIN: return post_begin_launch(&op.post, s);
         case OP_HEAD_DECODE: return conv_head_decode_launch(&op.conv, &op.post, op.i[0], s);
+        case OP_HEAD_GROUP: return conv_head_decode_group_launch(op.convs, op.i[0], &op.post, s);
         case OP_POST_FINISH: return post_finish_launch(&op.post, s);
     }
     set_error("unknown op kind");
@@ -169,6 +172,19 @@ extern "C" int ymi_plan_add_post_begin(ymi_plan* p, const ymi_post_desc* d) {
 extern "C" int ymi_plan_add_head_decode(ymi_plan* p, const ymi_conv_desc* conv, const ymi_post_desc* d, int level) {
     YMI_REQUIRE(p && conv && d, "ymi_plan_add_head_decode: null argument");
     return add_post_op(p, OP_HEAD_DECODE, d, conv, level);
+}
+
+extern "C" int ymi_plan_add_head_decode_group(ymi_plan* p, const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* d) {
+    YMI_REQUIRE(p && convs && d && n_levels >= 1 && n_levels <= YMI_MAX_LEVELS, "ymi_plan_add_head_decode_group: bad argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_HEAD_GROUP;
+    op.post = *d;
+    for (int l = 0; l < n_levels; ++l) op.convs[l] = convs[l];
+    op.i[0] = n_levels;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
 }
 
 extern "C" int ymi_plan_add_post_finish(ymi_plan* p, const ymi_post_desc* d) {

@@ -18,6 +18,8 @@
 //
 // Replaces: yolort/v5/models/common.py:69-70 (Conv.forward: conv2d -> BatchNorm2d -> SiLU, BN folded),
 //           common.py:115-116 (Bottleneck residual), yolort/models/box_head.py:36,74 (head conv).
+#include <string.h>
+
 #include "conv_common.hpp"
 #include "head_decode.hpp"
 
@@ -245,7 +247,7 @@ __device__ unsigned long long ymi_stamps[2048 * 128];
 // The epilogue is a functor: epi(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem) -- plain stores (StoreEpilogue)
 // or the fused detection decode of the head (head_decode.hpp).
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE, class Epi>
-__device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi) {
+__device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi, int block_id) {   // block_id: blockIdx.x, or the id within a grouped launch
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -267,7 +269,7 @@ __device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi)
     const int wave_m = (wave / WAVES_N) * WM, wave_n = (wave % WAVES_N) * WN;
 
     const int nblk = a.nblk_m * a.nblk_n;
-    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int lb = xcd_remap(block_id, nblk);
     const int bm = lb / a.nblk_n, bn = lb % a.nblk_n;
     const int m0 = bm * BM, n0 = bn * BN;
     const int nsteps = a.k_pad / BK;
@@ -535,7 +537,7 @@ struct StoreEpilogue {
 
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs a) {   // >= 2 waves per SIMD: <= 256 VGPR + AGPR
-    conv_igemm_v2_body<DT, ODT, BM, BN, WM, WN, STAGES, IS1X1, UTAP, PIPE>(a, StoreEpilogue<DT, ODT>{a});
+    conv_igemm_v2_body<DT, ODT, BM, BN, WM, WN, STAGES, IS1X1, UTAP, PIPE>(a, StoreEpilogue<DT, ODT>{a}, blockIdx.x);
 }
 
 // ---- detection head with the decode fused into the epilogue (head_decode.hpp): 128 pixels x (3 anchors x 32*TNA rows) ----
@@ -556,7 +558,33 @@ struct DecodeEpilogue {
 
 template <int DT, int TNA>
 __global__ __launch_bounds__(256) void conv_head_decode_kernel(const ConvArgs a, const HeadDecodeArgs h) {
-    conv_igemm_v2_body<DT, YMI_F32, 128, 96 * TNA, 32, 96 * TNA, HD_STAGES, false, true, true>(a, DecodeEpilogue<TNA>{a, h});
+    conv_igemm_v2_body<DT, YMI_F32, 128, 96 * TNA, 32, 96 * TNA, HD_STAGES, false, true, true>(a, DecodeEpilogue<TNA>{a, h}, blockIdx.x);
+}
+
+// every pyramid level's head in ONE launch: the levels are independent and the coarse ones have few blocks (100 for a
+// 20x20 map at batch 32), so back-to-back launches leave most of the chip idle -- block ranges select the level
+struct HeadGroupArgs {
+    ConvArgs a[YMI_MAX_LEVELS];
+    HeadDecodeArgs h[YMI_MAX_LEVELS];
+    int first_block[YMI_MAX_LEVELS + 1];
+    int n;
+};
+
+template <int DT, int TNA>
+__global__ __launch_bounds__(256) void conv_head_decode_group_kernel(const HeadGroupArgs g) {
+    // constant indices only: a runtime index into the by-value argument block would copy it to scratch
+    ConvArgs a = g.a[0];
+    HeadDecodeArgs h = g.h[0];
+    int first = g.first_block[0];
+    static_for<1, YMI_MAX_LEVELS>([&](auto lt) {
+        constexpr int l = decltype(lt)::value;
+        if (l < g.n && (int)blockIdx.x >= g.first_block[l] && (int)blockIdx.x < g.first_block[l] + g.a[l].nblk_m) {   // wave-uniform
+            a = g.a[l];
+            h = g.h[l];
+            first = g.first_block[l];
+        }
+    });
+    conv_igemm_v2_body<DT, YMI_F32, 128, 96 * TNA, 32, 96 * TNA, HD_STAGES, false, true, true>(a, DecodeEpilogue<TNA>{a, h}, (int)blockIdx.x - first);
 }
 
 template <typename K>
@@ -750,24 +778,8 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
 }
 
 
-template <int DT, int TNA>
-static int launch_head_decode(const ConvArgs& a0, const HeadDecodeArgs& h, hipStream_t s) {
-    ConvArgs a = a0;
-    constexpr int BN = 96 * TNA;
-    a.nblk_m = cdiv(a.M, 128);
-    a.nblk_n = 1;
-    size_t lds = (size_t)HD_STAGES * (128 + BN) * 64 + 16;
-    const size_t need = (size_t)HD_LDS_BYTES + 16;   // the ring doubles as the per-wave record buffers and worklists
-    if (lds < need) lds = need;
-    auto kfn = conv_head_decode_kernel<DT, TNA>;
-    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kfn, dim3(a.nblk_m), dim3(256), lds, s, a, h);
-    return check_launch("conv_head_decode_kernel");
-}
-
-// Head conv of pyramid level `level` with decode + threshold fused into the epilogue.  The descriptor's weights hold
-// every anchor's K rows padded to RA = round_up(K, 32) rows (cout = cout_pad = 3*RA); y is not written.
-int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s) {
+// validation + argument construction of one level's fused head (shared by the single and the grouped launch)
+static int head_decode_prepare(const ymi_conv_desc* d, const ymi_post_desc* post, int level, ConvArgs& a, HeadDecodeArgs& h, int& tna) {
     YMI_REQUIRE(d != nullptr && post != nullptr, "ymi_conv_head_decode: null descriptor");
     YMI_REQUIRE(level >= 0 && level < post->num_levels && post->num_levels <= YMI_MAX_LEVELS, "ymi_conv_head_decode: level %d out of range", level);
     YMI_REQUIRE(d->x && d->w && d->bias && d->zeros, "ymi_conv_head_decode: null buffer (x, w, bias and the zero page are required)");
@@ -777,7 +789,8 @@ int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, i
     YMI_REQUIRE(d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->cin % 32 == 0 && d->k_pad == d->cin,
                 "ymi_conv_head_decode: a 1x1 stride-1 convolution with cin %% 32 == 0 and k_pad == cin is required");
     YMI_REQUIRE(d->cout == 3 * ra && d->cout_pad == 3 * ra, "ymi_conv_head_decode: cout / cout_pad must be 3 x %d (anchor-padded packing)", ra);
-    YMI_REQUIRE(d->res == nullptr && d->cout_split == 0 && d->act == YMI_ACT_NONE, "ymi_conv_head_decode: no residual / second output / activation");
+    YMI_REQUIRE(d->res == nullptr && d->cout_split == 0 && d->act == YMI_ACT_NONE && d->chain_w == nullptr && d->y2_mode == 0,
+                "ymi_conv_head_decode: no residual / second output / chained conv / activation");
     YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16, "ymi_conv_head_decode: dtype must be F16 or BF16");
     YMI_REQUIRE(d->x_cstride % 8 == 0, "ymi_conv_head_decode: x_cstride must be a multiple of 8");
     YMI_REQUIRE(d->n == post->n && d->ho == post->lh[level] && d->wo == post->lw[level] && d->h == d->ho && d->w_in == d->wo,
@@ -790,30 +803,92 @@ int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, i
     YMI_REQUIRE(L.label_bits + L.anchor_bits <= 32, "ymi_conv_head_decode: candidate index exceeds 32 bits");
     const Workspace w = carve(post->ws, post->n, L.total_anchors, post->cand_cap);
     YMI_REQUIRE(post->ws_bytes >= w.total, "ymi_conv_head_decode: workspace too small");
-    ConvArgs a;
     { const int rc_args = fill_conv_args(d, a); if (rc_args != YMI_OK) return rc_args; }
-    if (a.M == 0) return YMI_OK;
-    HeadDecodeArgs h;
+    a.nblk_m = cdiv(a.M, 128);
+    a.nblk_n = 1;
     h.stride = post->stride[level];
     for (int k = 0; k < 6; ++k) h.anc[k] = post->anchors[level][k];
     h.K = K;
     h.level_off = 0;
     for (int l = 0; l < level; ++l) h.level_off += 3 * post->lh[l] * post->lw[l];
     h.sink = make_sink(post, w, L);
-    const int tna = ra / 32;
-#define YMI_HD_CASE(T)                                                                                 \
-    case T:                                                                                            \
-        return d->dtype == YMI_F16 ? launch_head_decode<YMI_F16, T>(a, h, s) : launch_head_decode<YMI_BF16, T>(a, h, s);
-    switch (tna) {
-        YMI_HD_CASE(1)
-        YMI_HD_CASE(2)
-        YMI_HD_CASE(3)
-        YMI_HD_CASE(4)
+    tna = ra / 32;
+    return YMI_OK;
+}
+
+static size_t head_decode_lds(int tna) {
+    size_t lds = (size_t)HD_STAGES * (128 + 96 * tna) * 64 + 16;
+    const size_t need = (size_t)HD_LDS_BYTES + 16;   // the ring doubles as the per-wave record buffers and worklists
+    return lds < need ? need : lds;
+}
+
+template <int DT, int TNA>
+static int launch_head_decode(const ConvArgs& a, const HeadDecodeArgs& h, hipStream_t s) {
+    const size_t lds = head_decode_lds(TNA);
+    auto kfn = conv_head_decode_kernel<DT, TNA>;
+    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kfn, dim3(a.nblk_m), dim3(256), lds, s, a, h);
+    return check_launch("conv_head_decode_kernel");
+}
+
+template <int DT, int TNA>
+static int launch_head_group(const HeadGroupArgs& g, hipStream_t s) {
+    const size_t lds = head_decode_lds(TNA);
+    auto kfn = conv_head_decode_group_kernel<DT, TNA>;
+    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kfn, dim3(g.first_block[g.n]), dim3(256), lds, s, g);
+    return check_launch("conv_head_decode_group_kernel");
+}
+
+#define YMI_HD_DISPATCH(FN, DTYPE, TNA_, ...)                                                              \
+    switch (TNA_) {                                                                                        \
+        case 1: return DTYPE == YMI_F16 ? FN<YMI_F16, 1>(__VA_ARGS__) : FN<YMI_BF16, 1>(__VA_ARGS__);     \
+        case 2: return DTYPE == YMI_F16 ? FN<YMI_F16, 2>(__VA_ARGS__) : FN<YMI_BF16, 2>(__VA_ARGS__);     \
+        case 3: return DTYPE == YMI_F16 ? FN<YMI_F16, 3>(__VA_ARGS__) : FN<YMI_BF16, 3>(__VA_ARGS__);     \
+        case 4: return DTYPE == YMI_F16 ? FN<YMI_F16, 4>(__VA_ARGS__) : FN<YMI_BF16, 4>(__VA_ARGS__);     \
     }
-#undef YMI_HD_CASE
-    set_error("ymi_conv_head_decode: unsupported anchor padding %d", ra);
+
+// Head conv of pyramid level `level` with decode + threshold fused into the epilogue.  The descriptor's weights hold
+// every anchor's K rows padded to RA = round_up(K, 32) rows (cout = cout_pad = 3*RA); y is not written.
+int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s) {
+    ConvArgs a;
+    HeadDecodeArgs h;
+    int tna = 0;
+    const int rc = head_decode_prepare(d, post, level, a, h, tna);
+    if (rc != YMI_OK) return rc;
+    if (a.M == 0) return YMI_OK;
+    YMI_HD_DISPATCH(launch_head_decode, d->dtype, tna, a, h, s)
+    set_error("ymi_conv_head_decode: unsupported anchor padding");
     return YMI_EINVAL;
 }
+
+// all levels in one launch (descs[l] belongs to level l of `post`)
+int conv_head_decode_group_launch(const ymi_conv_desc* descs, int n_levels, const ymi_post_desc* post, hipStream_t s) {
+    YMI_REQUIRE(descs != nullptr && post != nullptr && n_levels >= 1 && n_levels <= YMI_MAX_LEVELS && n_levels == post->num_levels,
+                "ymi_conv_head_decode_group: one descriptor per pyramid level of the post-process is required");
+    HeadGroupArgs g;
+    memset(&g, 0, sizeof(g));
+    g.n = n_levels;
+    int tna0 = 0, blocks = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        int tna = 0;
+        const int rc = head_decode_prepare(&descs[l], post, l, g.a[l], g.h[l], tna);
+        if (rc != YMI_OK) return rc;
+        YMI_REQUIRE(descs[l].dtype == descs[0].dtype && (l == 0 || tna == tna0), "ymi_conv_head_decode_group: levels must share dtype and class count");
+        tna0 = tna;
+    }
+    // coarse levels first: they have the longest K loops and the fewest blocks, so they should not form the tail
+    for (int l = n_levels - 1; l >= 0; --l) {
+        g.first_block[l] = blocks;
+        blocks += g.a[l].nblk_m;
+    }
+    g.first_block[n_levels] = blocks;
+    if (blocks == 0) return YMI_OK;
+    YMI_HD_DISPATCH(launch_head_group, descs[0].dtype, tna0, g, s)
+    set_error("ymi_conv_head_decode_group: unsupported anchor padding");
+    return YMI_EINVAL;
+}
+#undef YMI_HD_DISPATCH
 
 }  // namespace ymi
 
@@ -839,6 +914,10 @@ extern "C" int ymi_conv_stem_planar(const ymi_conv_desc* d, const void* const* i
     ConvArgs a;
     { const int rc_args = fill_conv_args(&dd, a); if (rc_args != YMI_OK) return rc_args; }
     return conv_stem_planar_launch(a, imgs, d->dtype, d->out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int ymi_conv_head_decode_group(const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* post, void* stream) {
+    return ymi::conv_head_decode_group_launch(convs, n_levels, post, (hipStream_t)stream);
 }
 
 extern "C" int ymi_conv_head_decode(const ymi_conv_desc* conv, const ymi_post_desc* post, int level, void* stream) {

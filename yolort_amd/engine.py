@@ -386,6 +386,24 @@ class Plan:
                      bytes=float(x.n * x.h * x.w * x.c * 2 + 3 * k_real * pc.k * 2 + x.n * x.h * x.w * 3 * 16),
                      ref_convs=1, tile=0, shape=f"{x.c}->{3 * k_real} k1x1 s1 {x.h}x{x.w} +decode")
 
+    def head_decode_group(self, xs: Sequence[View], pcs: Sequence[PackedConv], d: PostDesc, name: str = "head") -> None:
+        """the fused heads of all pyramid levels in ONE launch (ymi_conv_head_decode_group)"""
+        arr = (ConvDesc * len(xs))()
+        flops = nbytes = 0.0
+        k_real = int(d.num_classes) + 5
+        for i, (x, pc) in enumerate(zip(xs, pcs)):
+            if x.c != pc.cin or x.tail < 0:
+                raise YmiError(f"{name}: level {i} needs a plan-allocated input view matching the packed weights")
+            cd = self.conv_desc(x, pc, (1, 1), (0, 0), ACT_NONE, x, None)
+            cd.y = None
+            cd.y_cstride, cd.out_dtype = 0, dtype_code(torch.float32)
+            C.memmove(C.byref(arr, i * C.sizeof(ConvDesc)), C.byref(cd), C.sizeof(ConvDesc))
+            flops += 2.0 * x.n * x.h * x.w * 3 * k_real * pc.k_real
+            nbytes += float(x.n * x.h * x.w * x.c * 2 + 3 * k_real * pc.k * 2 + x.n * x.h * x.w * 3 * 16)
+        self.keep.append(arr)
+        self._record(self.lib.ymi_plan_add_head_decode_group(self.handle, arr, len(xs), C.byref(d)), name, kind="conv", flops=flops, bytes=nbytes,
+                     ref_convs=len(xs), tile=0, shape=f"{len(xs)} levels -> {3 * k_real} k1x1 s1 +decode (one launch)")
+
     def post_finish(self, d: PostDesc, total_anchors: int) -> None:
         self._record(self.lib.ymi_plan_add_post_finish(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0, bytes=0.0, shape=f"A={total_anchors}")
 

@@ -10,6 +10,7 @@ The training criterion `SetCriterion` (box_head.py:85-325) is out of scope (infe
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -38,6 +39,7 @@ class YOLOHead(HipModule):
             mi.bias = nn.Parameter(b.view(-1), requires_grad=True)
         self.head = blocks
         self._packed: Dict = {}
+        self.group_levels = os.environ.get("YOLORT_AMD_HEAD_GROUP", "1") != "0"   # fused heads of all levels in one launch
 
     def packed(self, i: int, dtype, device, cin_view: int) -> PackedConv:
         m = self.head[i]
@@ -78,8 +80,12 @@ class YOLOHead(HipModule):
     def emit_fused(self, plan: Plan, x: Sequence[View], post_desc) -> None:
         """head conv + decode + threshold in one kernel per level (csrc/head_decode.hpp); nothing is returned: boxes and
         candidate records land in the post-process workspace of `post_desc`"""
+        pcs = [self.packed_anchor_major(i, plan.dtype, plan.device, f.c) for i, f in enumerate(x)]
+        if self.group_levels and len(x) > 1:
+            plan.head_decode_group(list(x), pcs, post_desc, name="head.*")   # all levels in one launch
+            return
         for i, f in enumerate(x):
-            plan.head_decode(f, self.packed_anchor_major(i, plan.dtype, plan.device, f.c), post_desc, i, name=f"head.{i}")
+            plan.head_decode(f, pcs[i], post_desc, i, name=f"head.{i}")
 
     def emit(self, plan: Plan, x: Sequence[View], out=None) -> List[View]:
         """returns fp32 logits views (N,H,W,A*K) with channel a*K + k"""
