@@ -110,7 +110,7 @@ typedef struct ymi_conv_desc {
     /* optional CHAINED 1x1 convolution (Bottleneck.cv1 after C3.cv1, reference common.py:115,172): with K1 = cout_split
      * (or cout when there is no split) a second fused conv t = SiLU(chain_w * y[:, 0:K1] + chain_bias) is evaluated in
      * the epilogue from the freshly rounded outputs still in registers -- one launch instead of two and no re-read of y.
-     * chain_w: packed [round_up(chain_cout,128)][K1] like w (K1 % 32 == 0, K1 <= 64), chain_bias fp32 [chain_cout],
+     * chain_w: packed [round_up(chain_cout,128)][K1] like w (K1 in {32, 64, 128}), chain_bias fp32 [chain_cout],
      * chain_y an (n, ho, wo) view of chain_cout channels (chain_cout % 32 == 0, <= 128).  Needs act SILU, a 16-bit
      * output and a tile whose cout width equals K1 (auto tile selection takes care of it); NULL disables. */
     const void* chain_w;

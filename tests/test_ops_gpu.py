@@ -146,7 +146,7 @@ def test_conv_upsampled_second_output(dev, dtype, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("c_,tile", [(32, 0), (32, 63), (32, 76), (32, 13), (64, 0), (64, 62), (64, 72), (64, 12)])
+@pytest.mark.parametrize("c_,tile", [(32, 0), (32, 63), (32, 76), (32, 13), (64, 0), (64, 62), (64, 72), (64, 12), (64, 80), (64, 81), (128, 0), (128, 78), (128, 79)])
 def test_conv_chained_1x1(dev, dtype, c_, tile):
     """chain_w: C3.cv1+cv2 (split output) with the first Bottleneck's 1x1 evaluated in the same launch from the rounded
     outputs in registers -- all three outputs must equal the two-launch form bit for bit"""

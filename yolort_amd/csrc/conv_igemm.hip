@@ -525,7 +525,7 @@ struct StoreEpilogue {
             m = mbase + j * 32 + (lane & 31);
             ok = m < a.M;
         };
-        if constexpr (ODT == DT && TN <= 2) {   // chained 1x1 (launch checks: this wave tile spans exactly the chain's K channels)
+        if constexpr (ODT == DT && TN <= 4 && TN == (TN & -TN)) {   // chained 1x1 (launch checks: this wave tile spans exactly the chain's K channels)
             if (a.chain_w != nullptr && cbase0 == 0) {
                 finish_wave_tile_chain<DT, TN, TM>(a, acc, lane >> 5, lane, pix);
                 return;
@@ -599,7 +599,7 @@ static int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, BM);
     a.nblk_n = cdiv(a.cout_pad, BN);
-    if (a.chain_w != nullptr && !(BN == WN && BN == a.chain_k && BN <= 64)) {
+    if (a.chain_w != nullptr && !(BN == WN && BN == a.chain_k && BN <= 128)) {
         set_error("ymi_conv2d: this tile does not fit the chained 1x1 convolution (its cout width must equal %d)", a.chain_k);
         return YMI_EINVAL;
     }
@@ -641,7 +641,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         set_error("ymi_conv2d: the chained 1x1 convolution needs the pipelined implicit-GEMM kernel");
         return YMI_EINVAL;
     }
-    if (tile == 0 && a.chain_w != nullptr) tile = a.chain_k == 32 ? 3 : 2;   // 256x32 / 256x64: cout width == chain K, four waves along the pixels
+    if (tile == 0 && a.chain_w != nullptr) tile = a.chain_k == 32 ? 3 : (a.chain_k == 64 ? 2 : 78);   // cout width == chain K, four waves along the pixels
     if (tile == 0) {
         const int cp = a.cout_pad;
         if (cp <= 32) tile = 3;
@@ -685,6 +685,10 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
         case 68: return launch_v2<DT, ODT, 256, 128, 128, 64, 2, true>(a, is1x1, s);
         case 69: return launch_v2<DT, ODT, 128, 128, 64, 64, 3, true>(a, is1x1, s);    // 48 KB LDS: 3 blocks / CU
         case 70: return launch_v2<DT, ODT, 128, 64, 64, 32, 3, true>(a, is1x1, s);
+        case 78: return launch_v2<DT, ODT, 128, 128, 32, 128, 2, true>(a, is1x1, s);   // four waves along the pixels, each all 128 couts (chained 1x1, K = 128)
+        case 79: return launch_v2<DT, ODT, 128, 128, 32, 128, 3, true>(a, is1x1, s);
+        case 80: return launch_v2<DT, ODT, 128, 64, 32, 64, 2, true>(a, is1x1, s);
+        case 81: return launch_v2<DT, ODT, 128, 64, 32, 64, 3, true>(a, is1x1, s);
         case 71: return launch_v2<DT, ODT, 128, 128, 64, 64, 2, true>(a, is1x1, s);
         case 72: return launch_v2<DT, ODT, 256, 64, 64, 64, 2, true>(a, is1x1, s);
         case 73: return launch_v2<DT, ODT, 256, 32, 64, 32, 2, true>(a, is1x1, s);
@@ -751,9 +755,9 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     YMI_REQUIRE(d->y2_mode == 0 || d->y2_mode == 1, "ymi_conv2d: unknown y2_mode %d", d->y2_mode);
     if (d->chain_w != nullptr) {
         const int k1 = d->cout_split > 0 ? d->cout_split : d->cout;
-        YMI_REQUIRE(d->chain_bias && d->chain_y && (k1 == 32 || k1 == 64) && d->chain_cout % 32 == 0 && d->chain_cout >= 32 && d->chain_cout <= 128 &&
+        YMI_REQUIRE(d->chain_bias && d->chain_y && (k1 == 32 || k1 == 64 || k1 == 128) && d->chain_cout % 32 == 0 && d->chain_cout >= 32 && d->chain_cout <= 128 &&
                         d->chain_y_cstride % 8 == 0 && d->act == YMI_ACT_SILU && d->out_dtype == d->dtype && d->res == nullptr && d->y2_mode == 0 && a.zeros != nullptr,
-                    "ymi_conv2d: chained 1x1 needs chain_bias / chain_y, K1 in {32, 64}, chain_cout %% 32 == 0 (<= 128), SiLU, a 16-bit output, no residual, desc.zeros");
+                    "ymi_conv2d: chained 1x1 needs chain_bias / chain_y, K1 in {32, 64, 128}, chain_cout %% 32 == 0 (<= 128), SiLU, a 16-bit output, no residual, desc.zeros");
     }
     YMI_REQUIRE(d->y2_mode == 0 || (d->y2 != nullptr && a.split == 0 && d->cout % 32 == 0 && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0 && a.zeros != nullptr),
                 "ymi_conv2d: the upsampled second output needs y2, cout_split == 0, cout %% 32 == 0, a 16-bit output, y2_cstride %% 8 == 0 and desc.zeros");
