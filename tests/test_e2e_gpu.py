@@ -221,6 +221,25 @@ def test_stem_from_planar_equals_letterbox_path(dev, dtype):
     assert len(m.predict(odd)) == 2
 
 
+def test_planar_stem_batch_survives_capacity_growth(dev):
+    """a planar-stem batch whose candidates overflow the capacity is re-run from the planar images (the NHWC4 input
+    buffer is never filled on that path): same detections as the letterbox path with ample capacity"""
+    from yolort_amd.utils.synth import synth_images
+    imgs = [im.to(dev).half() for im in synth_images(2, 320, 320, seed=31)]
+    outs = []
+    for planar, cap in ((True, 128), (False, 1 << 16)):
+        m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.05, nms_thresh=0.45)
+        m.model.stem_from_planar = planar
+        m.model.cand_cap_per_image = cap
+        outs.append(m.predict(imgs))
+        if planar:
+            assert m.model.cand_cap_per_image > 128, "the capacity should have grown"
+    for a, b in zip(*outs):
+        assert len(a["scores"]) > 0
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), f"re-run planar batch disagrees on {k}"
+
+
 def test_mixed_sizes_and_yolo_forward(dev):
     """dynamic-shape letterbox batch + YOLO.forward on a pre-batched tensor (no rescale)."""
     from oracle import yolov5_oracle as O

@@ -3,10 +3,10 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 500 python bench.py --steps 100 --warmup 10 > gpurun_out/r01d_bench.log 2>&1; tail -1 gpurun_out/r01d_bench.log > gpurun_out/r01d_bench.json
+timeout 500 python bench.py --steps 100 --warmup 10 > gpurun_out/r01d_bench.log 2>&1; grep '^{"metric' gpurun_out/r01d_bench.log | tail -1 > gpurun_out/r01d_bench.json
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 8 --no-cpu-baseline > /tmp/b_s.log 2>&1)
 python tools/rocprof_summary.py $(find /tmp/prof_s -name "*.db" | head -1) > gpurun_out/r01d_rocprof_summary.csv
-tail -1 /tmp/b_s.log > gpurun_out/r01d_bench_under_rocprof.json
+grep '^{"metric' /tmp/b_s.log | tail -1 > gpurun_out/r01d_bench_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && YOLORT_AMD_AUTOTUNE=0 timeout 400 rocprofv3 --pmc $c -d /tmp/prof_$c -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline > /tmp/b_$c.log 2>&1)
 done
@@ -21,7 +21,8 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     nm="kernel_name" if "kernel_name" in cols else "name"
     rows=list(cur.execute(f"select {nm}, count(*), sum(value) from counters_collection where counter_name='{c}' group by {nm}"))
     conv=sum(v for n,k,v in rows if 'conv' in n)
-    nsteps=max(1, sum(k for n,k,v in rows if 'conv_head_decode' in n)//3)   # three head launches per forward pass
+    grp=sum(k for n,k,v in rows if 'conv_head_decode_group' in n)   # one grouped head launch per forward pass (else three per-level launches)
+    nsteps=max(1, grp if grp else sum(k for n,k,v in rows if 'conv_head_decode' in n)//3)
     allk=sum(v for n,k,v in rows)
     tot[c]=(conv,allk,nsteps)
     print(f"# {c}: conv kernels {conv/1024:.1f} MB total over the run, all kernels {allk/1024:.1f} MB (counter unit KB)")
@@ -32,4 +33,4 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     print(f"conv kernels (incl. fused head), autotune off, {steps} forward passes in the run (timed steps + the exclusive-conv and parity passes): FETCH_SIZE {f:.1f} MB/step raw ({2*f:.1f} MB with the gfx950 x2 correction), WRITE_SIZE {w:.1f} MB/step")
 PY
 cat gpurun_out/r01d_conv_traffic.txt | tail -3
-tail -1 gpurun_out/r01d_bench.json | cut -c1-400
+cut -c1-400 gpurun_out/r01d_bench.json

@@ -55,9 +55,11 @@ class PendingDetections:
     """Handle of an in-flight batch (YOLO.submit / YOLOv5.forward_async); `.result()` blocks on its
     completion event only -- later batches keep running on the GPU meanwhile."""
 
-    def __init__(self, owner: "YOLO", entry: _PlanEntry, rows, hook_result=None):
+    def __init__(self, owner: "YOLO", entry: _PlanEntry, rows, hook_result=None, planar=None):
         self.owner, self.entry, self.rows, self.hook_result = owner, entry, rows, hook_result
         self.event = entry.done
+        # planar input images when the stem read them directly (entry.x was never filled): a redo must start from them
+        self.planar = planar
 
     def result(self) -> List[Dict[str, Tensor]]:
         if self.hook_result is not None:
@@ -68,13 +70,13 @@ class PendingDetections:
         if host[1] & 2 and not host[1] & 1:   # the score prefix of a crowded image gave < detections_per_img survivors: exact full pass
             if os.environ.get("YOLORT_AMD_VERBOSE"):
                 print("[yolort_amd] score-prefix selection fell short: re-running with the full candidate set", flush=True)
-            return self.owner._redo_exact_full(e, self.rows)
+            return self.owner._redo_exact_full(e, self.rows, self.planar)
         if host[1] != 0:   # candidate capacity exceeded (nothing truncated): grow, rebuild, redo synchronously
             n = e.x.n
             per_image = host[3] if host[3] > 0 else (host[0] + n - 1) // n   # status[3]: largest per-image count (per-image sort path)
             if os.environ.get("YOLORT_AMD_VERBOSE"):
                 print(f"[yolort_amd] candidate capacity {self.owner.cand_cap_per_image}/image exceeded (status {host[:4]}): growing", flush=True)
-            return self.owner._redo_with_capacity(e, self.rows, per_image)
+            return self.owner._redo_with_capacity(e, self.rows, per_image, self.planar)
         p = e.post
         return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), host[4:])
 
@@ -173,7 +175,7 @@ class YOLO(nn.Module):
                 post = plan.postprocess(logits, strides, ag.anchor_grids, *args, rescale=rescale, flags=flags)
         return _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
 
-    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]], first_op: int = 0, ev0=None) -> PendingDetections:
+    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]], first_op: int = 0, ev0=None, planar=None) -> PendingDetections:
         """input view already filled on the current stream; enqueues the plan and returns a handle.
         Conv stack on the current stream, post-process + result copy on the entry's side stream, so
         the next batch's convolutions overlap this batch's sort/NMS (few, long-running waves)."""
@@ -211,7 +213,7 @@ class YOLO(nn.Module):
         e.done.record(side)
         if self.pipeline_depth <= 1:
             main.wait_event(e.done)
-        return PendingDetections(self, e, rescale_rows)
+        return PendingDetections(self, e, rescale_rows, planar=planar)
 
     def _acquire(self, n: int, h: int, w: int, device: torch.device) -> _PlanEntry:
         """next plan instance of the ring for this shape; waits (on the GPU, not the host) until the
@@ -222,7 +224,22 @@ class YOLO(nn.Module):
             e.main_stream.wait_event(e.done)
         return e
 
-    def _redo_with_capacity(self, e: _PlanEntry, rescale_rows, needed_per_image: int) -> List[Dict[str, Tensor]]:
+    def _resubmit(self, e_old: _PlanEntry, rescale_rows, planar) -> List[Dict[str, Tensor]]:
+        """re-run a batch synchronously on a (re)built plan instance: from the planar images when the stem read those
+        directly (the NHWC4 buffer of the old entry was never filled then), else from the old entry's input buffer"""
+        x_old = e_old.x
+        torch.cuda.synchronize()
+        e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
+        with torch.cuda.stream(e2.main_stream):
+            if planar is not None and e2.plan.stem_planar_ok(planar, (x_old.h, x_old.w)):
+                e2.plan.stem_from_planar(planar)
+                return self._submit_entry(e2, rescale_rows, 1, planar=planar).result()
+            if planar is not None:
+                raise YmiError("internal: a planar-stem batch cannot be re-run on a plan without the planar stem")
+            e2.x.base.copy_(x_old.base)
+            return self._submit_entry(e2, rescale_rows).result()
+
+    def _redo_with_capacity(self, e: _PlanEntry, rescale_rows, needed_per_image: int, planar=None) -> List[Dict[str, Tensor]]:
         # per-image regions are powers of two (the kernel rounds the capacity DOWN to one): grow to the next power
         # of two that holds the largest image.  Batches submitted before an earlier growth land here too and
         # simply re-run on the already grown plan.
@@ -230,21 +247,11 @@ class YOLO(nn.Module):
         if needed_per_image > cap_eff or e.post.cand_cap >= self.cand_cap_per_image * e.x.n:
             want = max(int(needed_per_image * 1.25) + 1024, 2 * cap_eff)
             self.cand_cap_per_image = 1 << (want - 1).bit_length()
-        x_old = e.x
-        torch.cuda.synchronize()
-        e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
-        with torch.cuda.stream(e2.main_stream):
-            e2.x.base.copy_(x_old.base)
-            return self._submit_entry(e2, rescale_rows).result()
+        return self._resubmit(e, rescale_rows, planar)
 
-    def _redo_exact_full(self, e: _PlanEntry, rescale_rows) -> List[Dict[str, Tensor]]:
+    def _redo_exact_full(self, e: _PlanEntry, rescale_rows, planar=None) -> List[Dict[str, Tensor]]:
         self.post_exact_full = True
-        x_old = e.x
-        torch.cuda.synchronize()
-        e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
-        with torch.cuda.stream(e2.main_stream):
-            e2.x.base.copy_(x_old.base)
-            return self._submit_entry(e2, rescale_rows).result()
+        return self._resubmit(e, rescale_rows, planar)
 
     def _run_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]]) -> List[Dict[str, Tensor]]:
         return self._submit_entry(e, rescale_rows).result()

@@ -82,10 +82,10 @@ class YOLOv5(nn.Module):
             first_op = 1 if planar else 0
             rows = [rescale_params((hb, wb), o) for o in original]
             if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
-                pend = model._submit_entry(e, None, first_op, ev0)
+                pend = model._submit_entry(e, None, first_op, ev0, planar=images if planar else None)
                 pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
                 return pend
-            return model._submit_entry(e, rows, first_op, ev0)
+            return model._submit_entry(e, rows, first_op, ev0, planar=images if planar else None)
 
     @torch.no_grad()
     def predict(self, x: Any, image_loader: Optional[Callable] = None) -> List[Dict[str, Tensor]]:
