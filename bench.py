@@ -312,6 +312,12 @@ def main():
             out["parity"] = parity_sample(model, images_gpu, images_cpu, sd_cpu, args.score_thresh)
             out["cpu_baseline"] = cpu_baseline(args.arch, sd_cpu, images_cpu, args.score_thresh)
         if args.per_op:
+            # the per-op profile replays the recorded plan from its NHWC4 input buffer: fill it through the letterbox
+            # path first (identity-size batches normally feed the stem from the planar images and never touch it)
+            yolo.stem_from_planar = False
+            collect(model.forward_async(images_gpu))
+            torch.cuda.synchronize()
+            e = next(iter(yolo._entries.values()))
             prof = e.plan.profile(iters=5)
             with open(args.per_op, "w") as f:
                 json.dump([{"name": n, "ms": ms, **meta} for n, ms, meta in prof], f, indent=1)
