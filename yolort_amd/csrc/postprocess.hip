@@ -289,8 +289,15 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* hi_i
 constexpr int IMG_SORT_MAX = 16384;
 
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, int np2) {
+    // Compare-exchange steps with distance j < chunk stay inside one wave's contiguous chunk of the array, so they need
+    // no block-wide barrier (the wave's own LDS accesses are ordered): with 16 waves on 4096 keys that is 68 of the 78
+    // steps -- the sort was barrier-latency bound (~1.5 us per __syncthreads of 16 waves), not work bound.
+    const int nwaves = blockDim.x >> 6;
+    const int chunk = np2 / nwaves >= 128 ? np2 / nwaves : 0;   // keys per wave (power of two); tiny arrays: block steps only
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int k = 2; k <= np2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+        int j = k >> 1;
+        for (; j > 0 && j >= chunk; j >>= 1) {   // partners in other waves' chunks
             for (int i = threadIdx.x; i < np2; i += blockDim.x) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
@@ -300,6 +307,23 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, int np2) {
                 }
             }
             __syncthreads();
+        }
+        if (j > 0) {                              // the remaining distances: this wave sorts within its own chunk
+            uint64_t* mine = key + wave * chunk;
+            const int base = wave * chunk;
+            for (; j > 0; j >>= 1) {
+                for (int t = lane; t < chunk; t += 64) {
+                    const int txj = t ^ j;
+                    if (txj > t) {
+                        const uint64_t x = mine[t], y = mine[txj];
+                        const bool asc = ((base + t) & k) == 0;
+                        if ((x > y) == asc) { mine[t] = y; mine[txj] = x; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();                      // next phase starts with cross-chunk distances (or the sort is done)
         }
     }
 }
@@ -445,23 +469,54 @@ __global__ __launch_bounds__(1024) void sort_image_kernel(uint64_t* in_hi, uint3
     const int img = blockIdx.x;
     const int raw = img_count[img];
     const int n_i = sel_count[img];   // records that take part (== min(raw, cap_img) unless the prefix selection cut the image)
+    if (threadIdx.x < 64) {   // first wave: offset of this image in the compact arrays = sum of the counts before it
+        int part = 0;
+        for (int j = threadIdx.x; j < img; j += 64) part += sel_count[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (threadIdx.x == 0) s_off = part;
+    }
     if (threadIdx.x == 0) {
-        int off = 0;
-        for (int j = 0; j < img; ++j) off += sel_count[j];
-        s_off = off;
         atomicAdd(&status[ST_NCAND], n_i);
         if (raw > cap_img) { atomicOr(&status[ST_OVERFLOW], YMI_STATUS_OVERFLOW_CAPACITY); atomicMax(&status[ST_RSV], raw); }
     }
     const int64_t base = (int64_t)img * cap_img;
     uint64_t* keys = in_hi + base;      // this image's region doubles as key scratch (u64 per record)
     uint32_t* rank = in_lo + base;      // ... and as rank scratch once the candidate ids moved into the keys
+    const uint32_t lmask = (1u << label_bits) - 1u;
+    if (n_i <= lds_keys) {
+        // single run (the common case after the prefix selection): both sorts stay in LDS, HBM is touched only to read
+        // the records once and to write G and P -- no scratch round trips between the phases
+        __syncthreads();   // s_off
+        const int off = s_off;
+        int np2 = 64;
+        while (np2 < n_i) np2 <<= 1;
+        for (int i = threadIdx.x; i < np2; i += blockDim.x)
+            lds_key[i] = i < n_i ? (((uint64_t)(uint32_t)keys[i] << 32) | rank[i]) : ~0ull;   // ~score << 32 | cand; padding sorts last
+        __syncthreads();
+        bitonic_sort_lds(lds_key, np2);   // G order: score descending, ties by candidate index
+        for (int i = threadIdx.x; i < n_i; i += blockDim.x) {
+            const uint64_t k = lds_key[i];
+            ghi[off + i] = ((uint64_t)(unsigned)img << 32) | (k >> 32);
+            glo[off + i] = (uint32_t)k;
+            keep[off + i] = 0;
+            lds_key[i] = ((uint64_t)((uint32_t)k & lmask) << 32) | (uint32_t)i;   // label << 32 | rank in G (same index read / written)
+        }
+        __syncthreads();
+        bitonic_sort_lds(lds_key, np2);   // P order: by label, then by G rank
+        for (int i = threadIdx.x; i < n_i; i += blockDim.x) {
+            const uint64_t k = lds_key[i];
+            phi[off + i] = ((uint64_t)(unsigned)img << 16) | (k >> 32);
+            plo[off + i] = (uint32_t)off + (uint32_t)k;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n_i; i += blockDim.x)
         keys[i] = ((uint64_t)(uint32_t)keys[i] << 32) | rank[i];   // ~score << 32 | cand  (same index read / written)
     __syncthreads();
     const int off = s_off;
     // G order: score descending, ties by candidate index
     sort_runs(keys, n_i, lds_key, lds_keys, rank);
-    const uint32_t lmask = (1u << label_bits) - 1u;
     for (int i = threadIdx.x; i < n_i; i += blockDim.x) {
         const uint64_t k = keys[i];
         const uint32_t r = rank[i];
