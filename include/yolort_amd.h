@@ -117,6 +117,12 @@ typedef struct ymi_conv_desc {
     const float* chain_bias;
     void* chain_y;
     int32_t chain_cout, chain_y_cstride;
+    /* chained conv over a CONCAT (C3.cv3 after the last Bottleneck, common.py:173): its input channels are the K1 fresh
+     * outputs followed by chain_k2 channels read from the (n, ho, wo) view chain_x2 (the other half of the concat buffer);
+     * chain_w rows then hold K1 + chain_k2 weights.  chain_k2 % 16 == 0, <= 128; 0 / NULL = fresh outputs only.  With a
+     * second source the producing conv may carry a residual and may be a 3x3 (LDS-halo variants with pixel-major waves). */
+    const void* chain_x2;
+    int32_t chain_x2_cstride, chain_k2;
     /* >= 256 readable zero bytes in device memory within +-4 GiB of x (e.g. the tail of x's own
      * buffer): source of out-of-image / out-of-range activation chunks for the direct-to-LDS loads of
      * the pipelined kernel, which also requires the packed weight ROWS to be zero-padded to a

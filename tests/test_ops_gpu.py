@@ -178,6 +178,44 @@ def test_conv_chained_1x1(dev, dtype, c_, tile):
     assert (t.as_tensor().float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < (6e-2 if dtype == torch.bfloat16 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("c_,tile,residual", [(32, 0, True), (32, 33, True), (32, 36, False), (32, 76, True), (64, 0, True), (64, 37, True), (64, 62, False), (64, 81, True)])
+def test_conv_chained_over_concat(dev, dtype, c_, tile, residual):
+    """C3.cv3 chained to the last Bottleneck.cv2 (3x3 + shortcut): the 1x1 over [fresh outputs | other half of the concat
+    buffer] is evaluated in the 3x3 launch's epilogue -- outputs bit-identical to the two-launch form (halo and implicit-GEMM producers)"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(61 + c_)
+    n, h, w = 2, 21, 19
+    x = torch.randn(n, c_, h, w, generator=g).to(dtype).float()
+    w1 = (torch.randn(c_, c_, 3, 3, generator=g) / (3 * c_ ** 0.5)).to(dtype).float()
+    b1 = torch.randn(c_, generator=g) * 0.1
+    w3 = (torch.randn(2 * c_, 2 * c_, 1, 1, generator=g) / (2 * c_) ** 0.5).to(dtype).float()
+    b3 = torch.randn(2 * c_, generator=g) * 0.1
+    plan = engine.Plan(dev, dtype)
+    xv = plan.alloc(n, h, w, c_)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, dtype))
+    rv = plan.alloc(n, h, w, c_)
+    rv.as_tensor().normal_()
+    pc1 = engine.PackedConv(w1, b1, None, dtype, dev)
+    pc3 = engine.PackedConv(w3, b3, None, dtype, dev)
+    cat_r, cat = plan.alloc(n, h, w, 2 * c_), plan.alloc(n, h, w, 2 * c_)
+    cat_r.as_tensor().normal_()
+    cat.as_tensor().copy_(cat_r.as_tensor())
+    # two launches (same producer tile: halo and implicit-GEMM kernels accumulate K in different orders for cin > 32)
+    plan.conv(xv, pc1, 1, 1, out=cat_r.slice_c(0, c_), res=rv if residual else None, tile=tile)
+    o_r = plan.conv(cat_r, pc3, 1, 0)
+    # one launch
+    o = plan.alloc(n, h, w, 2 * c_)
+    plan.conv(xv, pc1, 1, 1, out=cat.slice_c(0, c_), res=rv if residual else None, chain=(pc3, o, cat.slice_c(c_, c_)), tile=tile)
+    plan.run()
+    if tile != 0:
+        assert torch.equal(cat.as_tensor(), cat_r.as_tensor())
+        assert torch.equal(o.as_tensor(), o_r.as_tensor())
+    else:   # autotuned producers may differ between the two forms: fp32 accumulation order only
+        assert (cat.as_tensor().float() - cat_r.as_tensor().float()).abs().max().item() < 2e-2
+        assert (o.as_tensor().float() - o_r.as_tensor().float()).abs().max().item() < (8e-2 if dtype == torch.bfloat16 else 2e-2)
+
+
 def test_conv_views_and_residual(dev):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=20, w=20, k=3, s=1, p=1, residual=True, x_cs_extra=64, y_cs_extra=128)
     _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)

@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("y2", C.c_void_p), ("y2_cstride", C.c_int32), ("cout_split", C.c_int32),
         ("y2_mode", C.c_int32), ("reserved0", C.c_int32),
         ("chain_w", C.c_void_p), ("chain_bias", C.c_void_p), ("chain_y", C.c_void_p), ("chain_cout", C.c_int32), ("chain_y_cstride", C.c_int32),
+        ("chain_x2", C.c_void_p), ("chain_x2_cstride", C.c_int32), ("chain_k2", C.c_int32),
         ("zeros", C.c_void_p),
     ]
 

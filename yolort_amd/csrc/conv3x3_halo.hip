@@ -175,11 +175,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a, 
     }
 
     // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
-    finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, [&](int j, int64_t& m, bool& ok) {
+    auto pix = [&](int j, int64_t& m, bool& ok) {
         const int oy = oy0 + 2 * (wave_m / 32 + j) + ((lane >> 4) & 1), ox = ox0 + (lane & 15);
         ok = oy < a.ho && ox < a.wo;
         m = ((int64_t)img * a.ho + oy) * a.wo + ox;
-    });
+    };
+    if constexpr (ODT == DT && BN == WN && TN <= 2) {   // pixel-major waves: a chained 1x1 (C3.cv3) can run from the outputs in registers
+        if (a.chain_w != nullptr) {
+            finish_wave_tile_chain<DT, TN, TM>(a, acc, lane >> 5, lane, pix);
+            return;
+        }
+    }
+    finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, pix);
 }
 
 template <int DT, int ODT, int BN, int WM, int WN, int STAGES>
@@ -213,6 +220,10 @@ int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant
     YMI_REQUIRE(a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.cin % 32 == 0 && a.zeros != nullptr && a.split == 0,
                 "ymi_conv2d: the LDS-halo kernel handles 3x3 stride-1 pad-1 convolutions with cin %% 32 == 0 (and needs desc.zeros)");
     YMI_REQUIRE(a.k_pad == 9 * a.cin, "ymi_conv2d: halo kernel expects k_pad == 9*cin");
+    if (a.chain_w != nullptr) {   // chained conv: pixel-major variants only, cout width == the chain's fresh K
+        const int bn = (variant == 3 || variant == 6) ? 32 : (variant == 7 ? 64 : 0);
+        YMI_REQUIRE(bn != 0 && bn == a.chain_k && a.cout_pad == bn, "ymi_conv2d: this halo variant does not fit the chained convolution (cout width must equal %d)", a.chain_k);
+    }
     if (dtype == YMI_F16) return out_dtype == YMI_F32 ? halo_variant<YMI_F16, YMI_F32>(a, variant, s) : halo_variant<YMI_F16, YMI_F16>(a, variant, s);
     return out_dtype == YMI_F32 ? halo_variant<YMI_BF16, YMI_F32>(a, variant, s) : halo_variant<YMI_BF16, YMI_BF16>(a, variant, s);
 }

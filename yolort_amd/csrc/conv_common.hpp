@@ -45,6 +45,8 @@ struct ConvArgs {
     const float* chain_bias;
     void* chain_y;
     int chain_k, chain_cout, chain_y_cs;
+    const uint16_t* chain_x2;  // second K range of the chained conv: chain_k2 channels per pixel read from this view (NULL / 0 = none)
+    int chain_x2_cs, chain_k2;
     int up2;       // 1: y2 is an (n, 2ho, 2wo) view receiving every output channel nearest-upsampled x2 (split == 0)
     const uint16_t* zeros;
     int x_zero_off;    // (zeros - x) in elements: out-of-range activation chunks read x + x_zero_off
@@ -264,25 +266,51 @@ __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16
 template <int DT, int TN, int TM, class PixFn>
 __device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int hi, int lane, PixFn&& pix) {
     typedef typename Mfma<DT>::frag frag;
+    constexpr int S2MAX = 8;   // second-source k16 steps (chain_k2 <= 128)
     int64_t m[TM];
     bool m_ok[TM];
     u32x4 fr[TM][TN][2];
     const u32x2 none[4] = {};
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        pix(j, m[j], m_ok[j]);
+    for (int j = 0; j < TM; ++j) pix(j, m[j], m_ok[j]);
+    if (a.res != nullptr) {   // wave-uniform: the producer is a Bottleneck.cv2 with its shortcut
+        u32x2 rv[TM][TN][4];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) finish_subtile<DT, DT, false>(a, acc[i][j], m[j], m_ok[j], i * 32, hi, none, 0, fr[j][i]);
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) load_residual(a, m[j], m_ok[j], i * 32, hi, rv[j][i]);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) finish_subtile<DT, DT, true>(a, acc[i][j], m[j], m_ok[j], i * 32, hi, rv[j][i], 0, fr[j][i]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) finish_subtile<DT, DT, false>(a, acc[i][j], m[j], m_ok[j], i * 32, hi, none, 0, fr[j][i]);
     }
+    // second K range: 8 channels per lane and k16 step straight from the other tensor (zeros for pixels past the end)
+    const int s2n = a.chain_x2 != nullptr ? a.chain_k2 >> 4 : 0;   // wave-uniform
+    u32x4 xr[TM][S2MAX];
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < S2MAX; ++s2) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            xr[j][s2] = z;
+            if (s2 < s2n && m_ok[j]) xr[j][s2] = *reinterpret_cast<const u32x4*>(a.chain_x2 + m[j] * a.chain_x2_cs + 16 * s2 + 8 * hi);
+        }
     ConvArgs a2 = a;   // output side of the chained conv
     a2.y = a.chain_y; a2.y_cs = a.chain_y_cs; a2.cout = a.chain_cout; a2.cout_pad = a.chain_cout; a2.split = 0; a2.up2 = 0; a2.res = nullptr;
+    const int ktot = a.chain_k + (a.chain_x2 != nullptr ? a.chain_k2 : 0);
     const int tn2 = a.chain_cout >> 5;   // 1..4 (wave-uniform)
     for (int i2 = 0; i2 < tn2; ++i2) {
-        // weight fragments of cout rows i2*32 + (lane & 31), all 2*TN k16-steps
-        frag wf[2 * TN];
-        const uint16_t* wr = a.chain_w + (int64_t)(i2 * 32 + (lane & 31)) * a.chain_k + 8 * hi;
+        // weight fragments of cout rows i2*32 + (lane & 31): 2*TN k16-steps for the fresh outputs, then the second source's
+        frag wf[2 * TN + S2MAX];
+        const uint16_t* wr = a.chain_w + (int64_t)(i2 * 32 + (lane & 31)) * ktot + 8 * hi;
 #pragma unroll
-        for (int s2 = 0; s2 < 2 * TN; ++s2) wf[s2] = *reinterpret_cast<const frag*>(wr + 16 * s2);
+        for (int s2 = 0; s2 < 2 * TN + S2MAX; ++s2)
+            if (s2 < 2 * TN + s2n) wf[s2] = *reinterpret_cast<const frag*>(wr + 16 * s2);
         f32x4 b2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) b2[g] = *reinterpret_cast<const f32x4*>(a.chain_bias + i2 * 32 + g * 8 + hi * 4);
@@ -299,6 +327,13 @@ __device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const 
                 __builtin_memcpy(&xf, &fr[j][s2 >> 1][s2 & 1], 16);
                 acc2 = Mfma<DT>::run(wf[s2], xf, acc2);
             }
+#pragma unroll
+            for (int s2 = 0; s2 < S2MAX; ++s2)
+                if (s2 < s2n) {
+                    frag xf;
+                    __builtin_memcpy(&xf, &xr[j][s2], 16);
+                    acc2 = Mfma<DT>::run(wf[2 * TN + s2], xf, acc2);
+                }
             finish_subtile<DT, DT, false>(a2, acc2, m[j], m_ok[j], i2 * 32, hi, none);
         }
     }

@@ -637,7 +637,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile >= 0x100) { a.debug = tile >> 8; tile &= 0xff; }
     const bool force_v1 = tile < 0;
     if (force_v1) tile = -tile == 100 ? 0 : -tile;   // negative tile ids force the register-staged kernel (-100 = auto)
-    if (a.chain_w != nullptr && (force_v1 || (tile >= 1 && tile <= 5 && a.zeros == nullptr) || (tile >= 31 && tile <= 41))) {
+    if (a.chain_w != nullptr && (force_v1 || (tile >= 1 && tile <= 5 && a.zeros == nullptr) || tile == 41)) {
         set_error("ymi_conv2d: the chained 1x1 convolution needs the pipelined implicit-GEMM kernel");
         return YMI_EINVAL;
     }
@@ -717,6 +717,7 @@ static int fill_conv_args(const ymi_conv_desc* d, ConvArgs& a) {
     a.up2 = d->y2_mode == 1 ? 1 : 0;
     a.chain_w = (const uint16_t*)d->chain_w; a.chain_bias = d->chain_bias; a.chain_y = d->chain_y;
     a.chain_cout = d->chain_cout; a.chain_y_cs = d->chain_y_cstride; a.chain_k = d->cout_split > 0 ? d->cout_split : d->cout;
+    a.chain_x2 = (const uint16_t*)d->chain_x2; a.chain_x2_cs = d->chain_x2_cstride; a.chain_k2 = d->chain_x2 != nullptr ? d->chain_k2 : 0;
     a.kh = d->kh; a.kw = d->kw; a.x_zero_off = 0;
     auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
     a.magic_hw = magic(d->ho * d->wo);
@@ -756,8 +757,11 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     if (d->chain_w != nullptr) {
         const int k1 = d->cout_split > 0 ? d->cout_split : d->cout;
         YMI_REQUIRE(d->chain_bias && d->chain_y && (k1 == 32 || k1 == 64 || k1 == 128) && d->chain_cout % 32 == 0 && d->chain_cout >= 32 && d->chain_cout <= 128 &&
-                        d->chain_y_cstride % 8 == 0 && d->act == YMI_ACT_SILU && d->out_dtype == d->dtype && d->res == nullptr && d->y2_mode == 0 && a.zeros != nullptr,
-                    "ymi_conv2d: chained 1x1 needs chain_bias / chain_y, K1 in {32, 64, 128}, chain_cout %% 32 == 0 (<= 128), SiLU, a 16-bit output, no residual, desc.zeros");
+                        d->chain_y_cstride % 8 == 0 && d->act == YMI_ACT_SILU && d->out_dtype == d->dtype && d->y2_mode == 0 && a.zeros != nullptr,
+                    "ymi_conv2d: chained 1x1 needs chain_bias / chain_y, K1 in {32, 64, 128}, chain_cout %% 32 == 0 (<= 128), SiLU, a 16-bit output, desc.zeros");
+        YMI_REQUIRE(d->chain_x2 == nullptr || (d->chain_k2 % 16 == 0 && d->chain_k2 >= 16 && d->chain_k2 <= 128 && d->chain_x2_cstride % 8 == 0 && d->cout_split == 0),
+                    "ymi_conv2d: chained conv second source: chain_k2 %% 16 == 0 (16..128), chain_x2_cstride %% 8 == 0, no channel split");
+        YMI_REQUIRE(d->res == nullptr || d->chain_x2 != nullptr || true, "ymi_conv2d: internal");
     }
     YMI_REQUIRE(d->y2_mode == 0 || (d->y2 != nullptr && a.split == 0 && d->cout % 32 == 0 && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0 && a.zeros != nullptr),
                 "ymi_conv2d: the upsampled second output needs y2, cout_split == 0, cout %% 32 == 0, a 16-bit output, y2_cstride %% 8 == 0 and desc.zeros");

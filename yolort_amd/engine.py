@@ -142,6 +142,9 @@ class Plan:
         self.zeros = torch.zeros(1024, device=device, dtype=torch.uint8)
         self.conv_descs: Dict[int, ConvDesc] = {}
         self.chain_1x1 = os.environ.get("YOLORT_AMD_CHAIN", "1") != "0"   # Bottleneck.cv1 chained into C3.cv1+cv2's launch
+        # C3.cv3 chained into the last Bottleneck.cv2's launch (ymi_conv_desc.chain_x2): supported and tested, but measured
+        # +-0 end to end (the pixel-major producer tiles it needs cost what the saved launch gains) -> off by default
+        self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
         # per-shape tile selection by measurement at plan-build time ("measure, don't guess"): each conv is
         # timed once per candidate tile on its real buffers with HIP events; winners are cached per shape
@@ -208,13 +211,14 @@ class Plan:
     def conv(self, x: View, pc: PackedConv, stride: int | Tuple[int, int] = 1, pad: int | Tuple[int, int] = 0, act: int = ACT_SILU,
              out: Optional[View] = None, res: Optional[View] = None, out_dtype: Optional[torch.dtype] = None, name: str = "conv", tile: int = 0,
              out2: Optional[View] = None, split: int = 0, up2_out: Optional[View] = None,
-             chain: Optional[Tuple[PackedConv, View]] = None) -> View:
+             chain: Optional[Tuple] = None) -> View:
         """`out2`/`split`: output channels [split, cout) are written to view `out2` instead of `out`
         (one launch feeding two consumers of the same input, e.g. C3.cv1 + C3.cv2).
         `up2_out`: an (n, 2ho, 2wo, cout) view that additionally receives the whole output nearest-upsampled x2
         (the PAN's nn.Upsample folded into its producer; needs cout % 32 == 0).
         `chain` = (packed 1x1 conv, output view): a second conv on the first `split` (or all) output channels, evaluated in
-        this launch's epilogue from registers (Bottleneck.cv1 chained to C3.cv1; K in {32, 64})."""
+        this launch's epilogue from registers (Bottleneck.cv1 chained to C3.cv1; K in {32, 64}).  A third element
+        `x2` (view) makes it a conv over the concat [fresh outputs | x2] (C3.cv3 chained to the last Bottleneck.cv2)."""
         s = (stride, stride) if isinstance(stride, int) else tuple(stride)
         p = (pad, pad) if isinstance(pad, int) else tuple(pad)
         if pc.stem_superpixel:
@@ -241,12 +245,17 @@ class Plan:
         else:
             d = self.conv_desc(x, pc, s, p, act, out, res, tile, out2, split)
         if chain is not None:
-            pc2, tv = chain
+            pc2, tv = chain[0], chain[1]
+            x2 = chain[2] if len(chain) > 2 else None
             k1 = split if out2 is not None else pc.cout
-            if pc2.kh != 1 or pc2.kw != 1 or pc2.cin != k1 or pc2.k_pad != k1 or (tv.n, tv.h, tv.w, tv.c) != (x.n, ho, wo, pc2.cout) or up2_out is not None:
-                raise YmiError(f"{name}: chained conv must be a 1x1 over the first {k1} output channels with a matching output view")
+            k2 = 0 if x2 is None else x2.c
+            if (pc2.kh != 1 or pc2.kw != 1 or pc2.cin != k1 + k2 or pc2.k_pad != k1 + k2 or (tv.n, tv.h, tv.w, tv.c) != (x.n, ho, wo, pc2.cout) or up2_out is not None
+                    or (x2 is not None and ((x2.n, x2.h, x2.w) != (x.n, ho, wo) or out2 is not None or k2 % 16))):
+                raise YmiError(f"{name}: chained conv must be a 1x1 over the first {k1} output channels (+ the second source's) with matching views")
             d.chain_w, d.chain_bias, d.chain_y = pc2.w.data_ptr(), pc2.bias.data_ptr(), tv.ptr
             d.chain_cout, d.chain_y_cstride = pc2.cout, tv.cs
+            if x2 is not None:
+                d.chain_x2, d.chain_x2_cstride, d.chain_k2 = x2.ptr, x2.cs, k2
             self.keep.append(pc2)
         self.conv_descs[self.num_ops] = d   # op index -> descriptor (the fused stem path re-issues op 0 from planar images)
         if self.autotune and tile == 0 and d.zeros:

@@ -62,10 +62,11 @@ class Conv(HipModule):
         self._packed[key] = (sig, pc)
         return pc
 
-    def emit(self, plan: Plan, x: View, out: Optional[View] = None, res: Optional[View] = None, name: str = "conv", up2_out: Optional[View] = None) -> View:
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, res: Optional[View] = None, name: str = "conv", up2_out: Optional[View] = None,
+             chain=None) -> View:
         pc = self.packed(plan.dtype, plan.device, x.c)
         act = ACT_SILU if isinstance(self.act, nn.SiLU) else ACT_NONE
-        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act, out=out, res=res, name=name, up2_out=up2_out)
+        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act, out=out, res=res, name=name, up2_out=up2_out, chain=chain)
 
 
 class Bottleneck(HipModule):
@@ -78,10 +79,11 @@ class Bottleneck(HipModule):
         self.cv2 = Conv(c_, c2, 3, 1, g=g, version=version)
         self.add = shortcut and c1 == c2
 
-    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck", t: Optional[View] = None) -> View:
-        """`t`: cv1's output when the producer of x already computed it (chained 1x1, see C3.emit)"""
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck", t: Optional[View] = None, chain=None) -> View:
+        """`t`: cv1's output when the producer of x already computed it (chained 1x1, see C3.emit);
+        `chain`: a conv chained to cv2's output (C3.cv3 over the concat), passed through to Plan.conv"""
         y = t if t is not None else self.cv1.emit(plan, x, name=name + ".cv1")
-        return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + ".cv2")
+        return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + (".cv2+cv3" if chain is not None else ".cv2"), chain=chain)
 
 
 class C3(HipModule):
@@ -133,10 +135,25 @@ class C3(HipModule):
                       name=name + (".cv1+cv2+m.0.cv1" if chain_ok else ".cv1+cv2"), chain=chain)
         else:
             y = self.cv1.emit(plan, x, out=cat.slice_c(0, c_) if nb == 0 else None, name=name + ".cv1")
+        # cv3 over the concat [last Bottleneck output | cv2(x)] rides in the last Bottleneck's 3x3 launch: its first K range is
+        # that launch's rounded output in registers, the second is read from the concat buffer's other half
+        c2 = self.cv3.conv.out_channels
+        chain3 = None
+        if (fuse and plan.chain_1x1 and plan.chain_cv3 and nb >= 1 and c_ in (32, 64) and c2 % 32 == 0 and c2 <= 128 and isinstance(self.cv3.act, nn.SiLU)
+                and isinstance(self.m[nb - 1], Bottleneck) and self.m[nb - 1].cv2.conv.kernel_size == (3, 3) and self.m[nb - 1].cv2.conv.out_channels == c_):
+            o3 = out if out is not None else plan.alloc(x.n, x.h, x.w, c2)
+            chain3 = (self.cv3.packed(plan.dtype, plan.device, 2 * c_), o3, cat.slice_c(c_, c_))
         for j, b in enumerate(self.m):
-            y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}", **({"t": t0} if (j == 0 and t0 is not None) else {}))
+            kw = {}
+            if j == 0 and t0 is not None:
+                kw["t"] = t0
+            if j == nb - 1 and chain3 is not None:
+                kw["chain"] = chain3
+            y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}", **kw)
         if not fuse:
             self.cv2.emit(plan, x, out=cat.slice_c(c_, c_), name=name + ".cv2")
+        if chain3 is not None:
+            return chain3[1]
         return self.cv3.emit(plan, cat, out=out, name=name + ".cv3")
 
 
