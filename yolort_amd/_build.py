@@ -14,9 +14,15 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.environ.get("YOLORT_AMD_BUILD_OUT") or os.path.join(LIBDIR, "libyolort_amd.so")   # override: tuning builds only
 SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_stem.hip", "preproc_pool.hip", "postprocess.hip"]
+# the conv tile x dtype space and the fused heads are instantiated in their own translation units (parallel build)
+INST_SOURCES = sorted(f for f in os.listdir(CSRC) if (f.startswith("conv_inst_") or f.startswith("head_inst_")) and f.endswith(".hip"))
+MONOLITHIC = "-DYMI_STAMPS" in os.environ.get("YOLORT_AMD_BUILD_FLAGS", "")   # the timeline instrumentation keeps one device symbol: single TU
+SOURCES = SOURCES + ([] if MONOLITHIC else INST_SOURCES)
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(os.path.dirname(PKG), "include", "yolort_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
-FLAGS += os.environ.get("YOLORT_AMD_BUILD_FLAGS", "").split()   # e.g. -DYMI_STAMPS for tools/stamp_conv.py
+FLAGS += os.environ.get("YOLORT_AMD_BUILD_FLAGS", "").split()
+if MONOLITHIC:
+    FLAGS.append("-DYMI_MONOLITHIC")   # e.g. -DYMI_STAMPS for tools/stamp_conv.py
 
 
 def _hipcc() -> str:
@@ -53,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(r.stderr[-2000:], file=sys.stderr)
         return obj
 
-    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)

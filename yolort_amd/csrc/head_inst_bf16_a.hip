@@ -1,0 +1,8 @@
+// explicit instantiation of the fused detection head (conv_igemm_impl.hpp): YMI_BF16, anchor padding 32 / 64 rows
+#include "conv_igemm_impl.hpp"
+namespace ymi {
+template int launch_head_decode<YMI_BF16, 1>(const ConvArgs&, const HeadDecodeArgs&, hipStream_t);
+template int launch_head_group<YMI_BF16, 1>(const HeadGroupArgs&, hipStream_t);
+template int launch_head_decode<YMI_BF16, 2>(const ConvArgs&, const HeadDecodeArgs&, hipStream_t);
+template int launch_head_group<YMI_BF16, 2>(const HeadGroupArgs&, hipStream_t);
+}
