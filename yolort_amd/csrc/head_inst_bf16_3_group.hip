@@ -1,0 +1,5 @@
+// explicit instantiation of the fused detection head (conv_igemm_impl.hpp): YMI_BF16, anchor padding 96 rows, group launch
+#include "conv_igemm_impl.hpp"
+namespace ymi {
+template int launch_head_group<YMI_BF16, 3>(const HeadGroupArgs&, hipStream_t);
+}
