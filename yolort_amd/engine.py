@@ -430,7 +430,8 @@ class Plan:
         hb, wb = canvas_hw
         if wb % 8 or d.h != hb or d.w_in * 2 != wb or len(images) != d.n:
             return False
-        return all(im.dtype == self.dtype and tuple(im.shape) == (3, hb, wb) and im.is_contiguous() and im.data_ptr() % 16 == 0 for im in images)
+        return all(im.device == self.device and im.dtype == self.dtype and tuple(im.shape) == (3, hb, wb) and im.is_contiguous() and im.data_ptr() % 16 == 0
+                   for im in images)
 
     # ---- execution ----
     @property
