@@ -142,6 +142,13 @@ def parity_sample(model, images_gpu, images_cpu, sd, score_thresh, k=4):
 
     with torch.no_grad():
         ref = O.yolov5_forward([im.float() for im in images_cpu[:k]], sd, score_thresh=score_thresh)
+        # the same oracle with fp16 STORAGE emulated between layers (fp32 arithmetic): what any fp16-storage implementation
+        # can expect against the fp32 reference on this network -- the yardstick for the HIP path's own figure
+        O.EMULATE.dtype = torch.float16 if next(model.parameters()).dtype == torch.float16 else torch.bfloat16
+        try:
+            emu = O.yolov5_forward([im.to(O.EMULATE.dtype).float() for im in images_cpu[:k]], sd, score_thresh=score_thresh)
+        finally:
+            O.EMULATE.dtype = None
     got = model.forward(images_gpu[:k])
     ious, matched, total = [], 0, 0
     for r, d in zip(ref, got):
@@ -163,9 +170,12 @@ def parity_sample(model, images_gpu, images_cpu, sd, score_thresh, k=4):
     refs = [{"boxes": r["boxes"].numpy(), "scores": r["scores"].numpy(), "labels": r["labels"].numpy()} for r in ref]
     gots = [{"boxes": d["boxes"].float().cpu().numpy(), "scores": d["scores"].float().cpu().numpy(), "labels": d["labels"].cpu().numpy()} for d in got]
     ap = coco_ap(refs, gots)
+    emus = [{"boxes": r["boxes"].numpy(), "scores": r["scores"].numpy(), "labels": r["labels"].numpy()} for r in emu]
+    ap_emu = coco_ap(refs, emus)
     return {"images": k, "ref_dets": total, "matched_iou50": round(matched / max(total, 1), 4),
             "median_iou": round(float(np.median(ious)), 4) if ious else None,
             "map_vs_ref_50_95": round(ap, 4) if ap is not None else None,
+            "map_of_oracle_with_emulated_16bit_storage": round(ap_emu, 4) if ap_emu is not None else None,
             "note": "oracle (fp32 CPU restatement of the reference) detections as ground truth; the HIP path stores fp16"}
 
 
