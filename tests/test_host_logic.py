@@ -120,3 +120,30 @@ def test_synth_weights_are_deterministic():
     a, b = synth_weights(t, arch, seed=0), synth_weights(t, arch, seed=0)
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert float(a["model.backbone.body.0.bn.running_var"].mean()) != 1.0  # calibrated statistics were loaded
+
+
+def test_bench_coco_ap_metric():
+    """bench.py's 'mAP vs ref' (SURVEY.md 8d): identical detections score 1.0, shifted boxes score less, missing classes count"""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(0)
+
+    def mk(n):
+        xy = rng.random((n, 2)) * 500
+        wh = rng.random((n, 2)) * 80 + 20
+        return {"boxes": np.concatenate([xy, xy + wh], 1), "scores": rng.random(n), "labels": rng.integers(0, 5, n)}
+
+    refs = [mk(50), mk(40)]
+    assert bench.coco_ap(refs, refs, 5) == 1.0
+    shifted = [{**r, "boxes": r["boxes"] + 3.0} for r in refs]
+    ap = bench.coco_ap(refs, shifted, 5)
+    assert 0.3 < ap < 0.9
+    dropped = [{k: v[r["labels"] != 0] for k, v in r.items()} for r in refs]   # class 0 never detected
+    assert bench.coco_ap(refs, dropped, 5) < 0.85
+    assert bench.coco_ap([{"boxes": np.zeros((0, 4)), "scores": np.zeros(0), "labels": np.zeros(0, int)}], [mk(3)], 5) is None
