@@ -197,12 +197,12 @@ class YOLO(nn.Module):
             if ev0 is None:   # the caller already started the bracket when it issued op 0 itself (stem from planar images)
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record(main)
-            e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph and first_op == 0, stream=main)
+            e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph, stream=main)
             ev1.record(main)
             starts.append(ev0)
             ends.append(ev1)
         else:
-            e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph and first_op == 0, stream=main)
+            e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph, stream=main)
         side = e.post_stream
         side.wait_stream(main)
         if os.environ.get("YOLORT_AMD_DEBUG_SKIP_POST", "0") != "1":   # tuning aid: upper bound without sort/NMS

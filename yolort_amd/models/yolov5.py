@@ -59,7 +59,20 @@ class YOLOv5(nn.Module):
             if not im.is_cuda:
                 raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
         original = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
-        (hb, wb), sizes, pads = self.transform.geometry(original)
+        # host geometry (resize / pad / rescale rows) depends on the list of image sizes only: memoised, a serving loop sees
+        # the same few size lists again and again
+        gkey = (tuple(original), self.transform.min_size, self.transform.max_size, self.transform.size_divisible, self.transform.fixed_shape)
+        geo = self._geo_cache.get(gkey) if hasattr(self, "_geo_cache") else None
+        if geo is None:
+            (hb, wb), sizes, pads = self.transform.geometry(original)
+            geo = ((hb, wb), sizes, pads, [rescale_params((hb, wb), o) for o in original],
+                   all(o == (hb, wb) for o in original) and all(s_ == (hb, wb) for s_ in sizes))
+            if not hasattr(self, "_geo_cache"):
+                self._geo_cache = {}
+            if len(self._geo_cache) > 256:
+                self._geo_cache.clear()
+            self._geo_cache[gkey] = geo
+        (hb, wb), sizes, pads, rows_cached, identity = geo
         model = self.model
         if not isinstance(model, YOLO):
             raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
@@ -67,8 +80,7 @@ class YOLOv5(nn.Module):
         with torch.cuda.stream(e.main_stream):
             # fixed-size stream: every image already is the canvas (resize = identity, no padding) in the compute dtype ->
             # the stem reads the planar images itself, the letterbox pass and its NHWC4 copy are skipped (bit-identical)
-            planar = (model.stem_from_planar and not model.use_graph and all(o == (hb, wb) for o in original) and all(s_ == (hb, wb) for s_ in sizes)
-                      and e.plan.stem_planar_ok(images, (hb, wb)))
+            planar = model.stem_from_planar and identity and e.plan.stem_planar_ok(images, (hb, wb))
             ev0 = None
             if planar:
                 for im in images:
@@ -80,7 +92,7 @@ class YOLOv5(nn.Module):
             else:
                 self.transform.letterbox_into(images, e.x, sizes, pads)
             first_op = 1 if planar else 0
-            rows = [rescale_params((hb, wb), o) for o in original]
+            rows = rows_cached
             if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
                 pend = model._submit_entry(e, None, first_op, ev0, planar=images if planar else None)
                 pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
