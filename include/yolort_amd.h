@@ -38,6 +38,7 @@ extern "C" {
 #define YMI_BF16 1
 #define YMI_F32 2
 #define YMI_U8 3
+#define YMI_U8_HWC 4 /* ymi_letterbox input only: interleaved (h, w, 3) uint8, as image decoders deliver it */
 
 /* activation after conv */
 #define YMI_ACT_NONE 0
@@ -56,7 +57,9 @@ int ymi_device_count(void);
  * The host computes resized sizes / pad offsets with the reference's float recipe
  * (yolort_amd.models.transform) and passes them in `geom`.
  *   imgs[i]     device pointer to image i, planar CHW (3,h,w), contiguous, dtype in_dtype
- *               (YMI_F32 / YMI_F16 / YMI_BF16 in [0,1], or YMI_U8 in [0,255] which is scaled by 1/255)
+ *               (YMI_F32 / YMI_F16 / YMI_BF16 in [0,1], or YMI_U8 in [0,255] which is scaled by 1/255);
+ *               YMI_U8_HWC: interleaved (h,w,3) uint8 instead (the /255, the HWC -> CHW permute of
+ *               yolov5.py:218-228 and the letterbox are then one kernel)
  *   geom[i*6..] {h_in, w_in, h_resized, w_resized, pad_top, pad_left}
  *   out         (n, hb, wb, c_out) NHWC, dtype out_dtype, channels 3..c_out-1 zero-filled
  *   fill        pad value (reference: 114/255, transform.py:141)

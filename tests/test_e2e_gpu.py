@@ -240,6 +240,19 @@ def test_planar_stem_batch_survives_capacity_growth(dev):
             assert torch.equal(a[k], b[k]), f"re-run planar batch disagrees on {k}"
 
 
+def test_predict_accepts_decoded_hwc_uint8(dev):
+    """images as a decoder delivers them -- uint8 (H, W, 3) -- give the same detections as their planar (3, H, W) form"""
+    from yolort_amd.utils.synth import synth_images
+    m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.2)
+    planar = [(synth_images(1, h, w, seed=91 + i)[0] * 255).round().to(torch.uint8) for i, (h, w) in enumerate([(300, 400), (240, 320)])]
+    a = m.predict([u.to(dev) for u in planar])
+    b = m.predict([u.permute(1, 2, 0).contiguous().to(dev) for u in planar])
+    for x, y in zip(a, b):
+        assert len(x["scores"]) > 0
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(x[k], y[k])
+
+
 def test_mixed_sizes_and_yolo_forward(dev):
     """dynamic-shape letterbox batch + YOLO.forward on a pre-batched tensor (no rescale)."""
     from oracle import yolov5_oracle as O

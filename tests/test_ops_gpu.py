@@ -383,6 +383,24 @@ def test_letterbox_identity_fast_path(dev, hw, S):
     assert torch.equal(nt8.nchw().cpu(), ref8)
 
 
+def test_letterbox_interleaved_uint8_input(dev):
+    """YMI_U8_HWC: decoded images (H, W, 3) uint8 go straight into the letterbox kernel -- the result must equal the planar
+    uint8 path bit for bit (bilinear resize and identity sizes), i.e. permute + /255 + letterbox in one kernel"""
+    from yolort_amd.models.transform import YOLOTransform
+    from yolort_amd.utils.synth import synth_images
+    for shapes, S in (([(1080, 810), (480, 640), (375, 500), (100, 37)], 640), ([(320, 256)] * 3, 320)):
+        planar = [(synth_images(1, h, w, seed=h + w + i)[0] * 255).round().to(torch.uint8) for i, (h, w) in enumerate(shapes)]
+        hwc = [u.permute(1, 2, 0).contiguous() for u in planar]
+        t = YOLOTransform(S, S)
+        assert all(t.is_hwc(u) for u in hwc) and not any(t.is_hwc(u) for u in planar)
+        a, _ = t([u.to(dev) for u in planar], None, dtype=torch.float16)
+        b, _ = t([u.to(dev) for u in hwc], None, dtype=torch.float16)
+        assert a.image_sizes == b.image_sizes
+        assert torch.equal(a.nchw(), b.nchw())
+    with pytest.raises(Exception):
+        t([planar[0].to(dev), hwc[1].to(dev)], None, dtype=torch.float16)   # mixed layouts in one batch
+
+
 def _rand_boxes(rng, n, span=200.0):
     xy = rng.random((n, 2), dtype=np.float32) * span
     wh = rng.random((n, 2), dtype=np.float32) * 60 + 2

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLORT_AMD_LIB") or os.path.join(_HERE, "lib", "libyolort_amd.so")   # override: tuning builds only
 
 YMI_F16, YMI_BF16, YMI_F32, YMI_U8 = 0, 1, 2, 3
+YMI_U8_HWC = 4   # ymi_letterbox input only: interleaved (h, w, 3) uint8
 ACT_NONE, ACT_SILU = 0, 1
 MAX_LEVELS = 4
 

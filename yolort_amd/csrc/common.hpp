@@ -70,7 +70,7 @@ __device__ __forceinline__ float load_elem(const void* p, int64_t i) {
     if constexpr (DT == YMI_F16) return h2f(((const uint16_t*)p)[i]);
     else if constexpr (DT == YMI_BF16) return bf2f(((const uint16_t*)p)[i]);
     else if constexpr (DT == YMI_F32) return ((const float*)p)[i];
-    else return (float)((const uint8_t*)p)[i] / 255.0f;   // true division, like the reference's `read_image(...) / 255.0`
+    else return (float)((const uint8_t*)p)[i] / 255.0f;   // YMI_U8 / YMI_U8_HWC: true division, like the reference's `read_image(...) / 255.0`
 }
 template <int DT>
 __device__ __forceinline__ uint16_t to16(float v) {
@@ -81,6 +81,13 @@ template <int DT>
 __device__ __forceinline__ float from16(uint16_t v) {
     if constexpr (DT == YMI_F16) return h2f(v);
     else return bf2f(v);
+}
+
+// element index of channel c at (y, x) of an h x w image: planar (3, h, w), or interleaved (h, w, 3) for YMI_U8_HWC
+template <int DT>
+__device__ __forceinline__ int64_t src_index(int c, int y, int x, int w, int64_t plane) {
+    if constexpr (DT == YMI_U8_HWC) return ((int64_t)y * w + x) * 3 + c;
+    else return c * plane + (int64_t)y * w + x;
 }
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }

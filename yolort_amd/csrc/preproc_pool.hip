@@ -50,11 +50,10 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const LetterboxArgs a) {
         const int64_t plane = (int64_t)hin * win;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int64_t b = c * plane;
-            const float p00 = load_elem<IDT>(a.img[img], b + (int64_t)y0 * win + x0);
-            const float p01 = load_elem<IDT>(a.img[img], b + (int64_t)y0 * win + x1);
-            const float p10 = load_elem<IDT>(a.img[img], b + (int64_t)y1 * win + x0);
-            const float p11 = load_elem<IDT>(a.img[img], b + (int64_t)y1 * win + x1);
+            const float p00 = load_elem<IDT>(a.img[img], src_index<IDT>(c, y0, x0, win, plane));
+            const float p01 = load_elem<IDT>(a.img[img], src_index<IDT>(c, y0, x1, win, plane));
+            const float p10 = load_elem<IDT>(a.img[img], src_index<IDT>(c, y1, x0, win, plane));
+            const float p11 = load_elem<IDT>(a.img[img], src_index<IDT>(c, y1, x1, win, plane));
             const float top = __fadd_rn(__fmul_rn(p00, lx0), __fmul_rn(p01, lx1));
             const float bot = __fadd_rn(__fmul_rn(p10, lx0), __fmul_rn(p11, lx1));
             v[c] = __fadd_rn(__fmul_rn(top, ly0), __fmul_rn(bot, ly1));
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void letterbox_copy_kernel(const LetterboxArgs
             const int xx = x0 + i;
             const bool in = row_in && (unsigned)xx < (unsigned)win;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[i][c] = in ? load_elem<IDT>(a.img[img], c * plane + (int64_t)yy * win + xx) : a.fill;
+            for (int c = 0; c < 3; ++c) v[i][c] = in ? load_elem<IDT>(a.img[img], src_index<IDT>(c, yy, xx, win, plane)) : a.fill;
         }
     }
     if constexpr (ODT == YMI_F32) {
@@ -394,6 +393,7 @@ extern "C" int ymi_letterbox(const void* const* imgs, const int32_t* geom, int n
             case YMI_F16: rc = letterbox_dispatch<YMI_F16>(a, out_dtype, (hipStream_t)stream); break;
             case YMI_BF16: rc = letterbox_dispatch<YMI_BF16>(a, out_dtype, (hipStream_t)stream); break;
             case YMI_U8: rc = letterbox_dispatch<YMI_U8>(a, out_dtype, (hipStream_t)stream); break;
+            case YMI_U8_HWC: rc = letterbox_dispatch<YMI_U8_HWC>(a, out_dtype, (hipStream_t)stream); break;
             default: set_error("ymi_letterbox: bad in_dtype %d", in_dtype); return YMI_EINVAL;
         }
         if (rc != YMI_OK) return rc;

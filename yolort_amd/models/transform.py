@@ -100,18 +100,29 @@ class YOLOTransform(nn.Module):
         return (hb, wb), sizes, pads
 
     # ---- device -----------------------------------------------------------------------------
+    @staticmethod
+    def is_hwc(im: Tensor) -> bool:
+        """interleaved uint8 (H, W, 3) as image decoders deliver it (a (3, W, 3) uint8 tensor counts as planar)"""
+        return im.dtype == torch.uint8 and im.dim() == 3 and im.shape[-1] == 3 and im.shape[0] != 3
+
+    @staticmethod
+    def image_hw(im: Tensor) -> Tuple[int, int]:
+        return (int(im.shape[0]), int(im.shape[1])) if YOLOTransform.is_hwc(im) else (int(im.shape[-2]), int(im.shape[-1]))
+
     def letterbox_into(self, images: Sequence[Tensor], out: View, sizes, pads) -> None:
         lib = _lib.load(require_gpu=True)
         n = len(images)
-        kinds = {im.dtype for im in images}
+        kinds = {(im.dtype, self.is_hwc(im)) for im in images}
         if len(kinds) != 1:
-            raise YmiError("all images of a batch must share one dtype")
+            raise YmiError("all images of a batch must share one dtype and layout")
+        hwc = self.is_hwc(images[0])
         imgs = [im if im.is_contiguous() else im.contiguous() for im in images]
         ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in imgs])
         geom = (C.c_int32 * (6 * n))()
         for i, im in enumerate(imgs):
-            geom[6 * i: 6 * i + 6] = [im.shape[-2], im.shape[-1], sizes[i][0], sizes[i][1], pads[i][0], pads[i][1]]
-        check(lib.ymi_letterbox(ptrs, geom, n, dtype_code(imgs[0].dtype), out.ptr, out.h, out.w, out.c, dtype_code(out.dtype),
+            h_in, w_in = self.image_hw(im)
+            geom[6 * i: 6 * i + 6] = [h_in, w_in, sizes[i][0], sizes[i][1], pads[i][0], pads[i][1]]
+        check(lib.ymi_letterbox(ptrs, geom, n, _lib.YMI_U8_HWC if hwc else dtype_code(imgs[0].dtype), out.ptr, out.h, out.w, out.c, dtype_code(out.dtype),
                                 C.c_float(self.fill_color), _lib.stream_ptr()), "ymi_letterbox")
 
     def forward(self, images: Sequence[Tensor], targets=None, dtype: Optional[torch.dtype] = None, out: Optional[View] = None):
@@ -121,11 +132,11 @@ class YOLOTransform(nn.Module):
         for im in images:
             if im.dim() != 3:  # reference :185-189
                 raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], but got '{im.shape}'.")
-            if im.shape[0] != 3:
+            if im.shape[0] != 3 and not self.is_hwc(im):
                 raise ValueError(f"images are expected to have 3 channels, got {im.shape[0]}")
             if not im.is_cuda:
                 raise YmiError("yolort_amd runs on an MI355X only: images must live on 'cuda' (there is no CPU fallback)")
-        (hb, wb), sizes, pads = self.geometry([(int(im.shape[-2]), int(im.shape[-1])) for im in images])
+        (hb, wb), sizes, pads = self.geometry([self.image_hw(im) for im in images])
         if out is None:
             dt = dtype or (images[0].dtype if images[0].dtype.is_floating_point else torch.float32)
             t = torch.empty(len(images) * hb * wb * 4, device=images[0].device, dtype=dt)

@@ -58,7 +58,7 @@ class YOLOv5(nn.Module):
                 raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], but got '{im.shape}'.")
             if not im.is_cuda:
                 raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
-        original = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        original = [self.transform.image_hw(im) for im in images]   # (3, H, W) planar, or (H, W, 3) interleaved uint8
         # host geometry (resize / pad / rescale rows) depends on the list of image sizes only: memoised, a serving loop sees
         # the same few size lists again and again
         gkey = (tuple(original), self.transform.min_size, self.transform.max_size, self.transform.size_divisible, self.transform.fixed_shape)
@@ -107,13 +107,13 @@ class YOLOv5(nn.Module):
         return self.forward(images)
 
     def default_loader(self, img_path: str) -> Tensor:
-        """RGB uint8 CHW tensor; the /255 of the reference (yolov5.py:228) is fused into the letterbox
-        kernel's uint8 path (decode stays on the host, PIL)."""
+        """RGB uint8 image as decoded, (H, W, 3); the permute and the /255 of the reference (yolov5.py:218-228) are fused into
+        the letterbox kernel's interleaved-uint8 path (decode stays on the host, PIL)."""
         import numpy as np
         from PIL import Image
 
         arr = np.asarray(Image.open(img_path).convert("RGB"))
-        return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous()
+        return torch.from_numpy(arr.copy())   # (H, W, 3) uint8: the HWC -> CHW permute and the /255 happen inside the letterbox kernel
 
     def collate_images(self, samples: Any, image_loader: Callable) -> List[Tensor]:
         """Reference yolov5.py:230-262: everything moves to the model's device; floating inputs take the
