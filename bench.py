@@ -74,64 +74,7 @@ def cpu_baseline(arch, sd, images_cpu, score_thresh, budget_s=25.0):
             "sample": f"{passes} pass(es) of {n_sample} images 640x640 through oracle/yolov5_oracle.py (fp32, torch CPU, {cores} threads), incl. letterbox+NMS"}
 
 
-def _iou_matrix(a, b):
-    import numpy as np
-
-    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
-    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
-    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
-    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
-
-
-def coco_ap(refs, dets, num_classes=80):
-    """COCO-style AP@[.5:.95] (101-point interpolation, greedy score-ordered matching per class and image) of `dets`
-    with the ORACLE's detections `refs` as ground truth -- the 'mAP vs ref' of SURVEY.md 8d.  Lists of per-image dicts
-    of numpy arrays {boxes (n,4), scores (n), labels (n)}."""
-    import numpy as np
-
-    thrs = np.arange(0.5, 0.96, 0.05)
-    aps = []
-    for c in range(num_classes):
-        n_gt = sum(int((r["labels"] == c).sum()) for r in refs)
-        if n_gt == 0:
-            continue
-        recs = []   # (score, tp flags per threshold)
-        for r, d in zip(refs, dets):
-            gb = r["boxes"][r["labels"] == c]
-            m = d["labels"] == c
-            db, ds = d["boxes"][m], d["scores"][m]
-            order = np.argsort(-ds, kind="stable")
-            db, ds = db[order], ds[order]
-            iou = _iou_matrix(db, gb) if len(db) and len(gb) else np.zeros((len(db), len(gb)))
-            tp = np.zeros((len(db), len(thrs)), bool)
-            for ti, t in enumerate(thrs):
-                used = np.zeros(len(gb), bool)
-                for i in range(len(db)):
-                    cand = np.where(~used & (iou[i] >= t))[0]
-                    if len(cand):
-                        j = cand[np.argmax(iou[i, cand])]
-                        used[j] = True
-                        tp[i, ti] = True
-            recs += [(float(ds[i]), tp[i]) for i in range(len(db))]
-        if not recs:
-            aps.append(0.0)
-            continue
-        recs.sort(key=lambda x: -x[0])
-        tps = np.stack([x[1] for x in recs]).astype(np.float64)
-        ap_t = []
-        for ti in range(len(thrs)):
-            ctp = np.cumsum(tps[:, ti]); cfp = np.cumsum(1.0 - tps[:, ti])
-            rec = ctp / n_gt; prec = ctp / np.maximum(ctp + cfp, 1e-12)
-            for i in range(len(prec) - 2, -1, -1):
-                prec[i] = max(prec[i], prec[i + 1])
-            q = np.zeros(101)
-            inds = np.searchsorted(rec, np.linspace(0, 1, 101), side="left")
-            ok = inds < len(prec)
-            q[ok] = prec[inds[ok]]
-            ap_t.append(q.mean())
-        aps.append(float(np.mean(ap_t)))
-    return float(np.mean(aps)) if aps else None
+from yolort_amd.utils.metrics import coco_ap  # noqa: E402  (host-side metric; re-exported for tests)
 
 
 def parity_sample(model, images_gpu, images_cpu, sd, score_thresh, k=4):

@@ -147,3 +147,33 @@ def test_bench_coco_ap_metric():
     dropped = [{k: v[r["labels"] != 0] for k, v in r.items()} for r in refs]   # class 0 never detected
     assert bench.coco_ap(refs, dropped, 5) < 0.85
     assert bench.coco_ap([{"boxes": np.zeros((0, 4)), "scores": np.zeros(0), "labels": np.zeros(0, int)}], [mk(3)], 5) is None
+
+
+def test_detection_evaluator_surface():
+    """update()/compute() accumulator over in-memory ground truth (the reference's COCOEvaluator surface):
+    perfect detections score 100, shards merge, half the boxes missing halves the recall-limited AP"""
+    import numpy as np
+    import torch
+
+    from yolort_amd.utils.metrics import DetectionEvaluator
+
+    rng = np.random.default_rng(3)
+
+    def mk(n):
+        xy = rng.random((n, 2)) * 500
+        wh = rng.random((n, 2)) * 80 + 20
+        return {"boxes": torch.tensor(np.concatenate([xy, xy + wh], 1)), "scores": torch.tensor(rng.random(n)), "labels": torch.tensor(rng.integers(0, 4, n))}
+
+    imgs = [mk(40), mk(30), mk(20)]
+    tg = [{"boxes": d["boxes"], "labels": d["labels"]} for d in imgs]
+    a, b = DetectionEvaluator(4), DetectionEvaluator(4)
+    a.update(imgs[:2], tg[:2])
+    b.update(imgs[2:], tg[2:])
+    a.merge(b)
+    r = a.compute()
+    assert r["AP"] == 100.0 and r["AP50"] == 100.0 and r["AP75"] == 100.0
+    half = DetectionEvaluator(4)
+    half.update([{k: v[::2] for k, v in d.items()} for d in imgs], tg)
+    h = half.compute()
+    assert 35.0 < h["AP50"] < 65.0
+    assert DetectionEvaluator(4).compute()["AP"] == -1.0
