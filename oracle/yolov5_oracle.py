@@ -165,6 +165,18 @@ class _Emulate:
 EMULATE = _Emulate()
 
 
+class _Trace:
+    """Optional per-layer tap (tests/test_parity_gpu.py): when `hook` is set, every conv of the stack reports
+    hook(prefix, x, stride, pad) with its fp32 input BEFORE computing -- the per-layer GPU parity test feeds exactly
+    that tensor (rounded to the storage type) to the HIP launch that implements the layer."""
+
+    def __init__(self) -> None:
+        self.hook = None
+
+
+TRACE = _Trace()
+
+
 def _q(x: Tensor) -> Tensor:
     return x.to(EMULATE.dtype).to(torch.float32) if EMULATE.dtype is not None else x
 
@@ -173,6 +185,8 @@ def conv_bn_silu(x: Tensor, sd: Dict[str, Tensor], p: str, stride: int = 1, pad:
     """common.py:42-70 `Conv`: SiLU(BN(conv2d(x))), bias-free conv, pad=k//2 (autopad :35-39)."""
     w = sd[p + ".conv.weight"]
     k = w.shape[-1]
+    if TRACE.hook is not None:
+        TRACE.hook(p, x, stride, k // 2 if pad is None else pad)
     if EMULATE.dtype is not None:  # folded-BN, low-precision storage emulation (see _Emulate)
         scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + BN_EPS)
         bias = sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale
@@ -252,6 +266,8 @@ def head(features: List[Tensor], sd: Dict[str, Tensor], p: str = "head", num_anc
     """YOLOHead.forward (box_head.py:68-82): biased 1x1 conv, view (N,A,K,H,W) -> (N,A,H,W,K)."""
     outs = []
     for i, f in enumerate(features):
+        if TRACE.hook is not None:
+            TRACE.hook(f"{p}.head.{i}", f, 1, 0)
         y = F.conv2d(_q(f), _q(sd[f"{p}.head.{i}.weight"]), sd[f"{p}.head.{i}.bias"])
         n, _, h, w = y.shape
         outs.append(y.view(n, num_anchors, -1, h, w).permute(0, 1, 3, 4, 2).contiguous())

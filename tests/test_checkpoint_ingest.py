@@ -163,3 +163,50 @@ def test_loader_refuses_foreign_code(tmp_path):
     with pytest.raises(Exception):
         load_from_ultralytics(path)
     assert not os.path.exists("/tmp/ymi_pwned")
+
+
+def _global_call_pickle(module, name, *args):
+    """protocol-4 pickle of `module.name(*args)` (string args), built opcode by opcode -- `name` may be dotted"""
+    import pickle as P
+
+    def s(v):
+        b = v.encode()
+        return P.SHORT_BINUNICODE + bytes([len(b)]) + b
+
+    out = P.PROTO + b"\x04" + s(module) + s(name) + P.STACK_GLOBAL + P.MARK
+    for a in args:
+        out += s(a)
+    return out + P.TUPLE + P.REDUCE + P.STOP
+
+
+@pytest.mark.parametrize("module,name", [
+    ("torch._utils", "_import_dotted_name"),                 # resolves any dotted path when called: os.system one call away
+    ("torch._utils", "traceback.linecache.os.getcwd"),       # protocol-4 dotted name: attribute traversal out of an allowed module
+    ("collections", "_sys.getrecursionlimit"),
+    ("collections", "_sys"),
+    ("numpy", "memmap"),                                     # a real type whose constructor touches the file system
+    ("torch", "load"), ("torch.hub", "load"), ("os", "system"), ("builtins", "eval"), ("builtins", "getattr"),
+])
+def test_unpickler_resolves_nothing_outside_the_allow_list(module, name):
+    """module-level trust let crafted pickles reach real callables.  Every one of these must come back as
+    an inert stub class, both from find_class and when the pickle calls it."""
+    import io
+
+    from yolort_amd.models._checkpoint import _StubUnpickler, _UpstreamStub
+    cls = _StubUnpickler(io.BytesIO(b"")).find_class(module, name)
+    assert isinstance(cls, type) and issubclass(cls, _UpstreamStub), (module, name, cls)
+    obj = _StubUnpickler(io.BytesIO(_global_call_pickle(module, name, "os.getcwd"))).load()
+    assert isinstance(obj, _UpstreamStub)
+
+
+def test_unpickler_still_resolves_the_data_constructors():
+    import collections
+    import io
+
+    from yolort_amd.models._checkpoint import _StubUnpickler
+    u = _StubUnpickler(io.BytesIO(b""))
+    assert u.find_class("collections", "OrderedDict") is collections.OrderedDict
+    assert u.find_class("torch._utils", "_rebuild_tensor_v2") is torch._utils._rebuild_tensor_v2
+    assert u.find_class("torch", "float16") is torch.float16 and u.find_class("torch", "HalfStorage") is torch.HalfStorage
+    assert u.find_class("torch.nn.modules.conv", "Conv2d") is nn.Conv2d
+    assert u.find_class("builtins", "set") is set

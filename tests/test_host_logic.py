@@ -177,3 +177,29 @@ def test_detection_evaluator_surface():
     h = half.compute()
     assert 35.0 < h["AP50"] < 65.0
     assert DetectionEvaluator(4).compute()["AP"] == -1.0
+
+
+def test_coco_ap_known_answer_from_the_published_protocol():
+    """hand-computed vector for the COCO protocol (pycocotools cocoeval.accumulate: greedy score-ordered matching, precision
+    envelope, 101 recall points with searchsorted 'left', mean over IoU .50:.05:.95): one class, 2 ground-truth boxes,
+    detections d1 (0.9, IoU 1.0 with g1), d2 (0.8, no overlap), d3 (0.7, IoU 0.8 with g2).
+      thresholds .50 ... .80 (7 of 10): TP FP TP -> recall .5 .5 1, precision 1 .5 2/3 -> envelope 1 2/3 2/3
+                                        AP = (51 * 1 + 50 * 2/3) / 101
+      thresholds .85 .90 .95:           TP FP FP -> recall stays .5 -> AP = 51 / 101
+    """
+    import numpy as np
+
+    from yolort_amd.utils.metrics import COCO_IOU_THRS, DetectionEvaluator, coco_ap
+    assert len(COCO_IOU_THRS) == 10 and COCO_IOU_THRS[4] == 0.7 and abs(COCO_IOU_THRS[-1] - 0.95) < 1e-12
+    g = {"boxes": np.array([[0, 0, 10, 10], [20, 20, 30, 30]], np.float32), "labels": np.array([0, 0]), "scores": np.ones(2, np.float32)}
+    d = {"boxes": np.array([[0, 0, 10, 10], [50, 50, 60, 60], [20, 20, 30, 28]], np.float32), "labels": np.array([0, 0, 0]),
+         "scores": np.array([0.9, 0.8, 0.7], np.float32)}
+    want = (7 * (51 + 50 * 2 / 3) / 101 + 3 * 51 / 101) / 10
+    assert abs(coco_ap([g], [d], num_classes=1) - want) < 1e-9
+    # maxDets: only the best `max_dets` detections of an image count (COCO: 100) -- with max_dets=2, d3 is never seen
+    assert abs(coco_ap([g], [d], num_classes=1, max_dets=2) - 51 / 101) < 1e-9
+    ev = DetectionEvaluator(1)
+    assert ev.max_dets == 100
+    ev.update([d], [{"boxes": g["boxes"], "labels": g["labels"]}])
+    out = ev.compute()
+    assert abs(out["AP"] - 100 * want) < 1e-6 and abs(out["AP50"] - 100 * (51 + 50 * 2 / 3) / 101) < 1e-6 and abs(out["AP75"] - 100 * (51 + 50 * 2 / 3) / 101) < 1e-6

@@ -1,0 +1,318 @@
+"""Tight, on-config parity of the HIP path (MI355X), round 2:
+
+  * per-LAUNCH parity of the real benchmark plan (yolov5s fp16 bs 32 640x640, BASELINE configs[1]): every conv
+    launch of the recorded plan -- with the tile the plan actually uses, fused pairs / chained 1x1 / folded upsample
+    included -- is fed the oracle's input of that layer (rounded to the storage type) and compared with the fp32
+    oracle output of that single layer at <= 2e-3 of the layer's output range.  No chaotic amplification: a layer
+    sees exact inputs.
+  * fp32 PARITY MODE (csrc/conv_f32.hip): the whole network end to end against the fp32 CPU oracle with the direct
+    checks of SURVEY.md 8d -- equal counts, equal labels, |dscore| <= 1e-4, IoU >= 1 - 1e-3 -- on BASELINE configs[0]
+    (yolov5n thr 0.45, 2 images) and configs[1] (yolov5s, bs 32).
+  * in-kernel box rescale (transform.py:354-367) against the oracle's scale_coords, to 1 ulp.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from yolort_amd import _lib
+    _lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _build(arch, dev, dtype, **kw):
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_weights
+    head_gain = kw.pop("head_gain", 0.5)
+    m = YOLOv5(arch=arch, **kw)
+    sd = synth_weights(m.state_dict(), arch, seed=0, head_gain=head_gain)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    return (m if dtype == torch.float32 else m.to(dtype)), sd
+
+
+# ------------------------------------------------------------------------------------------------
+# per-launch parity of the benchmark plan
+# ------------------------------------------------------------------------------------------------
+def _fill(view, t_nchw, dtype):
+    """NCHW CPU tensor -> the NHWC view of a plan buffer (channels past the tensor's are zeroed: the stem's NHWC4)"""
+    dst = view.as_tensor()
+    src = t_nchw.permute(0, 2, 3, 1).to(dst.device).to(dtype)
+    if src.shape[-1] < dst.shape[-1]:
+        dst.zero_()
+        dst[..., : src.shape[-1]].copy_(src)
+    else:
+        dst.copy_(src)
+
+
+def _read(view):
+    return view.as_tensor().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _ref_conv(sd, p, xq, stride, pad, act=True):
+    """fp32 oracle arithmetic of ONE layer (common.py:42-70 / box_head.py:74) on the given input"""
+    if p + ".conv.weight" in sd:
+        y = F.conv2d(xq, sd[p + ".conv.weight"], None, stride, pad)
+        y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, 1e-3)
+        return F.silu(y) if act else y
+    return F.conv2d(xq, sd[p + ".weight"], sd[p + ".bias"], stride, pad)
+
+
+def _resolve(first, comp, known):
+    """oracle prefix of a '+'-joined op-name component, e.g. ('model.backbone.body.2.cv1', 'm.0.cv1') -> 'model.backbone.body.2.m.0.cv1'"""
+    base = first
+    for _ in range(4):
+        base = base.rsplit(".", 1)[0]
+        cand = base + "." + comp
+        if cand in known:
+            return cand
+    raise KeyError((first, comp))
+
+
+@pytest.mark.parametrize("arch,dtype,n,size,tol", [
+    ("yolov5_darknet_pan_s_r60", torch.float16, 32, 640, 2e-3),     # BASELINE configs[1], the benchmarked plan
+    ("yolov5_darknet_pan_n_r60", torch.bfloat16, 4, 320, 1.6e-2),   # bf16 storage: 2^-8 output rounding
+])
+def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size, tol):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    m, sd = _build(arch, dev, dtype, size=(size, size), score_thresh=0.25)
+    imgs_cpu = list(synth_images(n, size, size, seed=1))
+    imgs = [im.to(dev).to(dtype) for im in imgs_cpu]
+    m.predict(imgs)                       # builds the plan exactly as bench.py does (planar stem, fused head, pinned tiles)
+    torch.cuda.synchronize()
+    e = next(iter(m.model._entries.values()))
+    plan = e.plan
+    sdf = {k: v.float() for k, v in sd.items()}
+    # oracle pass over the same batch; every layer's input, rounded to the storage type
+    inputs = {}
+    O.TRACE.hook = lambda p, x, s, pad: inputs.__setitem__(p, x.to(dtype))
+    try:
+        with torch.no_grad():
+            O.yolov5_forward(imgs_cpu, sdf, size=(size, size), score_thresh=0.25)
+    finally:
+        O.TRACE.hook = None
+    known = set(inputs)
+    worst = []
+    checked = 0
+    for idx in sorted(plan.io):
+        io = plan.io[idx]
+        parts = io["name"].split("+")
+        p0 = "model." + parts[0]
+        assert p0 in known, f"op {idx} {io['name']}: no oracle layer {p0}"
+        xq = inputs[p0].float()
+        _fill(io["x"], xq, dtype)
+        res_q = None
+        if io["res"] is not None:         # Bottleneck shortcut: the block's input = input of its cv1
+            res_q = inputs[p0.rsplit(".", 1)[0] + ".cv1"].float()
+            _fill(io["res"], res_q, dtype)
+        plan.run(idx, idx + 1)
+        torch.cuda.synchronize()
+        stride, pad = io["stride"][0], io["pad"][0]
+        if parts[0].endswith("body.0"):   # stem: the plan runs its super-pixel form (6x3 s(2,1)); the layer is Conv(3,c,6,2,2)
+            stride, pad = 2, 2
+        with torch.no_grad():
+            refs = []   # (label, reference NCHW, HIP view)
+            r0 = _ref_conv(sdf, p0, xq, stride, pad)
+            if res_q is not None:
+                r0 = r0 + res_q
+            if io["split"]:
+                p1 = _resolve(p0, parts[1], known)
+                refs.append((p0, r0, io["y"]))
+                refs.append((p1, _ref_conv(sdf, p1, xq, stride, pad), io["y2"]))
+            else:
+                refs.append((p0, r0, io["y"]))
+            if io["chain_y"] is not None and io["chain_x2"] is None:
+                pc = _resolve(p0, parts[-1], known)
+                refs.append((pc, _ref_conv(sdf, pc, r0.to(dtype).float(), 1, 0), io["chain_y"]))
+        for label, ref, view in refs:
+            got = _read(view)
+            scale = float(ref.abs().max())
+            err = float((got - ref).abs().max())
+            worst.append((err / scale, label, plan.meta[idx].get("tile"), plan.meta[idx].get("shape")))
+            assert err <= tol * scale + 1e-6, f"op {idx} {label} (tile {plan.meta[idx].get('tile')}, {plan.meta[idx].get('shape')}): |hip-ref| {err:.5f} > {tol} x {scale:.3f}"
+            checked += 1
+        if io["up2"] is not None:         # folded nn.Upsample(x2): the 4 copies must equal the launch's own output bit for bit
+            y = io["y"].as_tensor()
+            up = io["up2"].as_tensor()
+            assert torch.equal(up, y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)), f"op {idx} {io['name']}: folded upsample differs"
+    worst.sort(reverse=True)
+    print(f"{checked} layer outputs of {len(plan.io)} launches checked; worst relative errors:")
+    for w in worst[:5]:
+        print("   %.2e  %s  tile %s  %s" % w)
+    n_ref_convs = sum(1 for k in known if ".head." not in k)
+    assert checked >= n_ref_convs, f"only {checked} of the reference's {n_ref_convs} conv layers were exercised"
+    # the stem as the benchmark runs it (straight from the planar images) equals op 0 on the letterboxed batch
+    if plan.stem_planar_ok(imgs, (size, size)):
+        _fill(plan.io[0]["x"], torch.stack(imgs_cpu).to(dtype).float(), dtype)
+        plan.run(0, 1)
+        torch.cuda.synchronize()
+        a = plan.io[0]["y"].as_tensor().clone()
+        plan.io[0]["y"].as_tensor().zero_()
+        plan.stem_from_planar(imgs)
+        torch.cuda.synchronize()
+        assert torch.equal(a, plan.io[0]["y"].as_tensor()), "planar stem differs from the letterbox + NHWC4 stem"
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 parity mode: the north-star tolerance end to end
+# ------------------------------------------------------------------------------------------------
+def _iou_pairs(a, b):
+    x1, y1 = np.maximum(a[:, None, 0], b[None, :, 0]), np.maximum(a[:, None, 1], b[None, :, 1])
+    x2, y2 = np.minimum(a[:, None, 2], b[None, :, 2]), np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None, :] - inter + 1e-30)
+
+
+def direct_checks(ref, got, thr, k=300, score_eps=1e-4, iou_min=1 - 1e-3):
+    """SURVEY.md 8d direct checks for one image.  Returns a dict of counts.  A detection whose score lies within
+    `score_eps` of the threshold (or of the K-th score when the image is cut at K) may legitimately appear on one side
+    only -- fp32 summation order decides it -- and is excused; everything else must pair up one to one with equal label,
+    |dscore| <= score_eps and IoU >= iou_min."""
+    rb, rs, rl = ref["boxes"], ref["scores"], ref["labels"]
+    gb, gs, gl = got["boxes"], got["scores"], got["labels"]
+    cut = thr
+    if len(rs) >= k or len(gs) >= k:
+        cut = max(thr, float(min(rs[-1] if len(rs) else 1.0, gs[-1] if len(gs) else 1.0)))
+    used = np.zeros(len(gs), bool)
+    bad, excused, paired, same_pos = 0, 0, 0, 0
+    min_iou, max_ds = 1.0, 0.0
+    iou = _iou_pairs(rb, gb) if len(rs) and len(gs) else np.zeros((len(rs), len(gs)))
+    for i in range(len(rs)):
+        cand = np.where((gl == rl[i]) & ~used & (np.abs(gs - rs[i]) <= score_eps))[0]
+        j = cand[np.argmax(iou[i, cand])] if len(cand) else -1
+        if j >= 0 and iou[i, j] >= iou_min:
+            used[j] = True
+            paired += 1
+            same_pos += int(i == j)
+            min_iou = min(min_iou, float(iou[i, j]))
+            max_ds = max(max_ds, abs(float(gs[j] - rs[i])))
+        elif rs[i] <= cut + score_eps:
+            excused += 1
+        else:
+            bad += 1
+    for j in np.where(~used)[0]:
+        if gs[j] <= cut + score_eps:
+            excused += 1
+        else:
+            bad += 1
+    return {"ref": len(rs), "got": len(gs), "paired": paired, "same_position": same_pos, "excused_at_cut": excused, "unexplained": bad,
+            "min_iou": min_iou, "max_dscore": max_ds, "equal_count": len(rs) == len(gs), "labels_equal": len(rs) == len(gs) and bool(np.array_equal(rl, gl))}
+
+
+def _np(d):
+    return {k: (v.detach().float().cpu().numpy() if k != "labels" else v.detach().cpu().numpy()) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("arch,n,thr,head_gain", [
+    ("yolov5_darknet_pan_n_r60", 2, 0.45, 1.0),    # BASELINE configs[0]
+    ("yolov5_darknet_pan_s_r60", 32, 0.25, 0.5),   # BASELINE configs[1] at its batch size
+])
+def test_fp32_parity_mode_meets_north_star_tolerance(dev, arch, n, thr, head_gain):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    m, sd = _build(arch, dev, torch.float32, score_thresh=thr, head_gain=head_gain)
+    m.set_compute_dtype(torch.float32)
+    imgs_cpu = [synth_images(1, 640, 640, seed=i + 1)[0] for i in range(n)]
+    dets = m.predict([im.to(dev) for im in imgs_cpu])
+    e = next(iter(m.model._entries.values()))
+    assert e.plan.fp32 and e.x.dtype == torch.float32 and all(f.dtype == torch.float32 for f in e.feats)
+    sdf = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs_cpu, sdf, score_thresh=thr)
+    tot = {"ref": 0, "paired": 0, "excused_at_cut": 0, "unexplained": 0, "same_position": 0}
+    images_equal_count = images_labels_equal = 0
+    min_iou, max_ds = 1.0, 0.0
+    for r, d in zip(ref, dets):
+        c = direct_checks(_np(r), _np(d), thr)
+        for k in tot:
+            tot[k] += c[k]
+        images_equal_count += int(c["equal_count"])
+        images_labels_equal += int(c["labels_equal"])
+        min_iou, max_ds = min(min_iou, c["min_iou"]), max(max_ds, c["max_dscore"])
+    print(f"{arch} x{n}: {tot}, images with equal count {images_equal_count}/{n}, identical label sequence {images_labels_equal}/{n}, "
+          f"min IoU {min_iou:.6f}, max |dscore| {max_ds:.2e}")
+    assert tot["ref"] > 20 * n
+    assert tot["unexplained"] == 0, tot
+    assert min_iou >= 1 - 1e-3 and max_ds <= 1e-4
+    assert tot["excused_at_cut"] <= max(2, tot["ref"] // 500), tot          # flips exactly at the cut are rare
+    assert images_equal_count >= n - max(1, n // 8) and images_labels_equal >= n - max(1, n // 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# fp16 production path at the benchmark batch size, tightened matching (IoU >= 0.9)
+# ------------------------------------------------------------------------------------------------
+def test_fp16_bs32_vs_oracle_tight_matching(dev):
+    """BASELINE configs[1] at its own batch (the timed plan: bs-32 tiles, 20x20 head waves spanning images, prefix
+    selection) against the fp32 oracle, a match needing IoU >= 0.9 (round 1: 0.5).  16-bit STORAGE moves scores by ~1e-2
+    on this synthetic network, whose detections crowd the threshold and the top-K cut, so the yardstick is the oracle
+    itself with fp16 storage emulated between layers (O.EMULATE): the HIP path must match the fp32 reference as well as
+    that emulation does (per image within 0.15, on average within 0.03), and must match the EMULATION tightly."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_e2e_gpu import match_fraction
+    arch = "yolov5_darknet_pan_s_r60"
+    m, sd = _build(arch, dev, torch.float16, score_thresh=0.25)
+    imgs_cpu = list(synth_images(32, 640, 640, seed=1))
+    dets = m.predict([im.to(dev).half() for im in imgs_cpu])
+    sdf = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs_cpu, sdf, score_thresh=0.25)
+        O.EMULATE.dtype = torch.float16
+        try:
+            emu = O.yolov5_forward([im.half().float() for im in imgs_cpu], sdf, score_thresh=0.25)
+        finally:
+            O.EMULATE.dtype = None
+    fr, fe, fh, mi = [], [], [], []
+    for r, e, d in zip(ref, emu, dets):
+        f, miou, _ = match_fraction(_np(r), _np(d), iou_thr=0.9, score_tol=0.05, margin=0.03, thr=0.25)
+        f_emu, _, _ = match_fraction(_np(r), _np(e), iou_thr=0.9, score_tol=0.05, margin=0.03, thr=0.25)
+        f_he, _, _ = match_fraction(_np(e), _np(d), iou_thr=0.9, score_tol=0.02, margin=0.03, thr=0.25)
+        fr.append(f)
+        fe.append(f_emu)
+        fh.append(f_he)
+        mi.append(miou)
+    print(f"bs32 fp16, match = same label, IoU >= 0.9: HIP vs fp32 oracle mean {np.mean(fr):.3f} (min {np.min(fr):.3f}); "
+          f"fp16-emulating oracle vs fp32 oracle mean {np.mean(fe):.3f} (min {np.min(fe):.3f}); HIP vs emulation mean {np.mean(fh):.3f} (min {np.min(fh):.3f}); "
+          f"median IoU of matches {np.mean(mi):.4f}")
+    assert np.mean(fr) >= np.mean(fe) - 0.03, (np.mean(fr), np.mean(fe))
+    assert all(a >= b - 0.15 for a, b in zip(fr, fe)), list(zip(fr, fe))
+    assert np.mean(fh) >= 0.9, np.mean(fh)
+    assert np.mean(mi) >= 0.95
+
+
+# ------------------------------------------------------------------------------------------------
+# a18: the in-kernel rescale
+# ------------------------------------------------------------------------------------------------
+def test_in_kernel_rescale_equals_scale_coords(dev):
+    """gather_topk_kernel applies (box - pad) / gain per image (transform.py:354-367).  The same batch through
+    YOLO.forward (no rescale) + the oracle's scale_coords must give the same boxes to 1 ulp, for shapes that hit the
+    letterbox rounding traps."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    m, _ = _build("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.2, head_gain=1.0)
+    shapes = [(270, 203), (240, 320), (180, 320), (375, 500), (641, 480), (97, 311)]
+    imgs = [synth_images(1, h, w, seed=40 + i)[0].to(dev).half() for i, (h, w) in enumerate(shapes)]
+    dets = m.predict(imgs)                                   # rescale inside the top-k gather kernel
+    nested, _ = m.transform(imgs, dtype=torch.float16)
+    canvas = nested.tensors                                  # (N,3,Hb,Wb) letterboxed batch
+    hb, wb = int(canvas.shape[2]), int(canvas.shape[3])
+    raw = m.model(canvas)                                    # canvas coordinates, no rescale
+    total = 0
+    for d, r, (h, w) in zip(dets, raw, shapes):
+        assert torch.equal(d["labels"], r["labels"]) and torch.equal(d["scores"], r["scores"])
+        want = O.scale_coords(r["boxes"].cpu(), (hb, wb), (h, w)).numpy()
+        got = d["boxes"].cpu().numpy()
+        ulp = np.spacing(np.maximum(np.abs(want), 1.0).astype(np.float32))
+        assert np.all(np.abs(got - want) <= ulp), float(np.abs(got - want).max())
+        total += len(got)
+    assert total > 50

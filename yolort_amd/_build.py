@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.environ.get("YOLORT_AMD_BUILD_OUT") or os.path.join(LIBDIR, "libyolort_amd.so")   # override: tuning builds only
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_stem.hip", "preproc_pool.hip", "postprocess.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_stem.hip", "conv_f32.hip", "preproc_pool.hip", "postprocess.hip"]
 # the conv tile x dtype space and the fused heads are instantiated in their own translation units (parallel build)
 INST_SOURCES = sorted(f for f in os.listdir(CSRC) if (f.startswith("conv_inst_") or f.startswith("head_inst_")) and f.endswith(".hip"))
 MONOLITHIC = "-DYMI_STAMPS" in os.environ.get("YOLORT_AMD_BUILD_FLAGS", "")   # the timeline instrumentation keeps one device symbol: single TU
@@ -49,14 +49,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objs = []
 
+    hdr = hashlib.sha256()
+    for f in HEADERS:
+        hdr.update(open(f, "rb").read())
+    hdr.update(" ".join(FLAGS).encode())
+    hdr_digest = hdr.hexdigest()
+
     def compile_one(src: str) -> str:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + (".dbg.o" if os.environ.get("YOLORT_AMD_BUILD_OUT") else ".o"))
+        # incremental: an object is reused when its own source, every header and the flags are unchanged
+        odig = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr_digest.encode()).hexdigest()
+        ostamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            return obj
         cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
         if verbose and r.stderr.strip():
             print(r.stderr[-2000:], file=sys.stderr)
+        open(ostamp, "w").write(odig)
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:

@@ -129,7 +129,7 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     YMI_REQUIRE(d->cout_pad % 32 == 0 && d->k_pad % 32 == 0, "ymi_conv2d: cout_pad (%d) / k_pad (%d) must be multiples of 32", d->cout_pad, d->k_pad);
     YMI_REQUIRE(d->k_pad >= d->kh * d->kw * d->cin, "ymi_conv2d: k_pad %d < K %d", d->k_pad, d->kh * d->kw * d->cin);
     YMI_REQUIRE(d->y_cstride % 4 == 0 && (d->res == nullptr || d->res_cstride % 4 == 0), "ymi_conv2d: y/res cstride must be multiples of 4");
-    YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16, "ymi_conv2d: dtype must be F16 or BF16");
+    YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16 || d->dtype == YMI_F32, "ymi_conv2d: dtype must be F16, BF16 or F32 (parity mode)");
     YMI_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == YMI_F32, "ymi_conv2d: out_dtype must equal dtype or be F32");
     YMI_REQUIRE(d->ho == (d->h + 2 * d->ph - d->kh) / d->sh + 1 && d->wo == (d->w_in + 2 * d->pw - d->kw) / d->sw + 1,
                 "ymi_conv2d: output size %dx%d inconsistent with input %dx%d k%dx%d s%dx%d p%dx%d", d->ho, d->wo, d->h, d->w_in, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);
@@ -143,7 +143,7 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     { const int rc_args = fill_conv_args(d, a); if (rc_args != YMI_OK) return rc_args; }
     YMI_REQUIRE(a.split == 0 || (d->y2 != nullptr && a.split % 8 == 0 && a.split < d->cout && d->res == nullptr && d->out_dtype == d->dtype && d->y2_cstride % 8 == 0),
                 "ymi_conv2d: invalid second-output configuration");
-    YMI_REQUIRE(a.split == 0 || a.zeros != nullptr, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");
+    YMI_REQUIRE(a.split == 0 || a.zeros != nullptr || d->dtype == YMI_F32, "ymi_conv2d: the second output needs the pipelined kernel (desc.zeros)");
     YMI_REQUIRE(d->y2_mode == 0 || d->y2_mode == 1, "ymi_conv2d: unknown y2_mode %d", d->y2_mode);
     if (d->chain_w != nullptr) {
         const int k1 = d->cout_split > 0 ? d->cout_split : d->cout;
@@ -167,6 +167,10 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
         YMI_REQUIRE(d->y_cstride % 8 == 0 || d->out_dtype == YMI_F32, "ymi_conv2d: y_cstride must be a multiple of 8");
     }
     if (a.M == 0) return YMI_OK;
+    if (d->dtype == YMI_F32) {   // fp32 parity mode (conv_f32.hip): exact fp32 arithmetic, one tile configuration
+        YMI_REQUIRE(d->chain_w == nullptr && d->y2_mode == 0, "ymi_conv2d: fp32 parity mode has no chained conv / upsampled second output");
+        return conv_f32_launch(a, is1x1, s);
+    }
     if (d->dtype == YMI_F16) {
         if (d->out_dtype == YMI_F32) return launch_dtype<YMI_F16, YMI_F32>(a, is1x1, d->tile, s);
         return launch_dtype<YMI_F16, YMI_F16>(a, is1x1, d->tile, s);

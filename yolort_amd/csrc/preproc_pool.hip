@@ -262,6 +262,44 @@ __global__ __launch_bounds__(256) void spp_pool_kernel(uint16_t* buf, int n, int
     *reinterpret_cast<u32x4*>(o + 3 * c) = o13;
 }
 
+// fp32 parity-mode form of the pyramid (4 channels = 16 B per thread, direct 13x13 window; max is exact)
+__global__ __launch_bounds__(256) void spp_pool_f32_kernel(float* buf, int n, int h, int w, int c, int cs) {
+    const int c4 = c / 4;
+    const int64_t total = (int64_t)n * h * w * c4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cc = (int)(gid % c4) * 4;
+    const int64_t pix = gid / c4;
+    const int x = (int)(pix % w);
+    const int y = (int)((pix / w) % h);
+    const int img = (int)(pix / ((int64_t)w * h));
+    f32x4 m5, m9, m13;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m5[e] = m9[e] = m13[e] = -INFINITY;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)h) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)w) continue;
+            const int adx = dx < 0 ? -dx : dx;
+            const int r = ady > adx ? ady : adx;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(buf + ((int64_t)(img * h + yy) * w + xx) * cs + cc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m13[e] = fmaxf(m13[e], v[e]);
+                if (r <= 4) m9[e] = fmaxf(m9[e], v[e]);
+                if (r <= 2) m5[e] = fmaxf(m5[e], v[e]);
+            }
+        }
+    }
+    float* o = buf + pix * cs + cc;
+    *reinterpret_cast<f32x4*>(o + c) = m5;
+    *reinterpret_cast<f32x4*>(o + 2 * c) = m9;
+    *reinterpret_cast<f32x4*>(o + 3 * c) = m13;
+}
+
 // LDS cascade form of the same pyramid: one block per (image, CPB-channel chunk), CPB = 32 (8 when c % 32 != 0).
 // The h x w plane of those channels is staged in LDS in its storage type and three 5x5 max stages are applied back to
 // back, each separable (row pass then column pass): mp9 = mp5(mp5(x)), mp13 = mp5(mp9) -- the SPPF identity of the
@@ -448,7 +486,12 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
     YMI_REQUIRE(buf && c % 8 == 0 && cstride >= 4 * c && cstride % 8 == 0, "ymi_spp_pool: c %% 8 == 0 and cstride >= 4c required");
     const int64_t total = (int64_t)n * h * w * (c / 8);
     if (total == 0) return YMI_OK;
-    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_spp_pool: dtype must be F16/BF16");
+    if (dtype == YMI_F32) {   // fp32 parity mode
+        dim3 g32((unsigned)((2 * total + 255) / 256)), b32(256);
+        hipLaunchKernelGGL(spp_pool_f32_kernel, g32, b32, 0, (hipStream_t)stream, (float*)buf, n, h, w, c, cstride);
+        return check_launch("spp_pool_f32_kernel");
+    }
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_spp_pool: dtype must be F16/BF16/F32");
     const int G = (c % 32 == 0) ? 4 : 1;
     const size_t lds = (size_t)h * w * G * 16 * 3;
     if (lds <= 160 * 1024 - 512) {  // the plane of 8*G channels fits the 160 KB LDS three times
@@ -470,7 +513,8 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
 
 extern "C" int ymi_upsample2x(const void* x, int x_cstride, int n, int h, int w, int c, void* y, int y_cstride, int dtype, void* stream) {
     YMI_REQUIRE(x && y && c % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0, "ymi_upsample2x: channels/strides must be multiples of 8");
-    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_upsample2x: dtype must be F16/BF16");
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16 || dtype == YMI_F32, "ymi_upsample2x: dtype must be F16/BF16/F32");
+    if (dtype == YMI_F32) { c *= 2; x_cstride *= 2; y_cstride *= 2; }   // fp32 parity mode: a typeless 16-byte copy, counted in 2-byte units
     const int64_t total = (int64_t)n * h * w * (c / 8);
     if (total == 0) return YMI_OK;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -480,7 +524,8 @@ extern "C" int ymi_upsample2x(const void* x, int x_cstride, int n, int h, int w,
 
 extern "C" int ymi_copy_view(const void* x, int x_cstride, int npix, int c, void* y, int y_cstride, int dtype, void* stream) {
     YMI_REQUIRE(x && y && c % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0, "ymi_copy_view: channels/strides must be multiples of 8");
-    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_copy_view: dtype must be F16/BF16");
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16 || dtype == YMI_F32, "ymi_copy_view: dtype must be F16/BF16/F32");
+    if (dtype == YMI_F32) { c *= 2; x_cstride *= 2; y_cstride *= 2; }   // fp32 parity mode: typeless copy in 2-byte units
     const int64_t total = (int64_t)npix * (c / 8);
     if (total == 0) return YMI_OK;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);

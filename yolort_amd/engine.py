@@ -141,6 +141,7 @@ class Plan:
         # zero page for the pipelined conv kernel's out-of-range operand chunks (see yolort_amd.h)
         self.zeros = torch.zeros(1024, device=device, dtype=torch.uint8)
         self.conv_descs: Dict[int, ConvDesc] = {}
+        self.io: Dict[int, dict] = {}
         self.chain_1x1 = os.environ.get("YOLORT_AMD_CHAIN", "1") != "0"   # Bottleneck.cv1 chained into C3.cv1+cv2's launch
         # C3.cv3 chained into the last Bottleneck.cv2's launch (ymi_conv_desc.chain_x2): supported and tested, but measured
         # +-0 end to end (the pixel-major producer tiles it needs cost what the saved launch gains) -> off by default
@@ -149,6 +150,12 @@ class Plan:
         # per-shape tile selection by measurement at plan-build time ("measure, don't guess"): each conv is
         # timed once per candidate tile on its real buffers with HIP events; winners are cached per shape
         self.autotune = os.environ.get("YOLORT_AMD_AUTOTUNE", "1") == "1"
+        # fp32 PARITY MODE (csrc/conv_f32.hip): fp32 activations between layers and exact fp32 arithmetic, one kernel per
+        # reference conv -- no fused pairs / chained convs / folded upsample / fused head, no tile choice.  This is the mode
+        # in which the HIP path meets the north-star tolerance against the fp32 CPU reference end to end.
+        self.fp32 = dtype == torch.float32
+        if self.fp32:
+            self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
 
     def __del__(self):
         try:
@@ -221,6 +228,7 @@ class Plan:
         `x2` (view) makes it a conv over the concat [fresh outputs | x2] (C3.cv3 chained to the last Bottleneck.cv2)."""
         s = (stride, stride) if isinstance(stride, int) else tuple(stride)
         p = (pad, pad) if isinstance(pad, int) else tuple(pad)
+        x_arg = x
         if pc.stem_superpixel:
             if x.c != 4 or x.cs != 4 or x.w % 2:
                 raise YmiError("stem super-pixel conv needs a dense NHWC4 input with even width")
@@ -258,6 +266,10 @@ class Plan:
                 d.chain_x2, d.chain_x2_cstride, d.chain_k2 = x2.ptr, x2.cs, k2
             self.keep.append(pc2)
         self.conv_descs[self.num_ops] = d   # op index -> descriptor (the fused stem path re-issues op 0 from planar images)
+        # op index -> the views this launch reads / writes (per-layer parity tests fill `x` / `res` and read the outputs)
+        self.io[self.num_ops] = {"name": name, "x": x_arg, "y": out, "y2": out2, "split": split if out2 is not None else 0, "up2": up2_out, "res": res,
+                                 "chain_y": None if chain is None else chain[1], "chain_x2": None if chain is None or len(chain) < 3 else chain[2],
+                                 "stride": s, "pad": p}
         if self.autotune and tile == 0 and d.zeros:
             d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None, chain is not None))
         esz = 2

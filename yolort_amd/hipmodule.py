@@ -19,8 +19,9 @@ from .engine import Plan, View
 
 
 def compute_dtype_of(module: nn.Module) -> torch.dtype:
-    """fp16/bf16 models compute in their own dtype; fp32-parameter models compute in
-    `module.compute_dtype` (default fp16) with fp32 accumulation -- the engine has no fp32 MFMA path."""
+    """fp16/bf16 models compute in their own dtype; fp32-parameter models compute in `module.compute_dtype`: fp16 by
+    default (16-bit storage, fp32 accumulation), or torch.float32 = the PARITY MODE of csrc/conv_f32.hip (fp32 storage and
+    exact fp32 MFMA arithmetic; ~16x slower, reproduces the fp32 CPU reference to rounding-order accuracy)."""
     p = next(module.parameters(), None)
     if p is not None and p.dtype in (torch.float16, torch.bfloat16):
         return p.dtype
@@ -85,6 +86,10 @@ class HipModule(nn.Module):
                 raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
             if t.dim() != 4:
                 raise ValueError(f"expected NCHW tensors, got shape {tuple(t.shape)}")
+        with torch.cuda.device(xs[0].device):   # plan construction and launches run on the inputs' device
+            return self._forward_on_device(xs, is_list)
+
+    def _forward_on_device(self, xs, is_list):
         cdt = compute_dtype_of(self)
         key = (tuple(tuple(t.shape) for t in xs), cdt, xs[0].device.index, weights_signature(self))
         entry = self._plans.get(key)

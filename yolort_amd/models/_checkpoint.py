@@ -5,7 +5,8 @@ unpickles it with its vendored copy of the upstream classes (yolort/v5, yolort/v
 Here no upstream code is vendored: every class the pickle names outside torch / numpy / builtins is
 replaced, while unpickling, by an empty ``nn.Module`` stub that just receives the pickled ``__dict__``
 (parameters, buffers, sub-modules, ``yaml``, ``stride``).  Nothing from the file is executed beyond
-the tensor rebuild functions of torch itself.  Layer indices are then renamed to the yolort layout
+an explicit allow-list of (module, name) data constructors -- the tensor rebuild functions of torch itself,
+OrderedDict, numpy's array reconstructors; dotted names are refused.  Layer indices are then renamed to the yolort layout
 (index maps: reference _checkpoint.py:53-64) and, like the reference (:81), the weights come back
 fp16-rounded.
 """
@@ -19,12 +20,32 @@ import torch
 from torch import nn
 
 _SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object"}
-_SAFE_FUNCTION_MODULES = ("torch._utils", "torch._tensor", "torch.nn.parameter", "numpy.core.multiarray", "numpy._core.multiarray", "_codecs",
-                          "copyreg", "copy_reg", "collections")
+# The ONLY callables a checkpoint may resolve to real objects: an explicit (module, name) allow-list of data
+# constructors.  A module-level trust ("everything in torch._utils") is NOT safe -- torch._utils._import_dotted_name,
+# collections._sys, ... lead straight to os.system -- and protocol-4 dotted names ("traceback.linecache.os.getcwd")
+# traverse attributes, so any name containing a dot is refused as well.
+_SAFE_CALLABLES = {
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch.nn.parameter", "Buffer"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"), ("torch.storage", "_LegacyStorage"),
+    ("collections", "OrderedDict"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("_codecs", "encode"),
+    ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"),
+}
+_TORCH_STORAGE_NAMES = {f"{t}Storage" for t in ("Float", "Half", "BFloat16", "Double", "Long", "Int", "Short", "Char", "Byte", "Bool")}
 
 
 class _UpstreamStub(nn.Module):
     """stand-in for any upstream class (models.yolo.Model, models.common.Conv, ...): state only, no code"""
+
+    def __init__(self, *args, **kwargs):   # a pickle may "call" the class with arguments (REDUCE): they are dropped
+        super().__init__()
 
     def forward(self, *args, **kwargs):  # pragma: no cover
         raise RuntimeError("upstream modules are not executable here; only their state is read")
@@ -32,20 +53,23 @@ class _UpstreamStub(nn.Module):
 
 class _StubUnpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
-        """Only data constructors resolve to real objects: safe builtins, torch / numpy *types* and the
-        tensor-rebuild helpers.  Everything else the pickle names (upstream classes, but also any
-        callable an untrusted file might smuggle in) becomes an inert nn.Module stub."""
-        root = module.split(".")[0]
-        if root in ("builtins", "__builtin__"):
-            if name in _SAFE_BUILTINS:
+        """Resolves ONLY: safe builtins, the allow-listed data constructors above, torch dtypes / legacy storage classes and
+        the parameter containers of torch.nn.modules (nn.Module subclasses, which the upstream tree is made of).  Everything
+        else the pickle names -- upstream classes, but also any callable an untrusted file smuggles in, however it is
+        spelled -- becomes an inert nn.Module stub; nothing from the file is ever imported or executed."""
+        if "." not in name:
+            if module in ("builtins", "__builtin__"):
+                if name in _SAFE_BUILTINS:
+                    return super().find_class(module, name)
+            elif (module, name) in _SAFE_CALLABLES:
                 return super().find_class(module, name)
-        elif module in _SAFE_FUNCTION_MODULES:
-            return super().find_class(module, name)
-        elif root in ("torch", "numpy", "pathlib", "argparse"):
-            obj = super().find_class(module, name)
-            if isinstance(obj, type):
-                return obj
-        return type(name, (_UpstreamStub,), {"__module__": module})
+            elif module == "torch" and (name in _TORCH_STORAGE_NAMES or isinstance(getattr(torch, name, None), torch.dtype)):
+                return getattr(torch, name)
+            elif module.startswith("torch.nn.modules."):
+                obj = super().find_class(module, name)
+                if isinstance(obj, type) and issubclass(obj, nn.Module):
+                    return obj
+        return type(name.replace(".", "_"), (_UpstreamStub,), {"__module__": module})
 
 
 class _StubPickle:

@@ -45,6 +45,7 @@ class _PlanEntry:
         self.rescale_host = torch.zeros(n, 3, dtype=torch.float32).pin_memory() if post is not None else None
         self.result_host = torch.zeros(4 + n, dtype=torch.int32).pin_memory() if post is not None else None
         self.done = None        # event recorded after the post-process + result copy of the last submit
+        self.outstanding = None  # the PendingDetections of the last submit while the host has not collected it yet
         self.post_stream = torch.cuda.Stream(device=x.base.device) if post is not None else None
         # each plan instance runs its conv stack on its own stream: consecutive batches overlap on the GPU
         # (the tail of one batch's kernels is filled by the next batch's), measured +12 % on yolov5s bs 32
@@ -58,15 +59,28 @@ class PendingDetections:
     def __init__(self, owner: "YOLO", entry: _PlanEntry, rows, hook_result=None, planar=None):
         self.owner, self.entry, self.rows, self.hook_result = owner, entry, rows, hook_result
         self.event = entry.done
+        self._result: Optional[List[Dict[str, Tensor]]] = None
         # planar input images when the stem read them directly (entry.x was never filled): a redo must start from them
         self.planar = planar
 
     def result(self) -> List[Dict[str, Tensor]]:
+        """blocks until this batch is done and returns its List[Dict]; idempotent (the first call detaches the results
+        from the plan instance's buffers, later calls return the same objects)"""
         if self.hook_result is not None:
             return self.hook_result
+        if self._result is None:
+            with torch.cuda.device(self.entry.x.base.device):
+                self._result = self._collect()
+            if self.entry.outstanding is self:
+                self.entry.outstanding = None
+        return self._result
+
+    def _collect(self) -> List[Dict[str, Tensor]]:
         e = self.entry
         self.event.synchronize()
         host = e.result_host.tolist()
+        if host[1] != 0 and e.outstanding is self:
+            e.outstanding = None   # a redo below may recycle this very instance: it must not wait for this handle again
         if host[1] & 2 and not host[1] & 1:   # the score prefix of a crowded image gave < detections_per_img survivors: exact full pass
             if os.environ.get("YOLORT_AMD_VERBOSE"):
                 print("[yolort_amd] score-prefix selection fell short: re-running with the full candidate set", flush=True)
@@ -115,7 +129,6 @@ class YOLO(nn.Module):
         self.cand_cap_per_image = int(os.environ.get("YOLORT_AMD_CAND_CAP", "16384"))
         self._entries: Dict[Tuple, _PlanEntry] = {}
         self._ring: Dict[Tuple, List[_PlanEntry]] = {}
-        self._ring_pos = 0
         # decode + threshold inside the head convolution's epilogue (the fp32 logits never reach memory); False keeps the
         # logits as plan buffers (`entry.logits`) and decodes them in the post-process op -- identical detections
         self.fuse_head_decode = os.environ.get("YOLORT_AMD_FUSED_HEAD", "1") != "0"
@@ -123,35 +136,71 @@ class YOLO(nn.Module):
         self.stem_from_planar = os.environ.get("YOLORT_AMD_STEM_PLANAR", "1") != "0"
         # True once a batch needed the full candidate set (include/yolort_amd.h YMI_POST_EXACT_FULL); sticky for this model
         self.post_exact_full = os.environ.get("YOLORT_AMD_POST_EXACT_FULL", "0") == "1"
-        self.pipeline_depth = 4   # plan instances per shape: later batches run while batch i is post-processed / collected
+        self.pipeline_depth = 4   # plan instances per shape (built lazily): later batches run while batch i is post-processed / collected
+        self.max_shapes = int(os.environ.get("YOLORT_AMD_MAX_SHAPES", "4"))                       # LRU of (batch, canvas) shapes with live plans
+        self.max_plan_bytes = int(float(os.environ.get("YOLORT_AMD_MAX_PLAN_GB", "96")) * 2**30)    # activation memory bound of that LRU
         self._has_warned = False
         # measurement hook (bench.py): (n_ops, starts, ends) -> HIP events around ops [0, n_ops) of every run
         self.bracket = None
 
     # ------------------------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype: torch.dtype) -> "YOLO":
+        """compute / storage type of the conv stack while the parameters are fp32: torch.float16 (default), torch.bfloat16,
+        or torch.float32 = parity mode (exact fp32 arithmetic, csrc/conv_f32.hip).  fp16 / bf16 parameter models always
+        compute in their own dtype."""
+        if dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            raise ValueError(f"unsupported compute dtype {dtype}")
+        self.compute_dtype = dtype
+        return self
+
     def fused(self) -> bool:
         return type(self.head) is YOLOHead and type(self.post_process) is PostProcess and type(self.anchor_generator) is AnchorGenerator and hasattr(self.backbone, "emit")
 
     def _entry(self, n: int, h: int, w: int, device: torch.device) -> _PlanEntry:
+        """a plan instance of this shape whose previous batch has been collected by the host.  Instances are built lazily
+        (one at first use, another only when a batch is submitted while every existing one is still in flight, up to
+        `pipeline_depth`); when all are busy the oldest is recycled after its uncollected results have been moved into
+        their handle (PendingDetections) -- a handle never reads buffers that a later batch has overwritten.  Shapes are
+        kept in a small LRU (`max_shapes`, `max_plan_bytes`): variable-size letterbox streams alternate between a few
+        canvases without rebuilding plans."""
         cdt = compute_dtype_of(self)
         pp = self.post_process
         post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
         key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode, self.post_exact_full)
         ring = self._ring.get(key)
-        if ring is not None:
-            self._ring_pos = (self._ring_pos + 1) % len(ring)
-            e = ring[self._ring_pos]
-            self._entries = {key: e}
-            return e
-        self._entries.clear()  # one live shape at a time keeps HBM use bounded
-        self._ring.clear()
-        if not hasattr(self.backbone, "emit"):
-            raise YmiError("the backbone must be a yolort_amd HIP module (custom torch backbones have no MI355X path)")
-        ring = [self._build_entry(n, h, w, device, cdt, pp) for _ in range(max(1, self.pipeline_depth))]
-        self._ring[key] = ring
-        self._ring_pos = 0
-        self._entries[key] = ring[0]
-        return ring[0]
+        if ring is None:
+            if not hasattr(self.backbone, "emit"):
+                raise YmiError("the backbone must be a yolort_amd HIP module (custom torch backbones have no MI355X path)")
+            ring = self._ring[key] = []
+        else:
+            self._ring[key] = self._ring.pop(key)   # most recently used last
+        e = None
+        for cand in ring:   # a free instance: nothing outstanding and its GPU work has drained
+            if cand.outstanding is None and (cand.done is None or cand.done.query()):
+                e = cand
+                break
+        if e is None and len(ring) < max(1, self.pipeline_depth):
+            self._evict(key)
+            e = self._build_entry(n, h, w, device, cdt, pp)
+            ring.append(e)
+        if e is None:       # all busy: recycle the oldest
+            e = ring.pop(0)
+            ring.append(e)
+            if e.outstanding is not None:
+                e.outstanding.result()   # host-synchronises on that batch and detaches its results from e's buffers
+        self._entries = {key: e}
+        return e
+
+    def _evict(self, keep_key) -> None:
+        """drop least-recently-used shapes beyond `max_shapes` / `max_plan_bytes` (never the shape in use; instances with an
+        uncollected batch are collected first)"""
+        def total() -> int:
+            return sum(en.plan.bytes_allocated for r in self._ring.values() for en in r)
+        while len(self._ring) > 1 and (len(self._ring) > self.max_shapes or total() > self.max_plan_bytes):
+            victim = next(k for k in self._ring if k != keep_key)
+            for en in self._ring.pop(victim):
+                if en.outstanding is not None:
+                    en.outstanding.result()
 
     def _build_entry(self, n: int, h: int, w: int, device: torch.device, cdt, pp) -> _PlanEntry:
         plan = Plan(device, cdt)
@@ -213,7 +262,9 @@ class YOLO(nn.Module):
         e.done.record(side)
         if self.pipeline_depth <= 1:
             main.wait_event(e.done)
-        return PendingDetections(self, e, rescale_rows, planar=planar)
+        pd = PendingDetections(self, e, rescale_rows, planar=planar)
+        e.outstanding = pd
+        return pd
 
     def _acquire(self, n: int, h: int, w: int, device: torch.device) -> _PlanEntry:
         """next plan instance of the ring for this shape; waits (on the GPU, not the host) until the
@@ -228,9 +279,9 @@ class YOLO(nn.Module):
         """re-run a batch synchronously on a (re)built plan instance: from the planar images when the stem read those
         directly (the NHWC4 buffer of the old entry was never filled then), else from the old entry's input buffer"""
         x_old = e_old.x
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(x_old.base.device)
         e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
-        with torch.cuda.stream(e2.main_stream):
+        with torch.cuda.device(x_old.base.device), torch.cuda.stream(e2.main_stream):
             if planar is not None and e2.plan.stem_planar_ok(planar, (x_old.h, x_old.w)):
                 e2.plan.stem_from_planar(planar)
                 return self._submit_entry(e2, rescale_rows, 1, planar=planar).result()
@@ -265,10 +316,11 @@ class YOLO(nn.Module):
         if not samples.is_cuda:
             raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
         n, c, h, w = samples.shape
-        e = self._acquire(n, h, w, samples.device)
-        with torch.cuda.stream(e.main_stream):
-            nchw_to_view(e.plan, samples, 4, out=e.x)
-            return self._submit_entry(e, None)
+        with torch.cuda.device(samples.device):   # plans, streams and launches belong to the inputs' device, whatever the caller's current one is
+            e = self._acquire(n, h, w, samples.device)
+            with torch.cuda.stream(e.main_stream):
+                nchw_to_view(e.plan, samples, 4, out=e.x)
+                return self._submit_entry(e, None)
 
     def forward(self, samples: Tensor, targets: Optional[Tensor] = None):
         """samples: batched images (N,3,H,W) in 0-1 range (reference yolo.py:141-183)."""

@@ -39,6 +39,11 @@ class YOLOv5(nn.Module):
         self.transform = YOLOTransform(size[0], size[1], size_divisible=size_divisible, fixed_shape=fixed_shape, fill_color=fill_color)
         self._has_warned = False
 
+    def set_compute_dtype(self, dtype: torch.dtype) -> "YOLOv5":
+        """see YOLO.set_compute_dtype (torch.float32 = fp32 parity mode for fp32-parameter models)"""
+        self.model.set_compute_dtype(dtype)
+        return self
+
     def forward(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
         """inputs: iterable of (3,H,W) tensors in 0-1 range (or uint8 0-255), possibly of different sizes
         (reference yolov5.py:135-189).  Returns List[Dict] with boxes in ORIGINAL image coordinates."""
@@ -76,6 +81,11 @@ class YOLOv5(nn.Module):
         model = self.model
         if not isinstance(model, YOLO):
             raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
+        with torch.cuda.device(images[0].device):   # plans, streams and launches belong to the images' device
+            return self._enqueue(model, images, (hb, wb), sizes, pads, rows_cached, identity, original)
+
+    def _enqueue(self, model: YOLO, images, canvas, sizes, pads, rows_cached, identity, original):
+        hb, wb = canvas
         e = model._acquire(len(images), hb, wb, images[0].device)
         with torch.cuda.stream(e.main_stream):
             # fixed-size stream: every image already is the canvas (resize = identity, no padding) in the compute dtype ->

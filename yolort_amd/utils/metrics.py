@@ -3,8 +3,9 @@
 `coco_ap` restates the published COCO detection protocol (AP averaged over IoU 0.50:0.05:0.95, 101-point interpolated
 precision, greedy score-ordered matching per class and image) for box detections.  `DetectionEvaluator` offers the
 update()/compute() surface of the reference's evaluator (yolort/data/coco_eval.py:28-120, which wraps pycocotools --
-absent here) on in-memory ground truth: SURVEY.md 8f-4.  Crowd / area-range / max-dets refinements of the COCO API are
-not modelled (no crowd boxes, all areas, every detection handed in is scored).
+absent here) on in-memory ground truth: SURVEY.md 8f-4.  COCO's maxDets = 100 cap (the top-100 detections of an image by
+score are evaluated) and its exact threshold grid linspace(.5, .95, 10) are applied; crowd boxes and the small / medium /
+large area ranges are not modelled (no crowd boxes, all areas).
 """
 from __future__ import annotations
 
@@ -21,11 +22,25 @@ def _iou_matrix(a, b):
     return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
 
 
-def coco_ap(refs, dets, num_classes=80, thrs=None):
+COCO_IOU_THRS = np.linspace(0.5, 0.95, 10)   # pycocotools Params.iouThrs (np.arange(.5, .96, .05) drifts: 0.7000000000000001 ...)
+COCO_MAX_DETS = 100
+
+
+def _top_dets(d, max_dets):
+    """the `max_dets` best detections of one image by score (stable), as pycocotools evaluates them (maxDets)"""
+    if max_dets is None or len(d["scores"]) <= max_dets:
+        return d
+    keep = np.argsort(-d["scores"], kind="stable")[:max_dets]
+    return {"boxes": d["boxes"][keep], "scores": d["scores"][keep], "labels": d["labels"][keep]}
+
+
+def coco_ap(refs, dets, num_classes=80, thrs=None, max_dets=None):
     """COCO-style AP@[.5:.95] (101-point interpolation, greedy score-ordered matching per class and image) of `dets`
     with the ORACLE's detections `refs` as ground truth -- the 'mAP vs ref' of SURVEY.md 8d.  Lists of per-image dicts
-    of numpy arrays {boxes (n,4), scores (n), labels (n)}."""
-    thrs = np.arange(0.5, 0.96, 0.05) if thrs is None else np.asarray(thrs)
+    of numpy arrays {boxes (n,4), scores (n), labels (n)}.  `max_dets`: keep only the best N detections per image
+    (COCO: 100); None scores everything handed in (the bench's mAP-vs-ref compares full 300-detection outputs)."""
+    thrs = COCO_IOU_THRS if thrs is None else np.asarray(thrs)
+    dets = [_top_dets(d, max_dets) for d in dets]
     aps = []
     for c in range(num_classes):
         n_gt = sum(int((r["labels"] == c).sum()) for r in refs)
@@ -75,8 +90,9 @@ class DetectionEvaluator:
     """Accumulates detections and ground truth per image; compute() returns COCO-style numbers in the 0-100 range
     (like the reference: yolort/data/coco_eval.py:31-34), -1 when nothing can be scored."""
 
-    def __init__(self, num_classes: int = 80):
+    def __init__(self, num_classes: int = 80, max_dets: Optional[int] = COCO_MAX_DETS):
         self.num_classes = num_classes
+        self.max_dets = max_dets   # COCO evaluates the top-100 detections per image (the model's default keeps 300)
         self._preds: List[Dict[str, np.ndarray]] = []
         self._gts: List[Dict[str, np.ndarray]] = []
 
@@ -108,8 +124,8 @@ class DetectionEvaluator:
     def compute(self) -> Dict[str, float]:
         if not self._gts:
             return {"AP": -1.0, "AP50": -1.0, "AP75": -1.0}
-        ap = coco_ap(self._gts, self._preds, self.num_classes)
-        ap50 = coco_ap(self._gts, self._preds, self.num_classes, thrs=np.array([0.5]))
-        ap75 = coco_ap(self._gts, self._preds, self.num_classes, thrs=np.array([0.75]))
+        ap = coco_ap(self._gts, self._preds, self.num_classes, max_dets=self.max_dets)
+        ap50 = coco_ap(self._gts, self._preds, self.num_classes, thrs=np.array([0.5]), max_dets=self.max_dets)
+        ap75 = coco_ap(self._gts, self._preds, self.num_classes, thrs=np.array([0.75]), max_dets=self.max_dets)
         f = lambda v: -1.0 if v is None else 100.0 * v  # noqa: E731
         return {"AP": f(ap), "AP50": f(ap50), "AP75": f(ap75)}
