@@ -1,20 +1,27 @@
 """Throughput benchmark of the MI355X YOLOv5 inference hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                      (BASELINE configs[1]: yolov5s fp16 bs 32 640x640)
+    python bench.py --config c3|c5|c1 ...                              (the other BASELINE configs, see CONFIGS below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path over one batch of 32 synthetic 640x640 images per GPU:
-letterbox -> CSPDarknet+PAN -> head -> decode + class-aware NMS + top-k + rescale -> List[Dict], with
-the images already resident in HBM (fp16, 0-1 range).  With N > 1 every rank runs its own shard
-(weak scaling: 32 images per GPU) and the fixed-shape detection slabs are all-gathered over RCCL.
+A "step" is one pass of the whole hot path over one batch of synthetic images per GPU: letterbox -> CSPDarknet+PAN ->
+head -> decode + class-aware NMS + top-k + rescale -> List[Dict], with the images already resident in HBM.  With N > 1
+every rank runs its own shard (weak scaling: `batch` images per GPU) and the fixed-shape detection slabs are all-gathered
+over RCCL.
 
 Rank 0 prints ONE JSON line: BASELINE.json's metric plus
-  "roofline"     : conv stack (the dominant kernel family, conv_igemm_kernel) -- algorithmic bytes of
-                   all conv launches of one step / time of those launches, measured with HIP events on
-                   the plan's stream inside the timed region, against the 8 TB/s HBM peak; the
-                   per-layer max(flops/2.5PF, bytes/8TB/s) bound of SURVEY.md 8d is reported too.
-  "cpu_baseline" : the oracle (CPU fp32 restatement of the reference) timed on this box's host cores
-                   on a bounded sample of the same workload (rank 0, N=1 only).
+  "roofline"     : the conv stack (dominant kernel family: conv_igemm_v2_kernel / conv3x3_halo_kernel / conv_halo8_kernel /
+                   conv_stem_planar_kernel / conv_head_decode_group_kernel) -- algorithmic bytes per launch / average launch
+                   time, where the launch time comes from HIP events recorded on the plan's own stream around the conv
+                   launches of batches that run ALONE on the GPU (one batch in flight, measured right after the timed
+                   region, same process, same buffers): the number rocprofv3's kernel durations reproduce.  The in-region
+                   figure (several batches sharing the GPU) and the step-time-based upper bound are reported next to it, and
+                   the letterbox / post-process launches get their own HBM-roofline entries.
+  "cpu_baseline" : the oracle (CPU fp32 restatement of the reference) timed on this box's host cores on a bounded sample of
+                   the same workload, split into the stages of SURVEY.md 8d (transform / backbone+PAN / head / decode +
+                   threshold / NMS), rank 0, N=1 only.
+  "parity"       : mAP-vs-ref of the production (16-bit storage) path, and the direct checks of SURVEY.md 8d (equal counts,
+                   equal labels, |dscore|, IoU) of the fp32 parity mode against the fp32 oracle.
 """
 from __future__ import annotations
 
@@ -33,75 +40,194 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12   # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 MFMA_PEAK = 2.5e15  # FLOP/s dense fp16/bf16
 
+C3_SHAPES = [(1080, 1920), (720, 1280), (1920, 1080), (1080, 810), (960, 1280), (1281, 1279), (641, 480), (375, 500)]
+CONFIGS = {   # BASELINE.json `configs`
+    "c1": dict(arch="yolov5_darknet_pan_n_r60", dtype="fp16", batch=2, size=640, score_thresh=0.45, head_gain=1.0, shapes="fixed"),
+    "c2": dict(arch="yolov5_darknet_pan_s_r60", dtype="fp16", batch=32, size=640, score_thresh=0.25, head_gain=0.5, shapes="fixed"),
+    "c3": dict(arch="yolov5_darknet_pan_m_r60", dtype="bf16", batch=64, size=1280, score_thresh=0.25, head_gain=2.0, shapes="dynamic"),
+    "c5": dict(arch="yolov5_darknet_pan_l6_r60", dtype="fp16", batch=8, size=1280, score_thresh=0.25, head_gain=3.0, shapes="fixed"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--arch", default="yolov5_darknet_pan_s_r60")
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--score-thresh", type=float, default=0.25)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config preset (default: the headline, configs[1])")
+    ap.add_argument("--arch", default=None)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
+    ap.add_argument("--shapes", default=None, choices=["fixed", "dynamic"], help="dynamic: image sizes cycled from SURVEY 8d's list (real letterbox)")
+    ap.add_argument("--score-thresh", type=float, default=None)
+    ap.add_argument("--head-gain", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(host cpus, 32))")
     ap.add_argument("--per-op", default="", help="write a per-op profile (json) to this path after the timed run")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("YOLORT_AMD_GRAPH", "0")), help="replay the conv stack as a captured hipGraph")
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = CONFIGS[a.config]
+    for k, v in preset.items():
+        if getattr(a, k.replace("-", "_"), None) is None:
+            setattr(a, k, v)
+    big = a.size > 640 or a.arch.split("_")[-2] in ("m", "l", "x", "l6", "m6", "x6")
+    if a.steps is None:
+        a.steps = 20 if big else 60
+    if a.warmup is None:
+        a.warmup = 5 if big else 10
+    return a
 
 
-def cpu_baseline(arch, sd, images_cpu, score_thresh, budget_s=25.0):
-    """oracle (port of the reference's algorithm) on the host cores, bounded sample"""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = port of the reference's algorithm), stage split of SURVEY.md 8d
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args, sd, images_cpu, budget_s=14.0):
     from oracle import yolov5_oracle as O
 
-    cores = min(os.cpu_count() or 1, 32)  # torch CPU convs stop scaling (and thrash) far below 256 threads
+    host = os.cpu_count() or 1
+    cores = args.cpu_threads or min(host, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    thr = args.score_thresh
+
+    def staged(imgs):
+        t = {}
+        t0 = time.perf_counter()
+        batch, _ = O.letterbox(imgs, args.size, args.size, kw.get("size_divisible", 32))
+        t["transform"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        feats = O.backbone(batch, sd, "model.backbone")
+        t["backbone_pan"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ho = O.head(feats, sd, "model.head")
+        t["head"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        strides, anchors = O.anchors_for(len(ho))
+        pred = O.decode(ho, strides, anchors)
+        cands = []
+        for i in range(pred.shape[0]):   # box_head.py:414-419: scores, boxes, multi-label threshold
+            p = pred[i]
+            scores = p[:, 5:] * p[:, 4:5]
+            cx, cy, w, h = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+            boxes = torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
+            inds, labels = torch.where(scores > thr)
+            cands.append((boxes[inds], scores[inds, labels], labels))
+        t["decode_threshold"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n_c = 0
+        for b, s, l in cands:            # box_head.py:422-427 (plain-C restatement of torchvision's batched_nms, oracle/nms_ref.c)
+            O.batched_nms(b, s, l, 0.45)[:300]
+            n_c += len(s)
+        t["nms"] = time.perf_counter() - t0
+        return t, n_c
+
     imgs = [im.float() for im in images_cpu]
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.yolov5_forward(imgs[:4], sd, score_thresh=score_thresh)  # warm-up on 4 images
+        staged(imgs[:1])                                       # warm-up (thread pool, oneDNN primitives)
         warm = time.perf_counter() - t0
-        n_sample = max(4, min(len(imgs), int(4 * (budget_s * 0.45) / max(warm, 1e-3)) // 4 * 4))
+        n_sample = int(max(1, min(len(imgs), budget_s / max(warm, 1e-3))))
         t0 = time.perf_counter()
-        passes = 0
-        while True:
-            O.yolov5_forward(imgs[:n_sample], sd, score_thresh=score_thresh)
-            passes += 1
-            dt = time.perf_counter() - t0
-            if passes >= 2 or dt > budget_s * 0.5:
-                break
-    return {"value": round(passes * n_sample / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{passes} pass(es) of {n_sample} images 640x640 through oracle/yolov5_oracle.py (fp32, torch CPU, {cores} threads), incl. letterbox+NMS"}
+        stages, n_c = staged(imgs[:n_sample])
+        dt = time.perf_counter() - t0
+    return {"value": round(n_sample / dt, 3), "unit": "images/s", "cores": cores, "host_cpus": host, "kind": "port",
+            "stages_ms_per_image": {k: round(v / n_sample * 1e3, 2) for k, v in stages.items()},
+            "candidates_per_image": round(n_c / n_sample, 1),
+            "sample": f"one pass of {n_sample} image(s) of the workload through oracle/yolov5_oracle.py (fp32, torch CPU, {cores} threads), all stages; "
+                      "NMS is the oracle's plain-C restatement (single thread), not torchvision's kernel"}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# parity sample
+# ----------------------------------------------------------------------------------------------------------------------
 from yolort_amd.utils.metrics import coco_ap  # noqa: E402  (host-side metric; re-exported for tests)
 
 
-def parity_sample(model, images_gpu, images_cpu, sd, score_thresh, k=4):
-    """'mAP vs ref' on a bounded sample: HIP detections scored against the oracle's as ground truth."""
+def _npd(d):
+    return {"boxes": d["boxes"].detach().float().cpu().numpy(), "scores": d["scores"].detach().float().cpu().numpy(), "labels": d["labels"].detach().cpu().numpy()}
+
+
+def direct_checks(ref, got, thr, k=300, score_eps=1e-4, iou_min=1 - 1e-3):
+    """SURVEY.md 8d direct checks over a list of images (numpy dicts): pairs every reference detection with a HIP detection
+    of the same label, |dscore| <= score_eps and IoU >= iou_min; detections within score_eps of the threshold / top-K cut may
+    appear on one side only (fp32 summation order decides) and are reported as `at_cut`."""
+    import numpy as np
+
+    out = {"images": len(ref), "ref_dets": 0, "hip_dets": 0, "paired": 0, "at_cut": 0, "unexplained": 0, "images_equal_count": 0, "images_labels_equal": 0,
+           "min_iou": 1.0, "max_dscore": 0.0}
+    for r, g in zip(ref, got):
+        rb, rs, rl, gb, gs, gl = r["boxes"], r["scores"], r["labels"], g["boxes"], g["scores"], g["labels"]
+        out["ref_dets"] += len(rs)
+        out["hip_dets"] += len(gs)
+        out["images_equal_count"] += int(len(rs) == len(gs))
+        out["images_labels_equal"] += int(len(rs) == len(gs) and bool(np.array_equal(rl, gl)))
+        cut = thr
+        if len(rs) >= k or len(gs) >= k:
+            cut = max(thr, float(min(rs[-1] if len(rs) else 1.0, gs[-1] if len(gs) else 1.0)))
+        used = np.zeros(len(gs), bool)
+        for i in range(len(rs)):
+            cand = np.where((gl == rl[i]) & ~used & (np.abs(gs - rs[i]) <= score_eps))[0]
+            best, bj = -1.0, -1
+            for j in cand:
+                x1, y1 = max(rb[i, 0], gb[j, 0]), max(rb[i, 1], gb[j, 1])
+                x2, y2 = min(rb[i, 2], gb[j, 2]), min(rb[i, 3], gb[j, 3])
+                inter = max(x2 - x1, 0.0) * max(y2 - y1, 0.0)
+                iou = inter / ((rb[i, 2] - rb[i, 0]) * (rb[i, 3] - rb[i, 1]) + (gb[j, 2] - gb[j, 0]) * (gb[j, 3] - gb[j, 1]) - inter + 1e-30)
+                if iou > best:
+                    best, bj = iou, j
+            if bj >= 0 and best >= iou_min:
+                used[bj] = True
+                out["paired"] += 1
+                out["min_iou"] = min(out["min_iou"], float(best))
+                out["max_dscore"] = max(out["max_dscore"], abs(float(gs[bj] - rs[i])))
+            elif rs[i] <= cut + score_eps:
+                out["at_cut"] += 1
+            else:
+                out["unexplained"] += 1
+        for j in np.where(~used)[0]:
+            if gs[j] <= cut + score_eps:
+                out["at_cut"] += 1
+            else:
+                out["unexplained"] += 1
+    out["min_iou"] = round(out["min_iou"], 6)
+    out["max_dscore"] = float(f"{out['max_dscore']:.3e}")
+    return out
+
+
+def parity_sample(args, model, images_gpu, images_cpu, sd, k):
+    """'mAP vs ref' on a bounded sample: HIP detections scored against the oracle's as ground truth, plus the
+    direct checks of the fp32 parity mode"""
     import numpy as np
 
     from oracle import yolov5_oracle as O
+    from yolort_amd.models import YOLOv5
 
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    thr = args.score_thresh
+    cpu = [im.float() for im in images_cpu[:k]]
+    dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     with torch.no_grad():
-        ref = O.yolov5_forward([im.float() for im in images_cpu[:k]], sd, score_thresh=score_thresh)
-        # the same oracle with fp16 STORAGE emulated between layers (fp32 arithmetic): what any fp16-storage implementation
-        # can expect against the fp32 reference on this network -- the yardstick for the HIP path's own figure
-        O.EMULATE.dtype = torch.float16 if next(model.parameters()).dtype == torch.float16 else torch.bfloat16
-        try:
-            emu = O.yolov5_forward([im.to(O.EMULATE.dtype).float() for im in images_cpu[:k]], sd, score_thresh=score_thresh)
-        finally:
-            O.EMULATE.dtype = None
+        ref = O.yolov5_forward(cpu, sd, size=(args.size, args.size), score_thresh=thr, **kw)
+        emu = None
+        if args.size <= 640:
+            # the same oracle with 16-bit STORAGE emulated between layers (fp32 arithmetic): what any 16-bit-storage implementation
+            # can expect against the fp32 reference on this network -- the yardstick for the production path's own figure
+            O.EMULATE.dtype = dt16
+            try:
+                emu = O.yolov5_forward([im.to(dt16).float() for im in cpu], sd, size=(args.size, args.size), score_thresh=thr, **kw)
+            finally:
+                O.EMULATE.dtype = None
     got = model.forward(images_gpu[:k])
+    refs, gots = [_npd(r) for r in ref], [_npd(d) for d in got]
     ious, matched, total = [], 0, 0
-    for r, d in zip(ref, got):
-        rb, rl = r["boxes"].numpy(), r["labels"].numpy()
-        gb, gl = d["boxes"].float().cpu().numpy(), d["labels"].cpu().numpy()
-        total += len(rl)
-        for i in range(len(rl)):
-            c = np.where(gl == rl[i])[0]
+    for r, d in zip(refs, gots):
+        total += len(r["labels"])
+        for i in range(len(r["labels"])):
+            c = np.where(d["labels"] == r["labels"][i])[0]
             if len(c) == 0:
                 continue
+            rb, gb = r["boxes"], d["boxes"]
             x1, y1 = np.maximum(rb[i, 0], gb[c, 0]), np.maximum(rb[i, 1], gb[c, 1])
             x2, y2 = np.minimum(rb[i, 2], gb[c, 2]), np.minimum(rb[i, 3], gb[c, 3])
             inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
@@ -110,16 +236,27 @@ def parity_sample(model, images_gpu, images_cpu, sd, score_thresh, k=4):
             if best >= 0.5:
                 matched += 1
                 ious.append(best)
-    refs = [{"boxes": r["boxes"].numpy(), "scores": r["scores"].numpy(), "labels": r["labels"].numpy()} for r in ref]
-    gots = [{"boxes": d["boxes"].float().cpu().numpy(), "scores": d["scores"].float().cpu().numpy(), "labels": d["labels"].cpu().numpy()} for d in got]
     ap = coco_ap(refs, gots)
-    emus = [{"boxes": r["boxes"].numpy(), "scores": r["scores"].numpy(), "labels": r["labels"].numpy()} for r in emu]
-    ap_emu = coco_ap(refs, emus)
-    return {"images": k, "ref_dets": total, "matched_iou50": round(matched / max(total, 1), 4),
-            "median_iou": round(float(np.median(ious)), 4) if ious else None,
-            "map_vs_ref_50_95": round(ap, 4) if ap is not None else None,
-            "map_of_oracle_with_emulated_16bit_storage": round(ap_emu, 4) if ap_emu is not None else None,
-            "note": "oracle (fp32 CPU restatement of the reference) detections as ground truth; the HIP path stores fp16"}
+    out = {"images": k, "ref_dets": total, "matched_iou50": round(matched / max(total, 1), 4),
+           "median_iou": round(float(np.median(ious)), 4) if ious else None,
+           "map_vs_ref_50_95": round(ap, 4) if ap is not None else None,
+           "note": f"oracle (fp32 CPU restatement of the reference) detections as ground truth; the production path stores {args.dtype}"}
+    if emu is not None:
+        ap_emu = coco_ap(refs, [_npd(r) for r in emu])
+        out["map_of_oracle_with_emulated_16bit_storage"] = round(ap_emu, 4) if ap_emu is not None else None
+    # fp32 parity mode of the same model (csrc/conv_f32.hip) against the same oracle detections: the north-star tolerance
+    m32 = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=thr, nms_thresh=0.45, detections_per_img=300, **kw)
+    m32.load_state_dict(sd)
+    m32 = m32.to(images_gpu[0].device).eval().set_compute_dtype(torch.float32)
+    got32 = m32.forward([im.to(images_gpu[0].device) for im in cpu])
+    out["fp32_parity_mode_direct_checks"] = direct_checks(refs, [_npd(d) for d in got32], thr)
+    del m32
+    torch.cuda.empty_cache()
+    return out
+
+
+def _elapsed(pairs):
+    return [s.elapsed_time(t) for s, t in zip(*pairs)]
 
 
 def main():
@@ -143,13 +280,17 @@ def main():
     from yolort_amd.utils.synth import synth_images, synth_weights
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    model = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300)
-    sd = synth_weights(model.state_dict(), args.arch, seed=0)
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    model = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300, **kw)
+    sd = synth_weights(model.state_dict(), args.arch, seed=0, head_gain=args.head_gain)
     model.load_state_dict(sd)
     model = model.to(dev).to(dtype).eval()
 
     # each rank's shard of the (weak-scaled) global batch: seeds differ per rank
-    images_cpu = list(synth_images(args.batch, args.size, args.size, seed=1 + rank))
+    if args.shapes == "dynamic":
+        images_cpu = [synth_images(1, *C3_SHAPES[i % len(C3_SHAPES)], seed=1 + rank * 1000 + i)[0] for i in range(args.batch)]
+    else:
+        images_cpu = list(synth_images(args.batch, args.size, args.size, seed=1 + rank))
     images_gpu = [im.to(dev).to(dtype) for im in images_cpu]
 
     yolo = model.model
@@ -181,9 +322,7 @@ def main():
     dets = run_steps(max(args.warmup, 1))
     torch.cuda.synchronize()
     e = next(iter(yolo._entries.values()))
-    n_conv_ops = e.n_conv_ops
-    # conv-stack bracket events (recorded on the plan's stream inside the timed region)
-    yolo.bracket = (n_conv_ops, [], [])
+    yolo.bracket = {"pre": ([], []), "conv": ([], []), "post": ([], [])}   # event pairs recorded on the launching streams inside the timed region
 
     if world > 1:
         import torch.distributed as dist
@@ -200,17 +339,18 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    starts, ends = yolo.bracket[1], yolo.bracket[2]
-    conv_ms = sum(s.elapsed_time(t) for s, t in zip(starts, ends)) / max(len(starts), 1)
-    # the same conv launches with ONE batch in flight (no overlap with other batches' kernels), after the
-    # timed region: the in-region brackets above include the time a batch's kernels share the GPU with the
-    # neighbouring batches' conv / post-process kernels, this one is the exclusive duration
-    yolo.bracket = (n_conv_ops, [], [])
-    for _ in range(10):
+    region = {k: _elapsed(v) for k, v in yolo.bracket.items()}
+    # the same launches with ONE batch in flight (no overlap with other batches' kernels), right after the timed region:
+    # per-launch durations as rocprofv3 sees them.  The in-region brackets above include the time a batch's kernels share
+    # the GPU with the neighbouring batches' conv / post-process kernels.
+    yolo.bracket = {"pre": ([], []), "conv": ([], []), "post": ([], [])}
+    n_excl = 10
+    for _ in range(n_excl):
         collect(model.forward_async(images_gpu))
-    torch.cuda.synchronize()
-    conv_ms_excl = sum(s.elapsed_time(t) for s, t in zip(yolo.bracket[1], yolo.bracket[2])) / 10
+        torch.cuda.synchronize()
+    excl = {k: _elapsed(v) for k, v in yolo.bracket.items()}
     yolo.bracket = None
+    mean = lambda v: (sum(v) / len(v)) if v else 0.0  # noqa: E731
 
     if rank == 0:
         conv_meta = [m for m in e.plan.meta if m["kind"] == "conv"]
@@ -218,52 +358,74 @@ def main():
         bytes_step = sum(m["bytes"] for m in conv_meta)
         flops_step = sum(m["flops"] for m in conv_meta)
         bound_s = sum(max(m["flops"] / MFMA_PEAK, m["bytes"] / HBM_PEAK) for m in conv_meta)
-        conv_s = conv_ms * 1e-3
+        conv_s = mean(excl["conv"]) * 1e-3                 # serial duration of the conv launches of one step
+        conv_s_region = mean(region["conv"]) * 1e-3
+        step_s = elapsed / args.steps
         achieved = bytes_step / conv_s / 1e9 if conv_s > 0 else 0.0
         ips = world * args.batch * args.steps / elapsed
         # HBM traffic of the conv launches from the committed PMC passes (rocprofv3 cannot run inside this process):
         # per launch like `achieved`; only quoted for the workload it was measured on
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv_traffic.json")
-        if os.path.exists(tpath) and args.arch == "yolov5_darknet_pan_s_r60" and args.batch == 32 and args.size == 640 and args.dtype == "fp16":
+        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")
+        if os.path.exists(tpath) and args.config == "c2" and args.arch == CONFIGS["c2"]["arch"] and args.batch == 32 and args.size == 640 and args.dtype == "fp16":
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = {"bytes_per_launch": round((tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6 / max(n_conv, 1)),
                        "bytes_per_step": round((tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6), "source": tj["source"], "correction": tj["correction"]}
+        # HBM-bound edge kernels: algorithmic bytes / exclusive event time
+        n_cand = int(e.post.status[0].item())
+        in_bytes = sum(im.numel() * im.element_size() for im in images_gpu)
+        lb_bytes = in_bytes + args.batch * e.x.h * e.x.w * 4 * 2
+        kernels = {}
+        if excl["pre"]:
+            ms = mean(excl["pre"])
+            kernels["letterbox_kernel"] = {"ms": round(ms, 4), "algorithmic_bytes": lb_bytes, "achieved_GBps": round(lb_bytes / ms / 1e6, 1),
+                                           "frac_of_hbm_peak": round(lb_bytes / (ms * 1e-3) / HBM_PEAK, 4), "launches_per_step": (args.batch + 31) // 32}
+        if excl["post"]:
+            ms = mean(excl["post"])
+            pbytes = n_cand * 12 * 4 + args.batch * e.post.total_anchors * 16   # records read by select / sort (twice) / NMS + boxes of every anchor
+            kernels["postprocess (select_prefix + sort_image + nms_segments + gather_topk)"] = {
+                "ms": round(ms, 4), "candidates_per_step": n_cand, "algorithmic_bytes": pbytes, "achieved_GBps": round(pbytes / ms / 1e6, 1),
+                "frac_of_hbm_peak": round(pbytes / (ms * 1e-3) / HBM_PEAK, 5), "note": "latency-bound (per-image sort + greedy NMS), not bandwidth-bound"}
+        workload = (f"{args.arch} {args.dtype} bs={args.batch}/GPU {args.size}x{args.size} "
+                    + ("dynamic-shape letterbox (8 cycled sizes, SURVEY 8d) -> " if args.shapes == "dynamic" else "fixed-size stream (letterbox = identity: the stem reads the planar images) -> ")
+                    + f"backbone+PAN+head+decode+NMS HIP path (BASELINE configs[{dict(c1=0, c2=1, c3=2, c5=4)[args.config]}])")
         out = {
-            "metric": "images/sec at 640x640 (bs=32) yolov5s",
+            "metric": "images/sec at 640x640 (bs=32) yolov5s" if args.config == "c2" else f"images/sec at {args.size}x{args.size} (bs={args.batch}) {args.arch}",
             "value": round(ips, 2),
             "unit": "images/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(step_s * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"{args.arch} {args.dtype} bs={args.batch}/GPU {args.size}x{args.size}, full letterbox+backbone+head+decode+NMS HIP path (BASELINE configs[1])",
-                       "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
-                       "weights": "seeded synthetic (yolort_amd/utils/synth.py)", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
-                       "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
-                       "candidates_per_step_rank0": int(e.post.status[0].item())},
+            "config": {"workload": workload, "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
+                       "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
+                       "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
+                       "candidates_per_step_rank0": n_cand, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
-                         "traffic": traffic, "kernel": "conv_igemm_kernel (all conv launches of one step)", "launches_per_step": n_conv,
-                         "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2), "conv_ms_per_step": round(conv_ms, 4),
-                         "algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_step": flops_step,
+                         "traffic": traffic,
+                         "kernel": "conv family: conv_igemm_v2_kernel, conv3x3_halo_kernel, conv_halo8_kernel, conv_stem_planar_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
+                         "launches_per_step": n_conv, "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2), "conv_ms_per_step": round(conv_s * 1e3, 4),
+                         "timing": f"HIP events on the plan's stream around the conv launches, one batch in flight, mean of {n_excl} steps right after the timed region",
+                         "algorithmic_bytes_per_step": bytes_step, "algorithmic_bytes_per_launch": round(bytes_step / max(n_conv, 1)), "algorithmic_flops_per_step": flops_step,
                          "tflops": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0,
                          "per_layer_bound_ms": round(bound_s * 1e3, 4), "frac_of_per_layer_bound": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0,
-                         "batches_in_flight": depth,
-                         "exclusive": {"conv_ms_per_step": round(conv_ms_excl, 4), "achieved": round(bytes_step / (conv_ms_excl * 1e-3) / 1e9, 2),
-                                       "frac": round(bytes_step / (conv_ms_excl * 1e-3) / HBM_PEAK, 4), "tflops": round(flops_step / (conv_ms_excl * 1e-3) / 1e12, 2),
-                                       "frac_of_per_layer_bound": round(bound_s / (conv_ms_excl * 1e-3), 4),
-                                       "note": "same launches, one batch in flight, measured right after the timed region"}},
+                         "in_timed_region": {"batches_in_flight": depth, "conv_ms_per_step": round(conv_s_region * 1e3, 4),
+                                             "note": "event brackets inside the timed region: a batch's conv launches share the GPU with its neighbours' kernels"},
+                         "from_step_time": {"frac": round(bytes_step / step_s / HBM_PEAK, 4), "frac_of_per_layer_bound": round(bound_s / step_s, 4),
+                                            "note": "algorithmic conv bytes / ms_per_step: upper bound (the step also holds letterbox + post-process)"},
+                         "other_kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.float().cpu() for k, v in model.state_dict().items()}
-            out["parity"] = parity_sample(model, images_gpu, images_cpu, sd_cpu, args.score_thresh)
-            out["cpu_baseline"] = cpu_baseline(args.arch, sd_cpu, images_cpu, args.score_thresh)
+            k_par = 4 if args.size <= 640 else 2
+            out["parity"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
+            out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
         if args.per_op:
             # the per-op profile replays the recorded plan from its NHWC4 input buffer: fill it through the letterbox
             # path first (identity-size batches normally feed the stem from the planar images and never touch it)

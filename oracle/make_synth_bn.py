@@ -25,8 +25,22 @@ def reference_template(arch: str):
     return yolo.__dict__[arch]().state_dict()
 
 
-def calibrate(arch: str, seed: int = 0, calib_hw: int = 320, calib_n: int = 2):
-    sd = synth_state_dict(reference_template(arch), seed=seed)
+# calibration batch per architecture: (resolution, images).  The statistics of the deep, low-resolution layers are heavy-tailed
+# and border-dominated, so a network is calibrated AT the resolution it is benchmarked at, on enough images for stable
+# per-channel variances (round 1 calibrated everything on 2 images of 320x320: yolov5m / yolov5l6 then ran 10-1000x hot at
+# 1280x1280 -- activations up to 3e4, ~10^6 candidates per image; n / s at 640x640 were and stay fine).
+CALIB = {"yolov5_darknet_pan_m_r60": (1280, 4), "yolov5_darknet_pan_l6_r60": (1280, 4)}
+
+
+def calibrate(arch: str, seed: int = 0, calib_hw: int = 0, calib_n: int = 0):
+    if not calib_hw:
+        calib_hw, calib_n = CALIB.get(arch, (320, 2))
+    try:
+        tmpl = reference_template(arch)
+    except Exception:   # /root/reference not importable (GPU box): same keys / shapes from this package
+        from yolort_amd.models import yolo as Y
+        tmpl = Y.__dict__[arch]().state_dict()
+    sd = synth_state_dict(tmpl, seed=seed)
     x = synth_images(calib_n, calib_hw, calib_hw, seed=1000 + seed)
     O.CALIB.active = True
     try:

@@ -1,0 +1,214 @@
+"""The reference's plug points on the MI355X: constructor injection of
+`post_process=` / `head=` / `anchor_generator=` into YOLO (yolort/models/yolo.py:65-81,159-175), a pre-built `model=` handed
+to YOLOv5 (yolov5.py:99,115-122), the operator-registry hook of INTEGRATION.md section 2, two fresh processes returning
+bit-identical detections (pinned tile table), and more batches in flight than plan instances."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from yolort_amd import _lib
+    _lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _np(d):
+    return {k: (v.detach().float().cpu().numpy() if k != "labels" else v.detach().cpu().numpy()) for k, v in d.items()}
+
+
+def _yolo(dev, thr=0.3, **hooks):
+    """YOLO built the way the reference builds it (build_model, yolo.py:226-265) with optional injected modules"""
+    from yolort_amd.models.backbone_utils import darknet_pan_backbone
+    from yolort_amd.models.yolo import YOLO
+    from yolort_amd.utils.synth import synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    backbone = darknet_pan_backbone("darknet_n_r6_0", 0.33, 0.25, version="r6.0")
+    m = YOLO(backbone, 80, score_thresh=thr, nms_thresh=0.45, **hooks)
+    sd = synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0)
+    m.load_state_dict(sd)
+    return m.to(dev).half().eval(), sd
+
+
+def test_injected_post_process_head_and_anchor_generator(dev):
+    """`e.post is None` branch of YOLO._submit_entry: HIP backbone, then the injected modules are CALLED with the reference's
+    tensor conventions -- head(List[NCHW]) -> List[(N,A,H,W,K)], anchor_generator(features) -> (grids, shifts),
+    post_process(head_outputs, grids, shifts) -> List[Dict] -- and the result matches the oracle like the fused path does"""
+    from oracle import yolov5_oracle as O
+    from test_e2e_gpu import match_fraction
+    from yolort_amd.models.anchor_utils import AnchorGenerator
+    from yolort_amd.models.box_head import PostProcess, YOLOHead
+    from yolort_amd.models.yolo import DEFAULT_ANCHORS
+    from yolort_amd.utils.synth import synth_images
+    calls = {"post": 0, "head": 0, "anchors": 0}
+
+    class MyPost(PostProcess):
+        def forward(self, head_outputs, grids, shifts):
+            calls["post"] += 1
+            assert len(head_outputs) == 3 and head_outputs[0].dim() == 5 and head_outputs[0].shape[1] == 3 and head_outputs[0].shape[-1] == 85
+            assert grids[0].shape[-1] == 2 and shifts[0].shape[-1] == 2
+            return super().forward(head_outputs, grids, shifts)
+
+    class MyHead(YOLOHead):
+        def forward(self, x):
+            calls["head"] += 1
+            return super().forward(x)
+
+    class MyAnchors(AnchorGenerator):
+        def forward(self, feature_maps):
+            calls["anchors"] += 1
+            return super().forward(feature_maps)
+
+    x = synth_images(3, 256, 320, seed=12)
+    ref_model, sd = _yolo(dev)
+    fused = ref_model(x.to(dev).half())
+    sdf = {"model." + k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = O.yolo_forward(x, sdf, 0.3, 0.45, 300, p="model.")
+    variants = {
+        "post_process": dict(post_process=MyPost([8, 16, 32], 0.3, 0.45, 300)),
+        "head": dict(head=MyHead([64, 128, 256], 3, [8, 16, 32], 80)),
+        "anchor_generator": dict(anchor_generator=MyAnchors([8, 16, 32], DEFAULT_ANCHORS)),
+    }
+    for name, hooks in variants.items():
+        m, _ = _yolo(dev, **hooks)
+        assert not m.fused()
+        out = m(x.to(dev).half())
+        assert len(out) == 3 and list(out[0].keys()) == ["scores", "labels", "boxes"]
+        for r, d, f in zip(ref, out, fused):
+            assert len(r["scores"]) > 10
+            frac, miou, _ = match_fraction(_np(r), _np(d), margin=0.03, thr=0.3)
+            assert frac >= 0.9 and miou >= 0.9, (name, frac, miou)
+            # hooks see fp16 head outputs (the reference's own GPU behaviour), the fused path fp32 logits: same detections up to that
+            frac2, miou2, _ = match_fraction(_np(f), _np(d), margin=0.02, thr=0.3, score_tol=0.02)
+            assert frac2 >= 0.95 and miou2 >= 0.97, (name, frac2, miou2)
+    assert calls["post"] == 1 and calls["head"] == 1 and calls["anchors"] == 1, calls
+
+
+def test_yolov5_accepts_a_prebuilt_model_and_rescales_after_a_post_process_hook(dev):
+    """YOLOv5(model=...) (yolov5.py:99,115-122) + an injected post_process: boxes come back in ORIGINAL image coordinates via
+    YOLOTransform.postprocess (yolov5.py:181), like the fused path's in-kernel rescale"""
+    from test_e2e_gpu import match_fraction
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.models.box_head import PostProcess
+    from yolort_amd.utils.synth import synth_images
+
+    class MyPost(PostProcess):
+        pass
+
+    hooked, _ = _yolo(dev, post_process=MyPost([8, 16, 32], 0.3, 0.45, 300))
+    plain, _ = _yolo(dev)
+    imgs = [synth_images(1, h, w, seed=70 + i)[0].to(dev).half() for i, (h, w) in enumerate([(200, 300), (333, 250)])]
+    a = YOLOv5(model=hooked, size=(320, 320))(imgs)
+    b = YOLOv5(model=plain, size=(320, 320))(imgs)
+    for x, y in zip(a, b):
+        assert len(y["scores"]) > 5
+        frac, miou, _ = match_fraction(_np(y), _np(x), margin=0.02, thr=0.3, score_tol=0.02)
+        assert frac >= 0.95 and miou >= 0.97, (frac, miou)
+
+
+def test_operator_registry_hook(dev):
+    """`yolort_amd::nms` registered through torch.library dispatches to ymi_batched_nms for CUDA
+    tensors and returns the oracle's kept indices bit for bit"""
+    from oracle import yolov5_oracle as O
+    import yolort_amd.ops as ops
+    lib = torch.library.Library("yolort_amd", "DEF")
+    lib.define("nms(Tensor boxes, Tensor scores, Tensor labels, float iou) -> Tensor")
+    lib.impl("nms", lambda b, s, l, iou: ops.batched_nms(b, s, l, iou), "CUDA")
+    g = torch.Generator().manual_seed(3)
+    n = 3000
+    xy = torch.rand(n, 2, generator=g) * 600
+    wh = torch.rand(n, 2, generator=g) * 120 + 4
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = (torch.rand(n, generator=g) * 64).floor() / 64          # heavy ties: order is decided by the stable index rule
+    labels = torch.randint(0, 7, (n,), generator=g)
+    keep = torch.ops.yolort_amd.nms(boxes.to(dev), scores.to(dev), labels.to(dev), 0.45)
+    want = O.batched_nms(boxes, scores, labels, 0.45)
+    assert keep.dtype == torch.int64 and torch.equal(keep.cpu(), want)
+    with pytest.raises(Exception):
+        torch.ops.yolort_amd.nms(boxes, scores, labels, 0.45)         # no CPU kernel registered: the op has no CPU fallback
+
+
+_DET_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from yolort_amd.models import YOLOv5
+from yolort_amd.utils.synth import synth_images, synth_weights
+arch = "yolov5_darknet_pan_s_r60"
+m = YOLOv5(arch=arch, score_thresh=0.25)
+m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0))
+m = m.to("cuda:0").half().eval()
+dets = m.predict([im.to("cuda:0").half() for im in synth_images(4, 640, 640, seed=1)])
+h = hashlib.sha256()
+for d in dets:
+    for k in ("scores", "labels", "boxes"):
+        h.update(d[k].cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), sum(len(d["scores"]) for d in dets))
+"""
+
+
+def test_two_fresh_processes_return_bit_identical_detections(dev):
+    """tiles come from the pinned table (yolort_amd/data/tiles_gfx950.json) or the library heuristic, never from timing at plan
+    build (YOLORT_AMD_AUTOTUNE is opt-in), so the K accumulation order -- and every detection bit -- is the same in every process"""
+    env = dict(os.environ)
+    env.pop("YOLORT_AMD_AUTOTUNE", None)
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", _DET_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
+        outs.append(line)
+    assert outs[0] == outs[1], outs
+    assert int(outs[0].split()[-1]) > 100
+
+
+def test_more_batches_in_flight_than_plan_instances(dev):
+    """submitting more batches than `pipeline_depth` before collecting any must not let a later batch
+    overwrite an uncollected one's results; result() is idempotent"""
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+    m = m.to(dev).half().eval()
+    m.model.pipeline_depth = 2
+    batches = [[synth_images(1, 128, 160, seed=200 + 2 * i)[0].to(dev), synth_images(1, 160, 120, seed=201 + 2 * i)[0].to(dev)] for i in range(7)]
+    sync = [m.forward(b) for b in batches]
+    pend = [m.forward_async(b) for b in batches]            # 7 in flight on 2 plan instances
+    assert sum(len(r) for r in m.model._ring.values()) <= 2
+    out = [p.result() for p in reversed(pend)][::-1]         # collected in reverse order on top
+    for s_, o_, p in zip(sync, out, pend):
+        assert p.result() is o_                              # idempotent
+        for x, y in zip(s_, o_):
+            assert len(x["scores"]) > 0
+            assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["scores"], y["scores"]) and torch.equal(x["boxes"], y["boxes"])
+
+
+def test_alternating_canvases_keep_their_plans(dev):
+    """a variable-size stream alternates between canvases; each keeps its plan instances (small LRU) instead of
+    rebuilding `pipeline_depth` plans per call"""
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+    m = m.to(dev).half().eval()
+    a = [synth_images(1, 128, 160, seed=1)[0].to(dev)]      # canvas 128x160
+    b = [synth_images(1, 160, 96, seed=2)[0].to(dev)]       # canvas 160x96
+    ra, rb = m.forward(a), m.forward(b)
+    plans = {id(e.plan) for r in m.model._ring.values() for e in r}
+    assert len(m.model._ring) == 2 and len(plans) == 2      # one lazily built instance per canvas
+    for _ in range(3):
+        xa, xb = m.forward(a), m.forward(b)
+        assert torch.equal(xa[0]["boxes"], ra[0]["boxes"]) and torch.equal(xb[0]["boxes"], rb[0]["boxes"])
+    assert {id(e.plan) for r in m.model._ring.values() for e in r} == plans   # nothing was rebuilt

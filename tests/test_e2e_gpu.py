@@ -306,7 +306,7 @@ def test_baseline_config3_yolov5m_bf16_dynamic_1280(dev):
     from yolort_amd.utils.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_m_r60"
     m = yolov5m(size=(1280, 1280), score_thresh=0.3)
-    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0))
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=2.0))   # m / l6 are calibrated at 1280 (oracle/make_synth_bn.py): sane activations need a larger head gain
     m = m.to(dev).to(torch.bfloat16).eval()
     shapes = [(641, 480), (375, 500), (1281, 1279)]
     imgs = [synth_images(1, h, w, seed=31 + i)[0] for i, (h, w) in enumerate(shapes)]
@@ -316,6 +316,7 @@ def test_baseline_config3_yolov5m_bf16_dynamic_1280(dev):
     sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
         ref = O.yolov5_forward(imgs, sd, size=(1280, 1280), score_thresh=0.3)
+    assert sum(len(r["scores"]) for r in ref) > 30
     for r, d in zip(ref, dets):
         frac, miou, _ = match_fraction(_np(r), _np(d), iou_thr=0.5, score_tol=0.15, margin=0.1, thr=0.3)
         assert frac >= 0.6 and miou >= 0.7, (frac, miou, len(r["scores"]))
@@ -353,12 +354,13 @@ def test_p6_model_runs(dev):
     from oracle import yolov5_oracle as O
     from yolort_amd.utils.synth import synth_images
     arch = "yolov5_darknet_pan_l6_r60"
-    m = _model(arch, dev, torch.float16, size=(256, 256), size_divisible=64, score_thresh=0.3)
+    m = _model(arch, dev, torch.float16, size=(256, 256), size_divisible=64, score_thresh=0.3, head_gain=3.0)
     imgs = [synth_images(1, 200, 256, seed=3)[0]]
     dets = m.predict([imgs[0].to(dev)])
     sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
         ref = O.yolov5_forward(imgs, sd, size=(256, 256), size_divisible=64, score_thresh=0.3)
+    assert len(ref[0]["scores"]) > 10
     frac, miou, _ = match_fraction(_np(ref[0]), _np(dets[0]), margin=0.03, thr=0.3)
     assert frac >= 0.9 and miou >= 0.9, (frac, miou)
 

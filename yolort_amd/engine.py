@@ -118,6 +118,29 @@ class PackedConv:
         return t
 
 
+_TILE_TABLE: Optional[Dict[str, int]] = None
+TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tiles_gfx950.json")
+
+
+def tile_key_str(key: Tuple, dtype: torch.dtype) -> str:
+    """stable text form of a conv launch's shape key (the JSON table's key)"""
+    n, h, w, cin, cout, kh, kw, s, p, xcs, ycs, odt, res, split, up2, chain = key
+    return (f"n{n} {h}x{w} c{cin}->{cout} k{kh}x{kw} s{s[0]}x{s[1]} p{p[0]}x{p[1]} xcs{xcs} ycs{ycs} odt{odt} res{int(bool(res))} split{split} "
+            f"up2{int(bool(up2))} chain{int(bool(chain))} {str(dtype).replace('torch.', '')}")
+
+
+def tile_table() -> Dict[str, int]:
+    """the pinned gfx950 tile table (empty when the file is absent: every conv then takes the library heuristic)"""
+    global _TILE_TABLE
+    if _TILE_TABLE is None:
+        import json
+        _TILE_TABLE = {}
+        if os.path.exists(TILE_TABLE_PATH):
+            with open(TILE_TABLE_PATH) as f:
+                _TILE_TABLE = {k: int(v) for k, v in json.load(f).get("tiles", {}).items()}
+    return _TILE_TABLE
+
+
 def conv_out_hw(h: int, w: int, k: Tuple[int, int], s: Tuple[int, int], p: Tuple[int, int]) -> Tuple[int, int]:
     return (h + 2 * p[0] - k[0]) // s[0] + 1, (w + 2 * p[1] - k[1]) // s[1] + 1
 
@@ -147,9 +170,14 @@ class Plan:
         # +-0 end to end (the pixel-major producer tiles it needs cost what the saved launch gains) -> off by default
         self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
-        # per-shape tile selection by measurement at plan-build time ("measure, don't guess"): each conv is
-        # timed once per candidate tile on its real buffers with HIP events; winners are cached per shape
-        self.autotune = os.environ.get("YOLORT_AMD_AUTOTUNE", "1") == "1"
+        # Tile selection is DETERMINISTIC: a pinned per-(shape, dtype) table for gfx950 committed in-tree
+        # (yolort_amd/data/tiles_gfx950.json, produced by tools/tune_tiles.py on an MI355X) and, for shapes it does not hold,
+        # the library's shape heuristic (tile 0).  Different tiles accumulate K in different orders, so a timing-based choice
+        # at plan build would make detections differ between processes / ranks; measuring is therefore opt-in
+        # (YOLORT_AMD_AUTOTUNE=1: each conv is timed once per candidate tile on its real buffers; tools/tune_tiles.py
+        # writes the winners back into the table).
+        self.autotune = os.environ.get("YOLORT_AMD_AUTOTUNE", "0") == "1"
+        self.use_tile_table = os.environ.get("YOLORT_AMD_TILE_TABLE", "1") != "0"
         # fp32 PARITY MODE (csrc/conv_f32.hip): fp32 activations between layers and exact fp32 arithmetic, one kernel per
         # reference conv -- no fused pairs / chained convs / folded upsample / fused head, no tile choice.  This is the mode
         # in which the HIP path meets the north-star tolerance against the fp32 CPU reference end to end.
@@ -270,8 +298,12 @@ class Plan:
         self.io[self.num_ops] = {"name": name, "x": x_arg, "y": out, "y2": out2, "split": split if out2 is not None else 0, "up2": up2_out, "res": res,
                                  "chain_y": None if chain is None else chain[1], "chain_x2": None if chain is None or len(chain) < 3 else chain[2],
                                  "stride": s, "pad": p}
-        if self.autotune and tile == 0 and d.zeros:
-            d.tile = self._autotune_tile(d, (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None, chain is not None))
+        if tile == 0 and d.zeros:
+            tkey = (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None, chain is not None)
+            if self.autotune:
+                d.tile = self._autotune_tile(d, tkey)
+            elif self.use_tile_table:
+                d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
@@ -289,6 +321,7 @@ class Plan:
         return out
 
     _TUNE_CACHE: Dict[Tuple, int] = {}
+    _TUNE_TIMES: Dict[str, Dict[str, float]] = {}
 
     def _autotune_tile(self, d: ConvDesc, key: Tuple) -> int:
         key = key + (self.dtype,)
@@ -332,6 +365,7 @@ class Plan:
             if times[t] < best_ms:
                 best, best_ms = t, times[t]
         Plan._TUNE_CACHE[key] = best
+        Plan._TUNE_TIMES[tile_key_str(key[:-1], key[-1])] = {str(t): round(times[t] * 1e3, 2) for t in ok}   # us per candidate (tools/tune_tiles.py)
         return best
 
     def spp_pool(self, buf: View, c: int, name: str = "spp_pool") -> None:

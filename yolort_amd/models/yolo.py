@@ -140,7 +140,8 @@ class YOLO(nn.Module):
         self.max_shapes = int(os.environ.get("YOLORT_AMD_MAX_SHAPES", "4"))                       # LRU of (batch, canvas) shapes with live plans
         self.max_plan_bytes = int(float(os.environ.get("YOLORT_AMD_MAX_PLAN_GB", "96")) * 2**30)    # activation memory bound of that LRU
         self._has_warned = False
-        # measurement hook (bench.py): (n_ops, starts, ends) -> HIP events around ops [0, n_ops) of every run
+        # measurement hook (bench.py): {"pre": ([], []), "conv": ([], []), "post": ([], [])} -> HIP event pairs recorded on
+        # the streams the kernels are launched on, around the letterbox launch, the conv launches and the post-process
         self.bracket = None
 
     # ------------------------------------------------------------------------------------------
@@ -240,22 +241,30 @@ class YOLO(nn.Module):
         else:
             e.rescale_host.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
         e.rescale.copy_(e.rescale_host, non_blocking=True)
-        if self.bracket is not None:
-            _, starts, ends = self.bracket
+        br = self.bracket
+        if br is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             if ev0 is None:   # the caller already started the bracket when it issued op 0 itself (stem from planar images)
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record(main)
             e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph, stream=main)
             ev1.record(main)
-            starts.append(ev0)
-            ends.append(ev1)
+            br["conv"][0].append(ev0)
+            br["conv"][1].append(ev1)
         else:
             e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph, stream=main)
         side = e.post_stream
         side.wait_stream(main)
         if os.environ.get("YOLORT_AMD_DEBUG_SKIP_POST", "0") != "1":   # tuning aid: upper bound without sort/NMS
-            e.plan.run(e.n_conv_ops, -1, stream=side)
+            if br is not None:
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record(side)
+                e.plan.run(e.n_conv_ops, -1, stream=side)
+                p1.record(side)
+                br["post"][0].append(p0)
+                br["post"][1].append(p1)
+            else:
+                e.plan.run(e.n_conv_ops, -1, stream=side)
         with torch.cuda.stream(side):
             e.result_host.copy_(torch.cat([e.post.status, e.post.count]), non_blocking=True)
         e.done = torch.cuda.Event()

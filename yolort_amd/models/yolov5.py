@@ -99,6 +99,13 @@ class YOLOv5(nn.Module):
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record(torch.cuda.current_stream())
                 e.plan.stem_from_planar(images)
+            elif model.bracket is not None:
+                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                l0.record(torch.cuda.current_stream())
+                self.transform.letterbox_into(images, e.x, sizes, pads)
+                l1.record(torch.cuda.current_stream())
+                model.bracket["pre"][0].append(l0)
+                model.bracket["pre"][1].append(l1)
             else:
                 self.transform.letterbox_into(images, e.x, sizes, pads)
             first_op = 1 if planar else 0
