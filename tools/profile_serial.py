@@ -1,0 +1,52 @@
+"""Profiling driver (run under rocprofv3): the benchmark workload with ONE batch in flight, so that the kernel dispatches of
+a step appear in plan order and every kernel runs alone on the GPU.  Writes the plan's op list (name, shape, tile,
+algorithmic flops / bytes) next to the trace; tools/layer_table.py joins the two into the per-layer roofline table.
+
+    rocprofv3 --kernel-trace --stats -d DIR -o r -- python tools/profile_serial.py --config c2 --steps 10 --ops gpurun_out/ops_c2.json
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from yolort_amd.models import YOLOv5  # noqa: E402
+from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=sorted(bench.CONFIGS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--ops", default="")
+    a = ap.parse_args()
+    c = bench.CONFIGS[a.config]
+    dev = torch.device("cuda:0")
+    dtype = torch.float16 if c["dtype"] == "fp16" else torch.bfloat16
+    kw = dict(size_divisible=64) if c["arch"].endswith("6_r60") else {}
+    m = YOLOv5(arch=c["arch"], size=(c["size"], c["size"]), score_thresh=c["score_thresh"], nms_thresh=0.45, detections_per_img=300, **kw)
+    m.load_state_dict(synth_weights(m.state_dict(), c["arch"], seed=0, head_gain=c["head_gain"]))
+    m = m.to(dev).to(dtype).eval()
+    if c["shapes"] == "dynamic":
+        imgs = [synth_images(1, *bench.C3_SHAPES[i % 8], seed=1 + i)[0].to(dev).to(dtype) for i in range(c["batch"])]
+    else:
+        imgs = [im.to(dev).to(dtype) for im in synth_images(c["batch"], c["size"], c["size"], seed=1)]
+    for _ in range(3):   # plan build, capacity growth, clocks
+        m.forward(imgs)
+    torch.cuda.synchronize()
+    e = next(iter(m.model._entries.values()))
+    if a.ops:
+        with open(a.ops, "w") as f:
+            json.dump({"config": a.config, "steps": a.steps, "batch": c["batch"],
+                       "ops": [{"name": n, **meta} for n, meta in zip(e.plan.names, e.plan.meta)]}, f, indent=1)
+    for _ in range(a.steps):
+        m.forward(imgs)
+        torch.cuda.synchronize()
+    print("profile_serial done", a.config, a.steps, flush=True)
+
+
+if __name__ == "__main__":
+    main()

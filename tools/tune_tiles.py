@@ -21,7 +21,7 @@ from yolort_amd.models import YOLOv5  # noqa: E402
 from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
 
 DEFAULT = ["yolov5_darknet_pan_s_r60:fp16:32:640", "yolov5_darknet_pan_n_r60:fp16:2:640", "yolov5_darknet_pan_m_r60:bf16:64:1280:dynamic",
-           "yolov5_darknet_pan_l6_r60:fp16:8:1280", "yolov5_darknet_pan_s_r60:bf16:32:640"]
+           "yolov5_darknet_pan_l6_r60:fp16:8:1280"]
 C3_SHAPES = [(1080, 1920), (720, 1280), (1920, 1080), (1080, 810), (960, 1280), (1281, 1279), (641, 480), (375, 500)]
 
 
