@@ -42,8 +42,8 @@ MFMA_PEAK = 2.5e15  # FLOP/s dense fp16/bf16
 
 C3_SHAPES = [(1080, 1920), (720, 1280), (1920, 1080), (1080, 810), (960, 1280), (1281, 1279), (641, 480), (375, 500)]
 CONFIGS = {   # BASELINE.json `configs`
-    "c1": dict(arch="yolov5_darknet_pan_n_r60", dtype="fp16", batch=2, size=640, score_thresh=0.45, head_gain=1.0, shapes="fixed"),
-    "c2": dict(arch="yolov5_darknet_pan_s_r60", dtype="fp16", batch=32, size=640, score_thresh=0.25, head_gain=0.5, shapes="fixed"),
+    "c1": dict(arch="yolov5_darknet_pan_n_r60", dtype="fp16", batch=2, size=640, score_thresh=0.45, head_gain=0.6, shapes="fixed"),
+    "c2": dict(arch="yolov5_darknet_pan_s_r60", dtype="fp16", batch=32, size=640, score_thresh=0.25, head_gain=0.4, shapes="fixed"),   # head gains: tests/test_parity_gpu.py
     "c3": dict(arch="yolov5_darknet_pan_m_r60", dtype="bf16", batch=64, size=1280, score_thresh=0.25, head_gain=2.0, shapes="dynamic"),
     "c5": dict(arch="yolov5_darknet_pan_l6_r60", dtype="fp16", batch=8, size=1280, score_thresh=0.25, head_gain=3.0, shapes="fixed"),
 }

@@ -109,8 +109,8 @@ def test_yolov5_accepts_a_prebuilt_model_and_rescales_after_a_post_process_hook(
     hooked, _ = _yolo(dev, post_process=MyPost([8, 16, 32], 0.3, 0.45, 300))
     plain, _ = _yolo(dev)
     imgs = [synth_images(1, h, w, seed=70 + i)[0].to(dev).half() for i, (h, w) in enumerate([(200, 300), (333, 250)])]
-    a = YOLOv5(model=hooked, size=(320, 320))(imgs)
-    b = YOLOv5(model=plain, size=(320, 320))(imgs)
+    a = YOLOv5(model=hooked, size=(320, 320)).eval()(imgs)
+    b = YOLOv5(model=plain, size=(320, 320)).eval()(imgs)
     for x, y in zip(a, b):
         assert len(y["scores"]) > 5
         frac, miou, _ = match_fraction(_np(y), _np(x), margin=0.02, thr=0.3, score_tol=0.02)
@@ -184,13 +184,13 @@ def test_more_batches_in_flight_than_plan_instances(dev):
     m.model.pipeline_depth = 2
     batches = [[synth_images(1, 128, 160, seed=200 + 2 * i)[0].to(dev), synth_images(1, 160, 120, seed=201 + 2 * i)[0].to(dev)] for i in range(7)]
     sync = [m.forward(b) for b in batches]
+    assert sum(len(d["scores"]) for r in sync for d in r) > 50 and len({len(r[0]["scores"]) for r in sync}) > 1   # batches differ
     pend = [m.forward_async(b) for b in batches]            # 7 in flight on 2 plan instances
     assert sum(len(r) for r in m.model._ring.values()) <= 2
     out = [p.result() for p in reversed(pend)][::-1]         # collected in reverse order on top
     for s_, o_, p in zip(sync, out, pend):
         assert p.result() is o_                              # idempotent
         for x, y in zip(s_, o_):
-            assert len(x["scores"]) > 0
             assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["scores"], y["scores"]) and torch.equal(x["boxes"], y["boxes"])
 
 

@@ -52,7 +52,9 @@ def _run_conv(dev, dtype, n, cin, cout, h, w, k, s, p, act=True, residual=False,
     plan.run()
     torch.cuda.synchronize()
     got = yv.as_tensor().float().cpu().permute(0, 3, 1, 2)
-    tol = 2e-2 if dtype == torch.float16 else 6e-2
+    # the reference is the fp32 convolution of the SAME rounded operands, so what remains is the output rounding (2^-11 / 2^-8
+    # relative), the fp32 summation order and the hardware exp2 / rcp of SiLU (~1e-6): round 1 allowed 2e-2 here
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= tol * max(1.0, scale), f"max err {err} (scale {scale})"
@@ -256,6 +258,17 @@ def test_conv_v1_v2_agree_at_scale(dev, k, s, p, cin, cout, hw):
 def test_conv3x3_halo_kernel(dev, variant, shape):
     """LDS-halo 3x3 s1 kernel (activation patch resident in LDS across the nine taps), incl. ragged
     image sizes (partial patches), residual and channel-slice views"""
+    _run_conv(dev, torch.float16, k=3, s=1, p=1, tile=variant, residual=True, x_cs_extra=32, y_cs_extra=64, seed=variant, **shape)
+    _run_conv(dev, torch.bfloat16, k=3, s=1, p=1, tile=variant, seed=variant + 1, **shape)
+
+
+@pytest.mark.parametrize("variant", [91, 92, 93, 94, 95, 96, 97])
+@pytest.mark.parametrize("shape", [dict(n=2, cin=32, cout=32, h=40, w=40), dict(n=1, cin=64, cout=64, h=33, w=21), dict(n=2, cin=128, cout=128, h=20, w=20),
+                                   dict(n=1, cin=32, cout=64, h=8, w=16), dict(n=3, cin=64, cout=96, h=17, w=35), dict(n=1, cin=64, cout=128, h=80, w=80),
+                                   dict(n=2, cin=32, cout=32, h=5, w=7), dict(n=1, cin=96, cout=160, h=24, w=52)])
+def test_conv_halo8_kernel(dev, variant, shape):
+    """8-wave LDS-halo 3x3 s1 kernel (conv_halo8.hip): every wave layout / ring depth, patch shapes chosen per map size
+    (16x16, 10x20, 6x40, whole tiny maps), ragged sizes, several cout blocks, residual and channel-slice views"""
     _run_conv(dev, torch.float16, k=3, s=1, p=1, tile=variant, residual=True, x_cs_extra=32, y_cs_extra=64, seed=variant, **shape)
     _run_conv(dev, torch.bfloat16, k=3, s=1, p=1, tile=variant, seed=variant + 1, **shape)
 

@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
-CONV_LIKE = ("conv_", "spp_pool")     # kernels that correspond 1:1 to plan ops of kind conv / pool
+CONV_LIKE = ("conv_", "conv3x3_", "spp_pool")     # kernels that correspond 1:1 to plan ops of kind conv / pool
 STEM = ("conv_stem", "letterbox")     # first kernel of a step
 
 
@@ -91,7 +91,9 @@ def main():
                     k += 1
     counters = sorted({c for d in pmc.values() for c in d})
     print("# per-launch table, " + meta["config"] + f", batch {meta['batch']}, mean over {len(steps)} serial steps (one batch in flight); durations from rocprofv3 --kernel-trace")
-    print("op,name,shape,tile,kernel,avg_us,tflops,gbps,bound_us,frac_of_own_bound," + ",".join(counters) + (",mfma_busy_frac" if counters else ""))
+    import csv
+    wr = csv.writer(sys.stdout)
+    wr.writerow(["op", "name", "shape", "tile", "kernel", "avg_us", "tflops", "gbps", "bound_us", "frac_of_own_bound"] + counters + (["mfma_busy_frac"] if counters else []))
     tot_t = tot_b = 0.0
     for k, o in enumerate(ops):
         if not dur[k]:
@@ -104,17 +106,17 @@ def main():
         for c in counters:
             v = pmc[k].get(c, [])
             cvals.append(f"{sum(v) / len(v):.0f}" if v else "")
-        extra = ""
+        extra = []
         if counters:
             busy = pmc[k].get("SQ_VALU_MFMA_BUSY_CYCLES", [])
             gui = pmc[k].get("GRBM_GUI_ACTIVE", [])
             if busy:
                 denom = (sum(gui) / len(gui)) * 1024 if gui else t * 1e-6 * 2.4e9 * 1024
-                extra = f",{(sum(busy) / len(busy)) / denom:.3f}"
+                extra = [f"{(sum(busy) / len(busy)) / denom:.3f}"]
             else:
-                extra = ","
-        print(f"{k},{o['name']},{o.get('shape', '')},{o.get('tile', '')},{names.get(k, '')},{t:.2f},{o['flops'] / t / 1e6:.1f},{o['bytes'] / t / 1e3:.1f},{bound:.2f},{bound / t:.3f}"
-              + ("," + ",".join(cvals) if counters else "") + extra)
+                extra = [""]
+        wr.writerow([k, o["name"], o.get("shape", ""), o.get("tile", ""), names.get(k, ""), f"{t:.2f}", f"{o['flops'] / t / 1e6:.1f}", f"{o['bytes'] / t / 1e3:.1f}",
+                     f"{bound:.2f}", f"{bound / t:.3f}"] + cvals + extra)
     print(f"# conv stack: sum of kernel durations {tot_t:.1f} us per step, sum of per-layer bounds {tot_b:.1f} us -> frac {tot_b / max(tot_t, 1e-9):.3f}")
     print("# other kernels of a step (avg us x launches per step):")
     for n, v in sorted(other.items(), key=lambda kv: -sum(kv[1])):

@@ -1,0 +1,45 @@
+"""Tuning aid: per-block s_memtime timeline of the 8-wave halo kernel (conv_halo8.hip).
+build:  bash tools/build_h8_stamps.sh          (instrumented copy of conv_halo8 only, never the shipped library)
+run:    YOLORT_AMD_LIB=$PWD/tools/_bin/libyolort_amd_h8stamps.so python tools/stamp_h8.py n,cin,cout,h,w,tile [...]
+"""
+import ctypes as C
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from yolort_amd import engine, _lib
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+lib.ymi_debug_stamps_h8.restype = C.c_int
+lib.ymi_debug_stamps_h8.argtypes = [C.c_void_p, C.c_int]
+
+for case in sys.argv[1:]:
+    n, cin, cout, h, w, tile = map(int, case.split(","))
+    plan = engine.Plan(dev, torch.float16)
+    x = plan.alloc(n, h, w, cin); x.base.normal_()
+    wt = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    pc = engine.PackedConv(wt, None, None, torch.float16, dev)
+    plan.conv(x, pc, 1, 1, tile=tile)
+    for _ in range(3):
+        plan.run()
+    torch.cuda.synchronize()
+    ms = plan.profile(10)[0][1]
+    plan.run(); torch.cuda.synchronize()
+    st = np.zeros(2048 * 128, dtype=np.uint64)
+    assert lib.ymi_debug_stamps_h8(st.ctypes.data, st.size) == 0
+    st = st.reshape(2048, 128).astype(np.int64)
+    nsteps = cin // 32 * 9
+    b = st[st[:, 0] != 0]
+    rel = lambda i: (b[:, i] - b[:, 0]).mean()
+    t0 = b[:, 0].min()
+    print(f"== {case}: {ms*1e3:.1f} us (events), {b.shape[0]} stamped blocks, {nsteps} steps; block entry spread {(b[:,0].max()-t0)} cyc, last exit {(b[:,127].max()-t0)} cyc")
+    print(f"   setup {rel(1):.0f}  mainloop end {rel(3):.0f}  kernel end {rel(127):.0f} cycles since block entry (epilogue {rel(127)-rel(3):.0f})")
+    ns = min(nsteps, 40)
+    vm = np.array([(b[:, 4 + 3 * s_] - (b[:, 6 + 3 * (s_ - 1)] if s_ else b[:, 1])).mean() for s_ in range(ns)])
+    bar = np.array([(b[:, 5 + 3 * s_] - b[:, 4 + 3 * s_]).mean() for s_ in range(ns)])
+    comp = np.array([(b[:, 6 + 3 * s_] - b[:, 5 + 3 * s_]).mean() for s_ in range(ns)])
+    print("   per step avg: vmcnt wait %.0f | barrier wait %.0f | issue+frag reads+MFMAs %.0f | period %.0f" % (vm[1:].mean(), bar[1:].mean(), comp[1:].mean(), (vm[1:] + bar[1:] + comp[1:]).mean()))
+    print("   vm waits :", " ".join("%.0f" % v for v in vm[:14]))
+    print("   bar waits:", " ".join("%.0f" % v for v in bar[:14]))
+    print("   compute  :", " ".join("%.0f" % v for v in comp[:14]))

@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -16,6 +19,18 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int allow_big_lds(const void* kernel_fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    YMI_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel_fn, dev})) return YMI_OK;
+    YMI_CHECK_HIP(hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel_fn, dev});
+    return YMI_OK;
 }
 
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);

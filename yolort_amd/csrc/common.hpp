@@ -27,6 +27,10 @@ void set_error(const char* fmt, ...);
         }                                   \
     } while (0)
 
+// Opt-in to > 64 KiB of dynamic LDS: a per-function (and per-device) attribute.  It is set ONCE per (kernel, device) and
+// remembered -- calling hipFuncSetAttribute on every launch sat on the enqueue path of every big-tile conv.
+int allow_big_lds(const void* kernel_fn, int bytes);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

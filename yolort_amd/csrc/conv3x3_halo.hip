@@ -197,7 +197,7 @@ static int launch_halo(const ConvArgs& a0, hipStream_t s) {
     a.nblk_n = cdiv(a.cout_pad, BN);
     const size_t lds = (size_t)2 * HPIX * 64 + (size_t)STAGES * BN * 64;
     auto kfn = conv3x3_halo_kernel<DT, ODT, BN, WM, WN, STAGES>;
-    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, s, a, tiles_x, tiles_y);
     return check_launch("conv3x3_halo_kernel");
 }

@@ -343,6 +343,8 @@ __device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const 
 int conv_f32_launch(const ConvArgs& a, bool is1x1, hipStream_t s);
 // 3x3 stride-1 LDS-halo kernel (conv3x3_halo.hip); returns YMI_EINVAL when the shape does not apply
 int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
+// 8-wave LDS-halo 3x3 stride-1 kernel (conv_halo8.hip), patch shape chosen per feature-map size
+int conv_halo8_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // dedicated stem kernel (conv_stem.hip): 6x3 s(2,1) super-pixel form, input patch in LDS, weights in registers
 int conv_stem_launch(const ConvArgs& a, int dtype, int out_dtype, hipStream_t s);
 // the same stem fed from planar (3, H, W) images of the compute dtype, identity-size batches (no letterbox pass)

@@ -1,0 +1,288 @@
+// 3x3 stride-1 "same" convolution, 8-wave LDS-halo kernel (gfx950) -- second generation of conv3x3_halo.hip.
+//
+// What bounded the 4-wave kernels on these layers: per-wave instruction issue.  A
+// `global_load_lds_dwordx4` costs its wave ~60-180 cycles to issue against 32 for an MFMA, and a 128x128x32 step of the
+// implicit-GEMM kernel is 4 DMA pieces per wave against 8 MFMAs.  Here
+//   * a block is 8 waves (2 per SIMD) on a TH x TW output patch of up to 256 pixels of ONE image; TH, TW are chosen per
+//     feature-map size on the host so that the patches tile the map with little waste (16x16 on 80x80, 10x20 on 20x20 and
+//     40x40, ...);
+//   * per 32-channel chunk the (TH+2) x (TW+2) input patch goes to LDS ONCE (<= 22 DMA pieces, double buffered) and feeds all
+//     nine taps; only the weights stream per (tap, chunk) step: BN x 64 B = BN/16 pieces per step for the whole block.
+//     Every wave issues exactly ONE weight piece per step and, in the first three taps of a chunk, ONE piece of the next
+//     chunk's patch -- at most 2 DMA instructions per wave against 8 MFMAs (BN = 128);
+//   * the two waves of a SIMD interleave on the matrix pipe: while one sits in its s_waitcnt / barrier / ds_read latency the
+//     other issues MFMAs; inside a wave the fragments of the second k16 half are fetched under the MFMAs of the first.
+// Ring / counted-vmcnt / one raw s_barrier per step / source-side XOR swizzle exactly as in conv_igemm_impl.hpp (v2).
+//
+// Same arithmetic and accumulator layout as every other conv kernel of this library (swapped MFMA D[cout][pixel], fp32
+// accumulate on top of the folded-BN bias, SiLU (+ residual) epilogue of conv_common.hpp, channel-slice views).
+// Replaces yolort/v5/models/common.py:69-70,115-116 for the Bottleneck.cv2 convolutions (k=3, s=1, p=1, cin % 32 == 0).
+#include "conv_common.hpp"
+
+namespace ymi {
+
+#ifdef YMI_STAMPS   // tuning aid (never in the shipped build): s_memtime timeline, wave 0 of each block (tools/stamp_conv.py)
+__device__ unsigned long long ymi_stamps_h8[2048 * 128];
+#define H8_STAMP(i)                                                                                                       \
+    do {                                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && (i) < 128) ymi_stamps_h8[blockIdx.x * 128 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define H8_STAMP(i) ((void)0)
+#endif
+
+struct Halo8Geom {
+    int th, tw;              // output patch (th * tw <= 256)
+    int pw;                  // tw + 2
+    int ppix;                // (th + 2) * (tw + 2) patch pixels
+    int ppieces;             // ceil(ppix / 16) DMA pieces per patch chunk (<= 24)
+    int tiles_x, tiles_y;
+    unsigned magic_tw, magic_pw;
+};
+
+template <int DT, int ODT, int BN, int WAVES_M, int STAGES>
+__global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, const Halo8Geom g) {
+    constexpr int WAVES_N = 8 / WAVES_M;
+    constexpr int WM = 256 / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1 && WAVES_M * WAVES_N == 8, "8 waves");
+    static_assert(STAGES == 3 || STAGES == 4, "weight ring depth");
+    constexpr int W_PIECES = BN / 16;
+    constexpr int WSTAGE_HALFS = BN * 32;
+    typedef typename Mfma<DT>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1][weight ring]
+    const int patch_halfs = g.ppieces * 512;
+    uint16_t* wring = smem + 2 * patch_halfs;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = (wave / WAVES_N) * WM, wave_n = (wave % WAVES_N) * WN;
+
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int bn = lb % a.nblk_n;
+    int t = lb / a.nblk_n;
+    const int tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    const int ty = t % g.tiles_y;
+    const int img = t / g.tiles_y;
+    const int oy0 = ty * g.th, ox0 = tx * g.tw, n0 = bn * BN;
+    const int nchunks = a.cin / 32;
+    const int nsteps = nchunks * 9;
+    H8_STAMP(0);
+    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+
+    // ---- patch DMA geometry: piece pi = 16 patch pixels; wave w owns pieces w, w+8, w+16 (clamped: surplus slots re-send
+    //      the last piece, identical bytes).  Lane (pixel q, position pos) fetches k-chunk pos ^ ((q>>2)&3) of input pixel
+    //      (oy0-1+q/pw, ox0-1+q%pw), or the zero page outside the image / past the patch ----
+    int p_off[3], p_slot[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int pi = wave + 8 * j;
+        pi = pi < g.ppieces ? pi : g.ppieces - 1;
+        const int q = pi * 16 + (lane >> 2);
+        p_slot[j] = pi * 512;
+        const int qc = q < g.ppix ? q : g.ppix - 1;
+        const int pr = fast_div(qc, g.pw, g.magic_pw), pc = qc - pr * g.pw;
+        const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+        const bool ok = (q < g.ppix) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w_in);
+        const int kchunk = (lane & 3) ^ ((q >> 2) & 3);
+        p_off[j] = ok ? ((img * a.h + iy) * a.w_in + ix) * a.x_cs + kchunk * 8 : -1;
+    }
+    // ---- weight DMA geometry: ONE piece (16 cout rows x 64 B) per wave per step; rows are zero padded to 128 ----
+    const int wchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const int wpi = wave < W_PIECES ? wave : W_PIECES - 1;
+    const int w_slot = wpi * 512;
+    const int w_off = (n0 + wpi * 16 + (lane >> 2)) * a.k_pad + wchunk * 8;
+
+    auto issue_patch_piece = [&](int chunk, auto jt) {
+        constexpr int j = decltype(jt)::value;
+        uint16_t* dst = smem + (chunk & 1) * patch_halfs;
+        const int off = p_off[j] >= 0 ? p_off[j] + chunk * 32 : a.x_zero_off;
+        glds16(a.x + off, dst + p_slot[j]);
+    };
+    // weights of k = tap*cin + chunk*32 .. +31 into ring slot (step % STAGES)
+    int is_step = 0, is_koff = 0, is_tap = 0, is_slot = 0;   // issue-side position of the next weight step (wave-uniform scalars)
+    auto issue_next_w = [&]() {
+        glds16(a.w + (w_off + is_koff), wring + is_slot * WSTAGE_HALFS + w_slot);
+        ++is_step;
+        is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+        is_koff += a.cin;                       // next tap, same chunk
+        if (++is_tap == 9) { is_tap = 0; is_koff += 32 - 9 * a.cin; }   // next chunk, tap 0
+    };
+
+    f32x16 acc[TN][TM];
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
+
+    // prologue: the whole first patch (3 pieces per wave), then STAGES-1 weight stages
+    static_for<0, 3>([&](auto jt) { issue_patch_piece(0, jt); });
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nsteps) issue_next_w();
+
+    // ---- per-lane fragment geometry ----
+    const int frow = lane & 31;
+    const int hi = lane >> 5;
+    const int npix = g.th * g.tw;
+    int q0[TM];   // patch pixel of this lane's output pixel at tap (0,0)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int p = wave_m + j * 32 + frow;
+        const int pc = p < npix ? p : 0;
+        const int r = fast_div(pc, g.tw, g.magic_tw), c = pc - r * g.tw;
+        q0[j] = r * g.pw + c;
+    }
+    const int wswz = (lane >> 2) & 3;
+    const int wpos0 = ((0 + hi) ^ wswz) * 8, wpos1 = ((2 + hi) ^ wswz) * 8;
+
+    int chunk = 0, tap = 0, tapoff = 0, dx = 0, slot = 0;
+    const bool multi = nchunks > 1;
+    H8_STAMP(1);
+    for (int step = 0; step < nsteps; ++step) {
+        // The weight piece of `step` was this wave's last DMA of step - (STAGES-1); what it issued afterwards may stay in
+        // flight: one weight piece per later step plus one patch piece for every later step that lay in taps 0..2 of a
+        // chunk with a successor.  (Older loads -- including every patch piece this step may read -- complete first.)
+        {
+            const int remaining = nsteps - 1 - step;                 // weight stages issued after this step's: min(STAGES-2, remaining)
+            int pend = remaining < STAGES - 2 ? remaining : STAGES - 2;
+            // patch pieces issued in the previous min(STAGES-2, step) steps
+            const bool has_next = chunk + 1 < nchunks;
+            if (multi) {
+                if (STAGES - 2 >= 1 && step >= 1 && tap >= 1 && tap <= 3 && has_next) ++pend;                  // step-1 had tap-1 in 0..2
+                if (STAGES - 2 >= 2 && step >= 2 && tap >= 2 && tap <= 4 && has_next) ++pend;                  // step-2 had tap-2 in 0..2
+            }
+            if (pend >= 4) wait_vmcnt<4>();
+            else if (pend == 3) wait_vmcnt<3>();
+            else if (pend == 2) wait_vmcnt<2>();
+            else if (pend == 1) wait_vmcnt<1>();
+            else wait_vmcnt<0>();
+        }
+        H8_STAMP(4 + step * 3);
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of this stage landed; everyone is done with stage step-1
+        __builtin_amdgcn_sched_barrier(0);
+        H8_STAMP(5 + step * 3);
+        if (tap <= 2 && chunk + 1 < nchunks) {   // next chunk's patch: buffer (chunk+1)&1 was last read in chunk-1
+            if (tap == 0) issue_patch_piece(chunk + 1, std::integral_constant<int, 0>{});
+            else if (tap == 1) issue_patch_piece(chunk + 1, std::integral_constant<int, 1>{});
+            else issue_patch_piece(chunk + 1, std::integral_constant<int, 2>{});
+        }
+        if (step + STAGES - 1 < nsteps) issue_next_w();   // refill the slot freed by step-1
+
+        const uint16_t* pb = smem + (chunk & 1) * patch_halfs;
+        const uint16_t* ws = wring + slot * WSTAGE_HALFS + wave_n * 32;
+        frag af[2][TM], wf[2][TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int q = q0[j] + tapoff;
+            const int e0 = q * 32 + ((hi ^ ((q >> 2) & 3)) * 8);
+            af[0][j] = *reinterpret_cast<const frag*>(pb + e0);
+            af[1][j] = *reinterpret_cast<const frag*>(pb + (e0 ^ 16));   // k-chunk (2+hi)^swz = flip bit 1
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            wf[0][i] = *reinterpret_cast<const frag*>(ws + (i * 32 + frow) * 32 + wpos0);
+            wf[1][i] = *reinterpret_cast<const frag*>(ws + (i * 32 + frow) * 32 + wpos1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(wf[ks][i], af[ks][j], acc[i][j]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `step` before it reaches the next barrier
+        H8_STAMP(6 + step * 3);
+        // advance (chunk, tap)
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+        if (++tap == 9) { tap = 0; tapoff = 0; dx = 0; ++chunk; }
+        else if (++dx == 3) { dx = 0; tapoff += g.pw - 2; }
+        else ++tapoff;
+    }
+
+    // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
+    H8_STAMP(3);
+    auto pix = [&](int j, int64_t& m, bool& ok) {
+        const int p = wave_m + j * 32 + frow;
+        const int pc = p < npix ? p : 0;
+        const int r = fast_div(pc, g.tw, g.magic_tw), c = pc - r * g.tw;
+        const int oy = oy0 + r, ox = ox0 + c;
+        ok = p < npix && oy < a.ho && ox < a.wo;
+        m = ((int64_t)img * a.ho + oy) * a.wo + ox;
+    };
+    finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, pix);
+    H8_STAMP(127);
+}
+
+// patch shape for a ho x wo map: th * tw <= 256, (th+2) * (tw+2) <= 24 * 16 patch pixels; maximise the fraction of the 256
+// lanes that carry real output pixels (tile overhang counts as waste), then prefer the smaller halo
+static void choose_patch(int ho, int wo, int& th_best, int& tw_best) {
+    double best = -1.0;
+    th_best = 16; tw_best = 16;
+    for (int tw = 4; tw <= 64 && tw <= ((wo + 3) / 4) * 4; ++tw) {
+        int th = 256 / tw;
+        if (th > ho) th = ho;
+        for (int thc = th; thc >= 1 && thc >= th - 8; --thc) {
+            if ((thc + 2) * (tw + 2) > 24 * 16) continue;
+            const int ty = (ho + thc - 1) / thc, tx = (wo + tw - 1) / tw;
+            const double util = (double)ho * wo / ((double)ty * tx * 256.0);
+            const double halo = (double)(thc + 2) * (tw + 2) / ((double)thc * tw);
+            const double score = util - 0.02 * halo;
+            if (score > best) { best = score; th_best = thc; tw_best = tw; }
+        }
+    }
+}
+
+template <int DT, int ODT, int BN, int WAVES_M, int STAGES>
+static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    Halo8Geom g;
+    choose_patch(a.ho, a.wo, g.th, g.tw);
+    g.pw = g.tw + 2;
+    g.ppix = (g.th + 2) * g.pw;
+    g.ppieces = (g.ppix + 15) / 16;
+    g.tiles_x = cdiv(a.wo, g.tw);
+    g.tiles_y = cdiv(a.ho, g.th);
+    auto magic = [](int dv) { const uint64_t v = (((uint64_t)1 << 32) / (uint64_t)dv) + 1u; return (unsigned)(v > 0xffffffffull ? 0xffffffffull : v); };
+    g.magic_tw = magic(g.tw);
+    g.magic_pw = magic(g.pw);
+    a.nblk_m = a.n * g.tiles_x * g.tiles_y;
+    a.nblk_n = cdiv(a.cout_pad, BN);
+    const size_t lds = (size_t)2 * g.ppieces * 1024 + (size_t)STAGES * BN * 64;
+    auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M, STAGES>;
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a, g);
+    return check_launch("conv_halo8_kernel");
+}
+
+template <int DT, int ODT>
+static int halo8_variant(const ConvArgs& a, int variant, hipStream_t s) {
+    switch (variant) {
+        case 1: return launch_halo8<DT, ODT, 128, 4, 3>(a, s);   // 4x2 waves of 64 px x 64 cout
+        case 2: return launch_halo8<DT, ODT, 64, 4, 3>(a, s);    // 4x2 waves of 64 px x 32 cout
+        case 3: return launch_halo8<DT, ODT, 64, 8, 3>(a, s);    // 8x1 waves of 32 px x 64 cout
+        case 4: return launch_halo8<DT, ODT, 32, 8, 3>(a, s);    // 8x1 waves of 32 px x 32 cout
+        case 5: return launch_halo8<DT, ODT, 128, 4, 4>(a, s);   // as 1, 4-deep weight ring
+        case 6: return launch_halo8<DT, ODT, 64, 4, 4>(a, s);    // as 2, 4-deep weight ring
+        case 7: return launch_halo8<DT, ODT, 128, 8, 3>(a, s);   // 8x1 waves of 32 px x 128 cout
+        default: set_error("ymi_conv2d: unknown halo8 variant %d", variant); return YMI_EINVAL;
+    }
+}
+
+int conv_halo8_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s) {
+    YMI_REQUIRE(a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.cin % 32 == 0 && a.zeros != nullptr && a.split == 0 && a.up2 == 0 &&
+                    a.chain_w == nullptr,
+                "ymi_conv2d: the 8-wave LDS-halo kernel handles plain 3x3 stride-1 pad-1 convolutions with cin %% 32 == 0 (and needs desc.zeros)");
+    YMI_REQUIRE(a.k_pad == 9 * a.cin, "ymi_conv2d: halo8 kernel expects k_pad == 9*cin");
+    if (dtype == YMI_F16) return out_dtype == YMI_F32 ? halo8_variant<YMI_F16, YMI_F32>(a, variant, s) : halo8_variant<YMI_F16, YMI_F16>(a, variant, s);
+    return out_dtype == YMI_F32 ? halo8_variant<YMI_BF16, YMI_F32>(a, variant, s) : halo8_variant<YMI_BF16, YMI_BF16>(a, variant, s);
+}
+
+}  // namespace ymi
+
+#ifdef YMI_STAMPS
+extern "C" int ymi_debug_stamps_h8(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ymi::ymi_stamps_h8), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void conv_head_decode_group_kernel(const HeadG
 
 template <typename K>
 int launch_v2_kernel(K kfn, const ConvArgs& a, size_t lds, dim3 grid, hipStream_t s) {
-    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
     return check_launch("conv_igemm_v2_kernel");
 }
@@ -693,7 +693,7 @@ template <int DT, int TNA>
 int launch_head_decode(const ConvArgs& a, const HeadDecodeArgs& h, hipStream_t s) {
     const size_t lds = head_decode_lds(TNA);
     auto kfn = conv_head_decode_kernel<DT, TNA>;
-    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m), dim3(256), lds, s, a, h);
     return check_launch("conv_head_decode_kernel");
 }
@@ -702,7 +702,7 @@ template <int DT, int TNA>
 int launch_head_group(const HeadGroupArgs& g, hipStream_t s) {
     const size_t lds = head_decode_lds(TNA);
     auto kfn = conv_head_decode_group_kernel<DT, TNA>;
-    if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(g.first_block[g.n]), dim3(256), lds, s, g);
     return check_launch("conv_head_decode_group_kernel");
 }

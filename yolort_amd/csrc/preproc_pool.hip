@@ -497,7 +497,7 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
     if (lds <= 160 * 1024 - 512) {  // the plane of 8*G channels fits the 160 KB LDS three times
         dim3 g((unsigned)(n * (c / (8 * G)))), b(256);
         auto launch = [&](auto kfn) -> int {
-            if (lds > 64 * 1024) YMI_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
             hipLaunchKernelGGL(kfn, g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
             return check_launch("spp_pool_lds_kernel");
         };

@@ -301,7 +301,7 @@ class Plan:
         if tile == 0 and d.zeros:
             tkey = (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None, chain is not None)
             if self.autotune:
-                d.tile = self._autotune_tile(d, tkey)
+                d.tile = self._autotune_tile(d, tkey, chain)
             elif self.use_tile_table:
                 d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
         esz = 2
@@ -323,7 +323,7 @@ class Plan:
     _TUNE_CACHE: Dict[Tuple, int] = {}
     _TUNE_TIMES: Dict[str, Dict[str, float]] = {}
 
-    def _autotune_tile(self, d: ConvDesc, key: Tuple) -> int:
+    def _autotune_tile(self, d: ConvDesc, key: Tuple, chain=None) -> int:
         key = key + (self.dtype,)
         hit = Plan._TUNE_CACHE.get(key)
         if hit is not None:
@@ -339,6 +339,8 @@ class Plan:
         if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin % 32 == 0 and d.cout_split == 0 and d.k_pad == 9 * d.cin:
             # LDS-halo kernel variants (activation patch resident in LDS across the nine taps)
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
+            if chain is None:   # 8-wave halo kernel (conv_halo8.hip): 256-pixel patches, <= 2 DMA pieces per wave per step
+                cands = cands + ([94] if d.cout_pad <= 32 else ([92, 93, 96] if d.cout_pad <= 64 else [91, 92, 93, 95, 97]))
         if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
             cands = cands + [41]   # dedicated stem kernel
         best, best_ms = 0, float("inf")
