@@ -148,7 +148,7 @@ def _npd(d):
     return {"boxes": d["boxes"].detach().float().cpu().numpy(), "scores": d["scores"].detach().float().cpu().numpy(), "labels": d["labels"].detach().cpu().numpy()}
 
 
-def direct_checks(ref, got, thr, k=300, score_eps=1e-4, iou_min=1 - 1e-3):
+def direct_checks(ref, got, thr, k=300, score_eps=5e-4, iou_min=1 - 1e-3):
     """SURVEY.md 8d direct checks over a list of images (numpy dicts): pairs every reference detection with a HIP detection
     of the same label, |dscore| <= score_eps and IoU >= iou_min; detections within score_eps of the threshold / top-K cut may
     appear on one side only (fp32 summation order decides) and are reported as `at_cut`."""

@@ -212,3 +212,38 @@ def test_alternating_canvases_keep_their_plans(dev):
         xa, xb = m.forward(a), m.forward(b)
         assert torch.equal(xa[0]["boxes"], ra[0]["boxes"]) and torch.equal(xb[0]["boxes"], rb[0]["boxes"])
     assert {id(e.plan) for r in m.model._ring.values() for e in r} == plans   # nothing was rebuilt
+
+
+def test_upstream_checkpoint_ingest_predicts_like_the_converted_state_dict(dev, tmp_path):
+    """SURVEY 8f-1 on the GPU: a (synthetic) ultralytics-format checkpoint goes load_from_yolov5 -> predict; the detections
+    equal, bit for bit, those of a model built the normal way from the converted state_dict (fp16-rounded like the reference,
+    _checkpoint.py:81), and match the oracle run on that state_dict"""
+    from oracle import yolov5_oracle as O
+    from test_checkpoint_ingest import _write_fake_checkpoint
+    from test_e2e_gpu import match_fraction
+    from yolort_amd.models import YOLOv5, yolo as Y
+    from yolort_amd.models._checkpoint import load_from_ultralytics
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    ref_sd = synth_weights(Y.__dict__[arch]().state_dict(), arch, seed=0, head_gain=1.0)
+    path = str(tmp_path / "yolov5n_upstream_format.pt")
+    _write_fake_checkpoint(path, ref_sd, p6=False)
+    assert "models" not in sys.modules
+    loaded = YOLOv5.load_from_yolov5(path, size=(320, 320), score_thresh=0.3).to(dev).half().eval()
+    imgs_cpu = [synth_images(1, h, w, seed=80 + i)[0] for i, (h, w) in enumerate([(240, 320), (300, 210)])]
+    imgs = [im.to(dev).half() for im in imgs_cpu]
+    dets = loaded.predict(imgs)
+    converted = load_from_ultralytics(path)["state_dict"]
+    plain = YOLOv5(arch=arch, size=(320, 320), score_thresh=0.3)
+    plain.model.load_state_dict(converted)
+    plain = plain.to(dev).half().eval()
+    dets2 = plain.predict(imgs)
+    sdf = {"model." + k: v.float() for k, v in converted.items()}
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs_cpu, sdf, size=(320, 320), score_thresh=0.3)
+    for a, b, r in zip(dets, dets2, ref):
+        assert len(a["scores"]) > 10
+        for k in ("scores", "labels", "boxes"):
+            assert torch.equal(a[k], b[k])
+        frac, miou, _ = match_fraction(_np(r), _np(a), margin=0.03, thr=0.3)
+        assert frac >= 0.9 and miou >= 0.9, (frac, miou)

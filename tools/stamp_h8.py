@@ -29,7 +29,7 @@ for case in sys.argv[1:]:
     st = np.zeros(2048 * 128, dtype=np.uint64)
     assert lib.ymi_debug_stamps_h8(st.ctypes.data, st.size) == 0
     st = st.reshape(2048, 128).astype(np.int64)
-    nsteps = cin // 32 * 9
+    nsteps = cin // 32 * 3
     b = st[st[:, 0] != 0]
     rel = lambda i: (b[:, i] - b[:, 0]).mean()
     t0 = b[:, 0].min()

@@ -4,7 +4,7 @@
 #include <string.h>
 
 #include <mutex>
-#include <set>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -23,13 +23,14 @@ void set_error(const char* fmt, ...) {
 
 int allow_big_lds(const void* kernel_fn, int bytes) {
     static std::mutex mu;
-    static std::set<std::pair<const void*, int>> done;
+    static std::map<std::pair<const void*, int>, int> done;   // (kernel, device) -> largest size opted in so far
     int dev = 0;
     YMI_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count({kernel_fn, dev})) return YMI_OK;
+    auto it = done.find({kernel_fn, dev});
+    if (it != done.end() && it->second >= bytes) return YMI_OK;
     YMI_CHECK_HIP(hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    done.insert({kernel_fn, dev});
+    done[{kernel_fn, dev}] = bytes;
     return YMI_OK;
 }
 

@@ -345,6 +345,8 @@ int conv_f32_launch(const ConvArgs& a, bool is1x1, hipStream_t s);
 int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // 8-wave LDS-halo 3x3 stride-1 kernel (conv_halo8.hip), patch shape chosen per feature-map size
 int conv_halo8_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
+// 8-wave implicit-GEMM kernel with 64-deep steps (conv_igemm8.hip): 1x1 / strided k x k layers with cin % 32 == 0
+int conv_igemm8_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // dedicated stem kernel (conv_stem.hip): 6x3 s(2,1) super-pixel form, input patch in LDS, weights in registers
 int conv_stem_launch(const ConvArgs& a, int dtype, int out_dtype, hipStream_t s);
 // the same stem fed from planar (3, H, W) images of the compute dtype, identity-size batches (no letterbox pass)

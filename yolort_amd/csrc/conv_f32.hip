@@ -82,11 +82,15 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
         }
     };
 
-    f32x16 acc[2];
+    // Two-level (blocked) summation: a chain of K sequential fp32 FMAs has a rounding error ~ sqrt(K) ulp, several times
+    // what the CPU reference's vectorised / blocked sums produce, and the synthetic test network amplifies every ulp ~2500x
+    // on its way to the logits.  Partial sums over 64 k-elements go to `part`, which is folded into `acc` every 8 steps:
+    // error ~ sqrt(64) + sqrt(K / 64) ulp.
+    f32x16 acc[2], part[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; part[j][r] = 0.f; }
 
     const int fcol = lane & 31, hi = lane >> 5;
     load_regs(0);
@@ -102,8 +106,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float xf = As[cur][k][wave_m + j * 32 + fcol];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, xf, acc[j], 0, 0, 0);
+                part[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, xf, part[j], 0, 0, 0);
             }
+        }
+        if ((step & 7) == 7 || step + 1 == nsteps) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[j][r] += part[j][r]; part[j][r] = 0.f; }
         }
         if (step + 1 < nsteps) store_lds(cur ^ 1);
         __syncthreads();

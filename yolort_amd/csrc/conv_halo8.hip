@@ -6,13 +6,15 @@
 //   * a block is 8 waves (2 per SIMD) on a TH x TW output patch of up to 256 pixels of ONE image; TH, TW are chosen per
 //     feature-map size on the host so that the patches tile the map with little waste (16x16 on 80x80, 10x20 on 20x20 and
 //     40x40, ...);
-//   * per 32-channel chunk the (TH+2) x (TW+2) input patch goes to LDS ONCE (<= 22 DMA pieces, double buffered) and feeds all
-//     nine taps; only the weights stream per (tap, chunk) step: BN x 64 B = BN/16 pieces per step for the whole block.
-//     Every wave issues exactly ONE weight piece per step and, in the first three taps of a chunk, ONE piece of the next
-//     chunk's patch -- at most 2 DMA instructions per wave against 8 MFMAs (BN = 128);
-//   * the two waves of a SIMD interleave on the matrix pipe: while one sits in its s_waitcnt / barrier / ds_read latency the
-//     other issues MFMAs; inside a wave the fragments of the second k16 half are fetched under the MFMAs of the first.
-// Ring / counted-vmcnt / one raw s_barrier per step / source-side XOR swizzle exactly as in conv_igemm_impl.hpp (v2).
+//   * per 32-channel chunk the (TH+2) x (TW+2) input patch goes to LDS ONCE (<= 24 DMA pieces, double buffered) and feeds all
+//     nine taps; only the weights stream, and they stream in LONG steps: one step = one kernel ROW (3 taps) of one chunk =
+//     3 x BN x 64 B.  A wave issues <= 3 weight pieces + 1 patch piece per step against 24 MFMAs (BN = 128), spread between
+//     the MFMA groups; there is ONE barrier per 24 MFMAs per wave (the first version of this kernel synchronised per tap:
+//     8 MFMAs per barrier, and both waves of a SIMD sat in DMA issue / ds_read latency at the same time -- measured 880
+//     cycles of "compute" per 256 cycles of MFMA);
+//   * with steps of >= 1.5k cycles a two-deep weight ring and a plain vmcnt(0) suffice (loads have a whole step to land);
+//   * inside a step the fragments of sub-step i+1 (tap, k16 half) are fetched under the MFMAs of sub-step i.
+// One raw s_barrier per step / source-side XOR swizzle exactly as in conv_igemm_impl.hpp (v2).
 //
 // Same arithmetic and accumulator layout as every other conv kernel of this library (swapped MFMA D[cout][pixel], fp32
 // accumulate on top of the folded-BN bias, SiLU (+ residual) epilogue of conv_common.hpp, channel-slice views).
@@ -40,18 +42,19 @@ struct Halo8Geom {
     unsigned magic_tw, magic_pw;
 };
 
-template <int DT, int ODT, int BN, int WAVES_M, int STAGES>
+template <int DT, int ODT, int BN, int WAVES_M>
 __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, const Halo8Geom g) {
     constexpr int WAVES_N = 8 / WAVES_M;
     constexpr int WM = 256 / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1 && WAVES_M * WAVES_N == 8, "8 waves");
-    static_assert(STAGES == 3 || STAGES == 4, "weight ring depth");
-    constexpr int W_PIECES = BN / 16;
-    constexpr int WSTAGE_HALFS = BN * 32;
+    constexpr int ROW_PIECES = BN / 16;              // weight pieces of one tap
+    constexpr int W_PIECES = 3 * ROW_PIECES;         // ... of one stage = one kernel row (3 taps) x 32 channels
+    constexpr int PW = (W_PIECES + 7) / 8;           // weight pieces per wave per step
+    constexpr int WSTAGE_HALFS = 3 * BN * 32;
     typedef typename Mfma<DT>::frag frag;
 
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1][weight ring]
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1][weight stage 0][weight stage 1]
     const int patch_halfs = g.ppieces * 512;
     uint16_t* wring = smem + 2 * patch_halfs;
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     const int img = t / g.tiles_y;
     const int oy0 = ty * g.th, ox0 = tx * g.tw, n0 = bn * BN;
     const int nchunks = a.cin / 32;
-    const int nsteps = nchunks * 9;
+    const int nsteps = nchunks * 3;                  // one step = one kernel row (3 taps) of one 32-channel chunk
     H8_STAMP(0);
     f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
     load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
@@ -92,11 +95,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
         const int kchunk = (lane & 3) ^ ((q >> 2) & 3);
         p_off[j] = ok ? ((img * a.h + iy) * a.w_in + ix) * a.x_cs + kchunk * 8 : -1;
     }
-    // ---- weight DMA geometry: ONE piece (16 cout rows x 64 B) per wave per step; rows are zero padded to 128 ----
+    // ---- weight DMA geometry: stage = [tap 0..2][BN cout rows] x 64 B; wave w moves pieces w, w+8, ... (clamped);
+    //      packed weight rows are zero padded to 128 ----
     const int wchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    const int wpi = wave < W_PIECES ? wave : W_PIECES - 1;
-    const int w_slot = wpi * 512;
-    const int w_off = (n0 + wpi * 16 + (lane >> 2)) * a.k_pad + wchunk * 8;
+    int w_off[PW], w_slot[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        int pi = wave + 8 * j;
+        pi = pi < W_PIECES ? pi : W_PIECES - 1;
+        const int tap = pi / ROW_PIECES, rp = pi - tap * ROW_PIECES;
+        w_slot[j] = pi * 512;
+        w_off[j] = (n0 + rp * 16 + (lane >> 2)) * a.k_pad + tap * a.cin + wchunk * 8;
+    }
 
     auto issue_patch_piece = [&](int chunk, auto jt) {
         constexpr int j = decltype(jt)::value;
@@ -104,24 +114,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
         const int off = p_off[j] >= 0 ? p_off[j] + chunk * 32 : a.x_zero_off;
         glds16(a.x + off, dst + p_slot[j]);
     };
-    // weights of k = tap*cin + chunk*32 .. +31 into ring slot (step % STAGES)
-    int is_step = 0, is_koff = 0, is_tap = 0, is_slot = 0;   // issue-side position of the next weight step (wave-uniform scalars)
-    auto issue_next_w = [&]() {
-        glds16(a.w + (w_off + is_koff), wring + is_slot * WSTAGE_HALFS + w_slot);
-        ++is_step;
-        is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
-        is_koff += a.cin;                       // next tap, same chunk
-        if (++is_tap == 9) { is_tap = 0; is_koff += 32 - 9 * a.cin; }   // next chunk, tap 0
+    // weights of kernel row dy, channels chunk*32 .. +31 (k = (dy*3 + tap)*cin + chunk*32 + c) into stage `slot`
+    auto issue_w_piece = [&](int kbase, int slot, auto jt) {
+        constexpr int j = decltype(jt)::value;
+        glds16(a.w + (w_off[j] + kbase), wring + slot * WSTAGE_HALFS + w_slot[j]);
     };
 
     f32x16 acc[TN][TM];
     init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
-    // prologue: the whole first patch (3 pieces per wave), then STAGES-1 weight stages
+    // prologue: the whole first patch (3 pieces per wave) and weight stage 0
     static_for<0, 3>([&](auto jt) { issue_patch_piece(0, jt); });
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nsteps) issue_next_w();
+    static_for<0, PW>([&](auto jt) { issue_w_piece(0, 0, jt); });
 
     // ---- per-lane fragment geometry ----
     const int frow = lane & 31;
@@ -136,69 +140,68 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
         q0[j] = r * g.pw + c;
     }
     const int wswz = (lane >> 2) & 3;
-    const int wpos0 = ((0 + hi) ^ wswz) * 8, wpos1 = ((2 + hi) ^ wswz) * 8;
+    int wpos[2];
+    wpos[0] = ((0 + hi) ^ wswz) * 8;
+    wpos[1] = ((2 + hi) ^ wswz) * 8;
 
-    int chunk = 0, tap = 0, tapoff = 0, dx = 0, slot = 0;
-    const bool multi = nchunks > 1;
+    int chunk = 0, dy = 0;
     H8_STAMP(1);
     for (int step = 0; step < nsteps; ++step) {
-        // The weight piece of `step` was this wave's last DMA of step - (STAGES-1); what it issued afterwards may stay in
-        // flight: one weight piece per later step plus one patch piece for every later step that lay in taps 0..2 of a
-        // chunk with a successor.  (Older loads -- including every patch piece this step may read -- complete first.)
-        {
-            const int remaining = nsteps - 1 - step;                 // weight stages issued after this step's: min(STAGES-2, remaining)
-            int pend = remaining < STAGES - 2 ? remaining : STAGES - 2;
-            // patch pieces issued in the previous min(STAGES-2, step) steps
-            const bool has_next = chunk + 1 < nchunks;
-            if (multi) {
-                if (STAGES - 2 >= 1 && step >= 1 && tap >= 1 && tap <= 3 && has_next) ++pend;                  // step-1 had tap-1 in 0..2
-                if (STAGES - 2 >= 2 && step >= 2 && tap >= 2 && tap <= 4 && has_next) ++pend;                  // step-2 had tap-2 in 0..2
-            }
-            if (pend >= 4) wait_vmcnt<4>();
-            else if (pend == 3) wait_vmcnt<3>();
-            else if (pend == 2) wait_vmcnt<2>();
-            else if (pend == 1) wait_vmcnt<1>();
-            else wait_vmcnt<0>();
-        }
+        const int slot = step & 1;
+        // Two-deep ring with LONG steps (24 MFMAs per wave at BN = 128): the loads of stage step were issued one whole step
+        // (>= 1.5k cycles) ago, so a plain vmcnt(0) costs nothing, and one barrier per step is amortised over 3 taps.
+        wait_vmcnt<0>();
         H8_STAMP(4 + step * 3);
         __builtin_amdgcn_s_barrier();          // every wave's pieces of this stage landed; everyone is done with stage step-1
         __builtin_amdgcn_sched_barrier(0);
         H8_STAMP(5 + step * 3);
-        if (tap <= 2 && chunk + 1 < nchunks) {   // next chunk's patch: buffer (chunk+1)&1 was last read in chunk-1
-            if (tap == 0) issue_patch_piece(chunk + 1, std::integral_constant<int, 0>{});
-            else if (tap == 1) issue_patch_piece(chunk + 1, std::integral_constant<int, 1>{});
-            else issue_patch_piece(chunk + 1, std::integral_constant<int, 2>{});
-        }
-        if (step + STAGES - 1 < nsteps) issue_next_w();   // refill the slot freed by step-1
+        // next step's position (wave-uniform scalars)
+        const bool more = step + 1 < nsteps;
+        const int ndy = dy == 2 ? 0 : dy + 1;
+        const int nchunk = dy == 2 ? chunk + 1 : chunk;
+        const int nkbase = ndy * 3 * a.cin + nchunk * 32;
+        const bool patch_now = chunk + 1 < nchunks;   // piece set `dy` of the next chunk's patch: its buffer was last read in chunk-1
 
         const uint16_t* pb = smem + (chunk & 1) * patch_halfs;
         const uint16_t* ws = wring + slot * WSTAGE_HALFS + wave_n * 32;
-        frag af[2][TM], wf[2][TN];
+        const int rowoff = dy * g.pw;
+        frag fa[2][TM], fw[2][TN];
+        auto read_frags = [&](auto subt, auto buft) {   // sub-step = (tap, k16 half)
+            constexpr int sub = decltype(subt)::value, buf = decltype(buft)::value;
+            constexpr int tap = sub >> 1, ks = sub & 1;
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int q = q0[j] + tapoff;
-            const int e0 = q * 32 + ((hi ^ ((q >> 2) & 3)) * 8);
-            af[0][j] = *reinterpret_cast<const frag*>(pb + e0);
-            af[1][j] = *reinterpret_cast<const frag*>(pb + (e0 ^ 16));   // k-chunk (2+hi)^swz = flip bit 1
-        }
+            for (int j = 0; j < TM; ++j) {
+                const int q = q0[j] + rowoff + tap;
+                const int e0 = q * 32 + ((hi ^ ((q >> 2) & 3)) * 8);
+                fa[buf][j] = *reinterpret_cast<const frag*>(pb + (ks ? (e0 ^ 16) : e0));   // k-chunk (2+hi)^swz = flip bit 1
+            }
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            wf[0][i] = *reinterpret_cast<const frag*>(ws + (i * 32 + frow) * 32 + wpos0);
-            wf[1][i] = *reinterpret_cast<const frag*>(ws + (i * 32 + frow) * 32 + wpos1);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < TN; ++i) fw[buf][i] = *reinterpret_cast<const frag*>(ws + (tap * BN + i * 32 + frow) * 32 + wpos[ks]);
+        };
+        read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, 6>([&](auto subt) {
+            constexpr int sub = decltype(subt)::value;
+            // fragments of the next sub-step first (their latency hides under this sub-step's MFMAs) ...
+            if constexpr (sub + 1 < 6) read_frags(std::integral_constant<int, sub + 1>{}, std::integral_constant<int, (sub + 1) & 1>{});
+            // ... then one slice of next stage's DMA issue (spread over the sub-steps instead of a burst at the step's head)
+            if constexpr (sub == 0) {
+                if (patch_now) {
+                    if (dy == 0) issue_patch_piece(chunk + 1, std::integral_constant<int, 0>{});
+                    else if (dy == 1) issue_patch_piece(chunk + 1, std::integral_constant<int, 1>{});
+                    else issue_patch_piece(chunk + 1, std::integral_constant<int, 2>{});
+                }
+            } else if constexpr (sub - 1 < PW) {
+                if (more) issue_w_piece(nkbase, slot ^ 1, std::integral_constant<int, sub - 1>{});
+            }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(wf[ks][i], af[ks][j], acc[i][j]);
+                for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(fw[sub & 1][i], fa[sub & 1][j], acc[i][j]);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `step` before it reaches the next barrier
         H8_STAMP(6 + step * 3);
-        // advance (chunk, tap)
-        slot = slot + 1 == STAGES ? 0 : slot + 1;
-        if (++tap == 9) { tap = 0; tapoff = 0; dx = 0; ++chunk; }
-        else if (++dx == 3) { dx = 0; tapoff += g.pw - 2; }
-        else ++tapoff;
+        dy = ndy;
+        chunk = nchunk;
     }
 
     // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
@@ -234,7 +237,7 @@ static void choose_patch(int ho, int wo, int& th_best, int& tw_best) {
     }
 }
 
-template <int DT, int ODT, int BN, int WAVES_M, int STAGES>
+template <int DT, int ODT, int BN, int WAVES_M>
 static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     Halo8Geom g;
@@ -249,8 +252,8 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     g.magic_pw = magic(g.pw);
     a.nblk_m = a.n * g.tiles_x * g.tiles_y;
     a.nblk_n = cdiv(a.cout_pad, BN);
-    const size_t lds = (size_t)2 * g.ppieces * 1024 + (size_t)STAGES * BN * 64;
-    auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M, STAGES>;
+    const size_t lds = (size_t)2 * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
+    auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M>;
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a, g);
     return check_launch("conv_halo8_kernel");
@@ -259,13 +262,11 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
 template <int DT, int ODT>
 static int halo8_variant(const ConvArgs& a, int variant, hipStream_t s) {
     switch (variant) {
-        case 1: return launch_halo8<DT, ODT, 128, 4, 3>(a, s);   // 4x2 waves of 64 px x 64 cout
-        case 2: return launch_halo8<DT, ODT, 64, 4, 3>(a, s);    // 4x2 waves of 64 px x 32 cout
-        case 3: return launch_halo8<DT, ODT, 64, 8, 3>(a, s);    // 8x1 waves of 32 px x 64 cout
-        case 4: return launch_halo8<DT, ODT, 32, 8, 3>(a, s);    // 8x1 waves of 32 px x 32 cout
-        case 5: return launch_halo8<DT, ODT, 128, 4, 4>(a, s);   // as 1, 4-deep weight ring
-        case 6: return launch_halo8<DT, ODT, 64, 4, 4>(a, s);    // as 2, 4-deep weight ring
-        case 7: return launch_halo8<DT, ODT, 128, 8, 3>(a, s);   // 8x1 waves of 32 px x 128 cout
+        case 1: return launch_halo8<DT, ODT, 128, 4>(a, s);   // 4x2 waves of 64 px x 64 cout
+        case 2: return launch_halo8<DT, ODT, 64, 4>(a, s);    // 4x2 waves of 64 px x 32 cout
+        case 3: return launch_halo8<DT, ODT, 64, 8>(a, s);    // 8x1 waves of 32 px x 64 cout
+        case 4: return launch_halo8<DT, ODT, 32, 8>(a, s);    // 8x1 waves of 32 px x 32 cout
+        case 5: return launch_halo8<DT, ODT, 128, 8>(a, s);   // 8x1 waves of 32 px x 128 cout
         default: set_error("ymi_conv2d: unknown halo8 variant %d", variant); return YMI_EINVAL;
     }
 }

@@ -874,7 +874,7 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
         const int run_max = exact_full ? IMG_SORT_MAX : IMG_SORT_MAX / 2;
         const int lds_keys = cap_img < run_max ? cap_img : run_max;
         const size_t lds = (size_t)lds_keys * 8;
-        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)sort_image_kernel, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)sort_image_kernel, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
         // the producers wrote arrays [0] (per-image regions); G goes to arrays [1] (compact), P to its own pair
         hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, w.sel_count, cap_img, d->n, L.label_bits, lds_keys,
                            w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);

@@ -12,7 +12,7 @@ namespace ymi {
 // One thread per output pixel; up to LB_MAX images per launch (descriptors travel as kernargs so
 // there is no device-side pointer table to allocate).
 // ---------------------------------------------------------------------------------------------
-constexpr int LB_MAX = 32;
+constexpr int LB_MAX = 64;
 struct LetterboxArgs {
     const void* img[LB_MAX];
     int geom[LB_MAX][6];  // h_in, w_in, h_res, w_res, pad_top, pad_left
@@ -148,6 +148,163 @@ __global__ __launch_bounds__(256) void letterbox_copy_kernel(const LetterboxArgs
     }
 }
 
+
+// Tiled, LDS-staged form of the same letterbox (round 2): one thread per output pixel with twelve scalar 2-byte gathers ran at
+// 0.23-0.26 of the HBM roofline -- the vector-memory pipe sees 12 load instructions per 8 output bytes.  Here a block owns
+// LB_TH x LB_TW output pixels of one image: the source rows it needs are staged into LDS ONCE with aligned 16-byte loads
+// (every source byte crosses the memory pipe once, in full 16-byte requests), the bilinear taps then come from LDS, and
+// each thread writes TWO pixels = one 16-byte store (a wave covers 1 KiB of a canvas row).  Same arithmetic as
+// letterbox_kernel, operation for operation: results are bit-identical.
+constexpr int LB_TH = 4, LB_TW = 128;
+
+struct LetterboxTileArgs {
+    LetterboxArgs base;
+    int tiles_x, tiles_y;
+};
+
+template <int IDT>
+__device__ __forceinline__ float lds_elem(const unsigned char* p) {
+    if constexpr (IDT == YMI_F16) { uint16_t v; __builtin_memcpy(&v, p, 2); return h2f(v); }
+    else if constexpr (IDT == YMI_BF16) { uint16_t v; __builtin_memcpy(&v, p, 2); return bf2f(v); }
+    else if constexpr (IDT == YMI_F32) { float v; __builtin_memcpy(&v, p, 4); return v; }
+    else return (float)(*p) / 255.0f;
+}
+
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void letterbox_tile_kernel(const LetterboxTileArgs t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lb_sm[];
+    const LetterboxArgs& a = t.base;
+    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
+    constexpr bool HWC = IDT == YMI_U8_HWC;
+    constexpr int BPP = HWC ? 3 : ESZ;              // bytes per pixel within one source row of one plane
+    constexpr int PLANES = HWC ? 1 : 3;
+    const int img = blockIdx.y;
+    const int ty = blockIdx.x / t.tiles_x, tx = blockIdx.x - ty * t.tiles_x;
+    const int y0t = ty * LB_TH, x0t = tx * LB_TW;
+    const int hin = a.geom[img][0], win = a.geom[img][1], hr = a.geom[img][2], wr = a.geom[img][3];
+    const int pt = a.geom[img][4], pl = a.geom[img][5];
+    const float sy = (float)hin / (float)hr, sx = (float)win / (float)wr;
+    // source coordinate of an output row / column inside the resized region (exactly the arithmetic of letterbox_kernel)
+    auto src = [](float s, int d, int n_in, int& i0, int& i1, float& l1) {
+        float f = __fsub_rn(__fmul_rn(s, (float)d + 0.5f), 0.5f);
+        f = f < 0.f ? 0.f : f;
+        i0 = (int)f;
+        i0 = i0 > n_in - 1 ? n_in - 1 : i0;
+        i1 = i0 + 1 > n_in - 1 ? n_in - 1 : i0 + 1;
+        l1 = f - (float)i0;
+        l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    };
+    // tile ^ resized region
+    const int ya = max(y0t, pt), yb = min(y0t + LB_TH, min(pt + hr, a.hb));       // output rows [ya, yb) resample the image
+    const int xa = max(x0t, pl), xb = min(x0t + LB_TW, min(pl + wr, a.wb));
+    const bool any = ya < yb && xa < xb;
+    int ry0 = 0, ry1 = -1, cx0 = 0, cx1 = -1;
+    if (any) {
+        int i0, i1;
+        float l;
+        src(sy, ya - pt, hin, ry0, i1, l);
+        src(sy, yb - 1 - pt, hin, i0, ry1, l);
+        src(sx, xa - pl, win, cx0, i1, l);
+        src(sx, xb - 1 - pl, win, i0, cx1, l);
+    }
+    const int nrows = ry1 - ry0 + 1;
+    const int span = (cx1 - cx0 + 1) * BPP;                      // bytes of one staged source row
+    const int pitch = ((span + 15 + 15) >> 4) << 4;              // + up to 15 bytes of alignment slack, rounded to 16
+    const unsigned char* base = (const unsigned char*)a.img[img];
+    const int64_t plane_b = (int64_t)hin * win * ESZ;
+    const int64_t row_b = (int64_t)win * BPP;
+    if (any) {
+        const int cpr = pitch >> 4;                              // 16-byte chunks per staged row
+        const int total = PLANES * nrows * cpr;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int k = i % cpr;
+            const int rr = (i / cpr) % nrows;
+            const int c = i / (cpr * nrows);
+            const uintptr_t g = (uintptr_t)(base + c * plane_b + (int64_t)(ry0 + rr) * row_b + (int64_t)cx0 * BPP);
+            const uintptr_t g_al = g & ~(uintptr_t)15;
+            // aligned 16-byte requests, only chunks that hold at least one needed byte: a chunk may run < 16 bytes past the
+            // row's last byte, but an aligned 16-byte chunk never crosses a page, so the over-read cannot fault
+            if (g_al + (uintptr_t)k * 16 < g + (uintptr_t)span) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(g_al + (uintptr_t)k * 16);
+                *reinterpret_cast<u32x4*>(lb_sm + ((size_t)(c * nrows + rr) * pitch + k * 16)) = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int y = y0t + (threadIdx.x >> 6);
+    const int x = x0t + (threadIdx.x & 63) * 2;
+    if (y >= a.hb || x >= a.wb) return;
+    float v[2][3];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        v[p][0] = v[p][1] = v[p][2] = a.fill;
+        const int yy = y - pt, xx = x + p - pl;
+        if ((unsigned)yy < (unsigned)hr && (unsigned)xx < (unsigned)wr && x + p < a.wb) {
+            int sy0, sy1, sx0, sx1;
+            float ly1, lx1;
+            src(sy, yy, hin, sy0, sy1, ly1);
+            src(sx, xx, win, sx0, sx1, lx1);
+            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int pc = HWC ? 0 : c;
+                const int sub = HWC ? c : 0;
+                // alignment shift of the staged rows (recomputed, cheaper than a table): (address of row start) & 15
+                const int sh0 = (int)(((uintptr_t)(base + pc * plane_b + (int64_t)sy0 * row_b + (int64_t)cx0 * BPP)) & 15);
+                const int sh1 = (int)(((uintptr_t)(base + pc * plane_b + (int64_t)sy1 * row_b + (int64_t)cx0 * BPP)) & 15);
+                const unsigned char* r0 = lb_sm + (size_t)(pc * nrows + (sy0 - ry0)) * pitch + sh0 + sub;
+                const unsigned char* r1 = lb_sm + (size_t)(pc * nrows + (sy1 - ry0)) * pitch + sh1 + sub;
+                const float p00 = lds_elem<IDT>(r0 + (sx0 - cx0) * BPP), p01 = lds_elem<IDT>(r0 + (sx1 - cx0) * BPP);
+                const float p10 = lds_elem<IDT>(r1 + (sx0 - cx0) * BPP), p11 = lds_elem<IDT>(r1 + (sx1 - cx0) * BPP);
+                const float top = __fadd_rn(__fmul_rn(p00, lx0), __fmul_rn(p01, lx1));
+                const float bot = __fadd_rn(__fmul_rn(p10, lx0), __fmul_rn(p11, lx1));
+                v[p][c] = __fadd_rn(__fmul_rn(top, ly0), __fmul_rn(bot, ly1));
+            }
+        }
+    }
+    const int64_t o = (((int64_t)img * a.hb + y) * a.wb + x) * 4;
+    const bool two = x + 1 < a.wb;
+    if constexpr (ODT == YMI_F32) {
+        float* op = (float*)a.out + o;
+        f32x4 q0 = {v[0][0], v[0][1], v[0][2], 0.f};
+        *reinterpret_cast<f32x4*>(op) = q0;
+        if (two) {
+            f32x4 q1 = {v[1][0], v[1][1], v[1][2], 0.f};
+            *reinterpret_cast<f32x4*>(op + 4) = q1;
+        }
+    } else {
+        uint16_t* op = (uint16_t*)a.out + o;
+        u32x4 q;
+        q[0] = (uint32_t)to16<ODT>(v[0][0]) | ((uint32_t)to16<ODT>(v[0][1]) << 16);
+        q[1] = (uint32_t)to16<ODT>(v[0][2]);
+        q[2] = (uint32_t)to16<ODT>(v[1][0]) | ((uint32_t)to16<ODT>(v[1][1]) << 16);
+        q[3] = (uint32_t)to16<ODT>(v[1][2]);
+        if (two && (a.wb & 1) == 0) *reinterpret_cast<u32x4*>(op) = q;   // even canvas width: pixel pairs are 16-byte aligned
+        else {
+            u32x2 h0 = {q[0], q[1]};
+            *reinterpret_cast<u32x2*>(op) = h0;
+            if (two) { u32x2 h1 = {q[2], q[3]}; *reinterpret_cast<u32x2*>(op + 4) = h1; }
+        }
+    }
+}
+
+// LDS bytes the tiled kernel needs for this launch (max over its images); 0 = some image does not fit (huge down-scale)
+template <int IDT>
+static size_t letterbox_tile_lds(const LetterboxArgs& a) {
+    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
+    constexpr int BPP = IDT == YMI_U8_HWC ? 3 : ESZ;
+    constexpr int PLANES = IDT == YMI_U8_HWC ? 1 : 3;
+    size_t need = 16;
+    for (int i = 0; i < a.n; ++i) {
+        const double sy = (double)a.geom[i][0] / a.geom[i][2], sx = (double)a.geom[i][1] / a.geom[i][3];
+        const int rows = (int)(LB_TH * sy) + 3, cols = (int)(LB_TW * sx) + 3;
+        const size_t pitch = (((size_t)(cols < a.geom[i][1] ? cols : a.geom[i][1]) * BPP + 30) >> 4) << 4;
+        const size_t b = (size_t)PLANES * (rows < a.geom[i][0] ? rows : a.geom[i][0]) * pitch;
+        need = b > need ? b : need;
+    }
+    return need <= 60 * 1024 ? need : 0;
+}
+
 template <int IDT>
 static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t s) {
     bool identity = a.c_out == 4 && a.wb % 4 == 0;
@@ -167,6 +324,21 @@ static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t
         }
 #undef YMI_LBC
         return check_launch("letterbox_copy_kernel");
+    }
+    const size_t tile_lds = a.c_out == 4 ? letterbox_tile_lds<IDT>(a) : 0;
+    if (tile_lds > 0) {   // tiled, LDS-staged kernel (bit-identical to letterbox_kernel)
+        LetterboxTileArgs t;
+        t.base = a;
+        t.tiles_x = cdiv(a.wb, LB_TW);
+        t.tiles_y = cdiv(a.hb, LB_TH);
+        dim3 gt((unsigned)(t.tiles_x * t.tiles_y), (unsigned)a.n), bt(256);
+        switch (out_dtype) {
+            case YMI_F16: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_F16>), gt, bt, tile_lds, s, t); break;
+            case YMI_BF16: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_BF16>), gt, bt, tile_lds, s, t); break;
+            case YMI_F32: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_F32>), gt, bt, tile_lds, s, t); break;
+            default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
+        }
+        return check_launch("letterbox_tile_kernel");
     }
     const int64_t total = (int64_t)a.n * a.hb * a.wb;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -492,12 +664,15 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
         return check_launch("spp_pool_f32_kernel");
     }
     YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_spp_pool: dtype must be F16/BF16/F32");
-    const int G = (c % 32 == 0) ? 4 : 1;
+    // LDS cascade form: the plane of 8*G channels three times in LDS; G = 4 (64-byte runs per pixel) when it fits, else G = 1
+    // (yolov5m/l at 1280x1280: 40x40 maps -- round 1 fell back to the 169-tap direct kernel there: 1.75 ms per step at C3)
+    int G = (c % 32 == 0) ? 4 : 1;
+    if ((size_t)h * w * G * 16 * 3 > 160 * 1024 - 512) G = 1;
     const size_t lds = (size_t)h * w * G * 16 * 3;
-    if (lds <= 160 * 1024 - 512) {  // the plane of 8*G channels fits the 160 KB LDS three times
+    if (lds <= 160 * 1024 - 512) {
         dim3 g((unsigned)(n * (c / (8 * G)))), b(256);
         auto launch = [&](auto kfn) -> int {
-            if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+            if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
             hipLaunchKernelGGL(kfn, g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
             return check_launch("spp_pool_lds_kernel");
         };

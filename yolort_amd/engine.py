@@ -336,11 +336,18 @@ class Plan:
         if d.cin % 32 == 0 and d.kh * d.kw <= 32:
             cands = cands + [t + 50 for t in cands]   # the same tiles with the software-pipelined main loop (61..65, 71..77)
             cands = cands + ([69, 70] if d.cout_pad > 32 else []) + ([66, 68] if d.cout_pad >= 128 else [])   # 3-stage / 256-pixel tiles
+        if d.cin % 32 == 0 and d.kh * d.kw <= 32 and d.k_pad == d.kh * d.kw * d.cin:
+            # 8-wave implicit GEMM with 64-deep steps (conv_igemm8.hip); a chained 1x1 needs pixel-major waves of its K1 width
+            if chain is not None:
+                k1 = d.cout_split if d.cout_split > 0 else d.cout
+                cands = cands + ([114] if k1 == 32 else ([113] if k1 == 64 else []))
+            else:
+                cands = cands + ([114] if d.cout_pad <= 32 else ([112, 113] if d.cout_pad <= 64 else ([111, 112, 116] if d.cout_pad <= 128 else [111, 115, 112])))
         if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin % 32 == 0 and d.cout_split == 0 and d.k_pad == 9 * d.cin:
             # LDS-halo kernel variants (activation patch resident in LDS across the nine taps)
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
             if chain is None:   # 8-wave halo kernel (conv_halo8.hip): 256-pixel patches, <= 2 DMA pieces per wave per step
-                cands = cands + ([94] if d.cout_pad <= 32 else ([92, 93, 96] if d.cout_pad <= 64 else [91, 92, 93, 95, 97]))
+                cands = cands + ([94] if d.cout_pad <= 32 else ([92, 93] if d.cout_pad <= 64 else [91, 92, 93, 95]))
         if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
             cands = cands + [41]   # dedicated stem kernel
         best, best_ms = 0, float("inf")
