@@ -119,7 +119,7 @@ class PackedConv:
 
 
 _TILE_TABLE: Optional[Dict[str, int]] = None
-TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tiles_gfx950.json")
+TILE_TABLE_PATH = os.environ.get("YOLORT_AMD_TILE_TABLE_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tiles_gfx950.json")   # override: A/B runs only
 
 
 def tile_key_str(key: Tuple, dtype: torch.dtype) -> str:
@@ -336,6 +336,13 @@ class Plan:
         if d.cin % 32 == 0 and d.kh * d.kw <= 32:
             cands = cands + [t + 50 for t in cands]   # the same tiles with the software-pipelined main loop (61..65, 71..77)
             cands = cands + ([69, 70] if d.cout_pad > 32 else []) + ([66, 68] if d.cout_pad >= 128 else [])   # 3-stage / 256-pixel tiles
+        if d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1 and d.cin % 32 == 0 and d.cin <= 128 and d.k_pad == d.cin and d.out_dtype == d.dtype and d.y2_mode == 0 and d.cout % 32 == 0:
+            # streaming 1x1 kernel (conv1x1_stream.hip): variant = cout tiles of 32 per wave; a split / chained conv fixes the block width
+            k1 = d.cout_split if d.cout_split > 0 else 0
+            if chain is not None:
+                cands = cands + [120 + (k1 if k1 else d.cout) // 32]
+            else:
+                cands = cands + [120 + t for t in (1, 2, 3, 4) if (k1 == 0 or k1 % (32 * t) == 0)]
         if d.cin % 32 == 0 and d.kh * d.kw <= 32 and d.k_pad == d.kh * d.kw * d.cin:
             # 8-wave implicit GEMM with 64-deep steps (conv_igemm8.hip); a chained 1x1 needs pixel-major waves of its K1 width
             if chain is not None:
