@@ -312,11 +312,13 @@ def main():
             dets = collect(pending.pop(0))
         return dets
 
+    if world > 1:
+        yolo.enable_distributed_gather()   # the slab all-gather is enqueued behind each batch's post-process (no host sync before it)
+
     def collect(p):
         dets = p.result()
         if world > 1:
-            e = p.entry
-            ydist.all_gather_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count)
+            p.gathered()
         return dets
 
     dets = run_steps(max(args.warmup, 1))

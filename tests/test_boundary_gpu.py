@@ -247,3 +247,44 @@ def test_upstream_checkpoint_ingest_predicts_like_the_converted_state_dict(dev, 
             assert torch.equal(a[k], b[k])
         frac, miou, _ = match_fraction(_np(r), _np(a), margin=0.03, thr=0.3)
         assert frac >= 0.9 and miou >= 0.9, (frac, miou)
+
+
+_GATHER_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%d), RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from yolort_amd.models import YOLOv5
+from yolort_amd.utils.synth import synth_images, synth_weights
+arch = "yolov5_darknet_pan_n_r60"
+m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
+m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+m = m.to("cuda:0").half().eval()
+m.model.enable_distributed_gather(force=True)
+batches = [[synth_images(1, 128, 160, seed=300 + i)[0].to("cuda:0"), synth_images(1, 160, 120, seed=400 + i)[0].to("cuda:0")] for i in range(4)]
+pend = [m.forward_async(b) for b in batches]
+ok = True
+for p in pend:
+    dets = p.result()
+    b, s, l, c = p.gathered()
+    for i, d in enumerate(dets):
+        k = int(c[i])
+        ok = ok and k == len(d["scores"]) and torch.equal(b[i, :k], d["boxes"]) and torch.equal(s[i, :k], d["scores"]) and torch.equal(l[i, :k], d["labels"])
+    ok = ok and int(c.sum()) > 0
+print("GATHER_OK" if ok else "GATHER_MISMATCH")
+dist.destroy_process_group()
+"""
+
+
+def test_slab_all_gather_is_enqueued_behind_the_post_process(dev):
+    """SURVEY 8e / VERDICT r1 weak 12: with YOLO.enable_distributed_gather() the fixed-shape slab all-gather (RCCL, backend
+    "nccl") is issued from the post-process stream of every batch; here on a world of one rank (the only GPU of the box), several
+    batches in flight -- the gathered slab equals the local detections"""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    r = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT % (ROOT, port)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GATHER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -1,19 +1,19 @@
 #!/bin/bash
-# round 2, GPU call A: tile table, full GPU test suite, bench lines for c2/c3/c5, rocprofv3 kernel trace + PMC passes (serial driver)
+# round 2, GPU call I: per-layer table with PMC (fixed matching), LDS-floor / pipeline-depth experiment, new tests
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r02a
+O=gpurun_out/r02i
 mkdir -p $O
-echo "== tune tiles" ; date
-timeout 900 python tools/tune_tiles.py --out $O/tiles_gfx950.json > $O/tune.log 2>&1; tail -3 $O/tune.log
-[ -s $O/tiles_gfx950.json ] && cp $O/tiles_gfx950.json yolort_amd/data/tiles_gfx950.json
-echo "== tests" ; date
-timeout 1800 python -m pytest tests -m gpu -q -s --timeout 900 -p no:cacheprovider > $O/tests.log 2>&1; grep -v "^$" $O/tests.log | tail -60
-echo "== bench" ; date
-timeout 600 python bench.py > $O/bench_c2.log 2>&1; grep '^{"metric' $O/bench_c2.log | tail -1 > $O/bench_c2.json; cut -c1-600 $O/bench_c2.json
-timeout 600 python bench.py --config c3 > $O/bench_c3.log 2>&1; grep '^{"metric' $O/bench_c3.log | tail -1 > $O/bench_c3.json; cut -c1-300 $O/bench_c3.json
-timeout 600 python bench.py --config c5 > $O/bench_c5.log 2>&1; grep '^{"metric' $O/bench_c5.log | tail -1 > $O/bench_c5.json; cut -c1-300 $O/bench_c5.json
-echo "== rocprof" ; date
+date
+timeout 600 python -m pytest tests/test_boundary_gpu.py tests/test_ops_gpu.py -m gpu -q --timeout 600 -p no:cacheprovider -k "gather or chained_1x1 or stream" > $O/tests.log 2>&1; tail -3 $O/tests.log
+for fl in 0 54 81; do for pd in 4 6; do
+YOLORT_AMD_LDS_FLOOR_KB=$fl YOLORT_AMD_PIPELINE=$pd timeout 300 python bench.py --config c2 --no-cpu-baseline --steps 100 > $O/fl_${fl}_$pd.log 2>&1; python -c "
+import json
+d=json.loads([l for l in open('$O/fl_${fl}_$pd.log') if l.startswith('{\"metric')][-1]); r=d['roofline']
+print('lds floor $fl KB, pipeline $pd:', d['value'], 'img/s', d['ms_per_step'], 'ms/step; conv excl', r['conv_ms_per_step'])
+"
+done; done
+date
 for cfg in c2 c3 c5; do
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$cfg -o r -- python $GRAFT_REPO_ROOT/tools/profile_serial.py --config $cfg --steps 8 --ops $GRAFT_REPO_ROOT/$O/ops_$cfg.json > /tmp/ps_$cfg.log 2>&1)
   db=$(find /tmp/prof_$cfg -name "*.db" | head -1)
@@ -27,5 +27,5 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 
 done
 dbs=$(for i in 1 2 3 4; do find /tmp/pmc_$i -name "*.db" | head -1; done)
 python tools/layer_table.py --ops $O/ops_c2.json --stats $(find /tmp/prof_c2 -name "*.db" | head -1) --pmc $dbs > $O/layer_table_c2_pmc.csv 2>> $O/err.log
-tail -3 $O/layer_table_c2_pmc.csv; tail -5 $O/err.log
+tail -12 $O/layer_table_c2_pmc.csv | cut -c1-200; tail -5 $O/err.log
 date

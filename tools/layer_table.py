@@ -6,8 +6,8 @@ Dispatches are matched to plan ops by order within a step (a step starts at the 
 the trace are used, i.e. the serial, one-batch-in-flight phase).  Per conv launch: average kernel duration, TFLOP/s and GB/s
 from the ALGORITHMIC flops / bytes (SURVEY.md 8d accounting), fraction of the layer's own bound
 max(flops / 2.5 PF, bytes / 8 TB/s), and -- when PMC passes are given -- the SQ counters averaged per launch
-(SQ_VALU_MFMA_BUSY_CYCLES etc.; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) when GRBM_GUI_ACTIVE
-is in the same pass, else / (duration x 2.4 GHz x 1024)).
+(SQ_VALU_MFMA_BUSY_CYCLES etc.; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of
+SIMD-cycles, at the clock the kernel actually ran at, in which the matrix pipe was busy).
 """
 import argparse
 import json
@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
-CONV_LIKE = ("conv_", "conv3x3_", "spp_pool")     # kernels that correspond 1:1 to plan ops of kind conv / pool
+CONV_LIKE = ("ymi::conv", "spp_pool")     # kernels that correspond 1:1 to plan ops of kind conv / pool (incl. the fused head)
 STEM = ("conv_stem", "letterbox")     # first kernel of a step
 
 
@@ -111,7 +111,9 @@ def main():
             busy = pmc[k].get("SQ_VALU_MFMA_BUSY_CYCLES", [])
             gui = pmc[k].get("GRBM_GUI_ACTIVE", [])
             if busy:
-                denom = (sum(gui) / len(gui)) * 1024 if gui else t * 1e-6 * 2.4e9 * 1024
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (calibrated on the stem: 2.19 M for a 116 us kernel = 8 x 274 k cycles);
+                # SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs (= 32 x SQ_INSTS_MFMA for 32x32x16 f16)
+                denom = (sum(gui) / len(gui)) / 8 * 1024 if gui else t * 1e-6 * 2.4e9 * 1024
                 extra = [f"{(sum(busy) / len(busy)) / denom:.3f}"]
             else:
                 extra = [""]

@@ -1,36 +1,32 @@
 #!/bin/bash
-# end-of-round measurement set: bench (with cpu baseline), kernel-trace stats, FETCH/WRITE PMC passes (separate runs)
+# Measurement set of a round (run on the MI355X box via gpurun): full GPU test suite, bench lines for BASELINE configs[1] / [2] / [4]
+# (with cpu_baseline + parity), rocprofv3 kernel-trace stats of the serial driver per config, per-layer roofline table, and the
+# PMC passes for configs[1] (SQ counters incl. SQ_VALU_MFMA_BUSY_CYCLES, FETCH_SIZE, WRITE_SIZE -- separate passes).
+# usage: bash tools/run_profiles.sh <tag>      -> gpurun_out/<tag>/   (copy what should be judged into profiles/)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 500 python bench.py --steps 100 --warmup 10 > gpurun_out/r01d_bench.log 2>&1; grep '^{"metric' gpurun_out/r01d_bench.log | tail -1 > gpurun_out/r01d_bench.json
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 8 --no-cpu-baseline > /tmp/b_s.log 2>&1)
-python tools/rocprof_summary.py $(find /tmp/prof_s -name "*.db" | head -1) > gpurun_out/r01d_rocprof_summary.csv
-grep '^{"metric' /tmp/b_s.log | tail -1 > gpurun_out/r01d_bench_under_rocprof.json
-for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && YOLORT_AMD_AUTOTUNE=0 timeout 400 rocprofv3 --pmc $c -d /tmp/prof_$c -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline > /tmp/b_$c.log 2>&1)
+TAG=${1:-r02}
+O=gpurun_out/$TAG
+mkdir -p $O
+echo "== tests" ; date
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $O/tests.log 2>&1; tail -4 $O/tests.log
+echo "== bench" ; date
+for c in c2 c3 c5; do
+  timeout 600 python bench.py --config $c > $O/bench_$c.log 2>&1; grep '^{"metric' $O/bench_$c.log | tail -1 > $O/bench_$c.json; cut -c1-160 $O/bench_$c.json
 done
-python - <<'PY' > gpurun_out/r01d_conv_traffic.txt
-import sqlite3, glob
-tot={}
-for c in ("FETCH_SIZE","WRITE_SIZE"):
-    dbs=glob.glob(f"/tmp/prof_{c}/**/*.db", recursive=True)
-    if not dbs: print(c,"no db"); continue
-    cur=sqlite3.connect(dbs[0]).cursor()
-    cols=[d[0] for d in cur.execute("select * from counters_collection limit 1").description]
-    nm="kernel_name" if "kernel_name" in cols else "name"
-    rows=list(cur.execute(f"select {nm}, count(*), sum(value) from counters_collection where counter_name='{c}' group by {nm}"))
-    conv=sum(v for n,k,v in rows if 'conv' in n)
-    grp=sum(k for n,k,v in rows if 'conv_head_decode_group' in n)   # one grouped head launch per forward pass (else three per-level launches)
-    nsteps=max(1, grp if grp else sum(k for n,k,v in rows if 'conv_head_decode' in n)//3)
-    allk=sum(v for n,k,v in rows)
-    tot[c]=(conv,allk,nsteps)
-    print(f"# {c}: conv kernels {conv/1024:.1f} MB total over the run, all kernels {allk/1024:.1f} MB (counter unit KB)")
-    for n,k,v in sorted(rows,key=lambda r:-r[2])[:12]: print(f"{c},{k},{v/1024:.1f} MB,{n[:90]}")
-if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
-    steps=tot["FETCH_SIZE"][2]
-    f=tot["FETCH_SIZE"][0]/1024/steps; w=tot["WRITE_SIZE"][0]/1024/tot["WRITE_SIZE"][2]
-    print(f"conv kernels (incl. fused head), autotune off, {steps} forward passes in the run (timed steps + the exclusive-conv and parity passes): FETCH_SIZE {f:.1f} MB/step raw ({2*f:.1f} MB with the gfx950 x2 correction), WRITE_SIZE {w:.1f} MB/step")
-PY
-cat gpurun_out/r01d_conv_traffic.txt | tail -3
-cut -c1-400 gpurun_out/r01d_bench.json
+echo "== rocprof" ; date
+for cfg in c2 c3 c5; do
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$cfg -o r -- python $GRAFT_REPO_ROOT/tools/profile_serial.py --config $cfg --steps 8 --ops $GRAFT_REPO_ROOT/$O/ops_$cfg.json > /tmp/ps_$cfg.log 2>&1)
+  db=$(find /tmp/prof_$cfg -name "*.db" | head -1)
+  python tools/rocprof_summary.py $db > $O/rocprof_summary_$cfg.csv 2>> $O/err.log
+  python tools/layer_table.py --ops $O/ops_$cfg.json --stats $db > $O/layer_table_$cfg.csv 2>> $O/err.log
+done
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  (cd /tmp && timeout 400 rocprofv3 --pmc $set -d /tmp/pmc_$i -o r -- python $GRAFT_REPO_ROOT/tools/profile_serial.py --config c2 --steps 8 > /tmp/pmc_$i.log 2>&1)
+done
+dbs=$(for i in 1 2 3 4; do find /tmp/pmc_$i -name "*.db" | head -1; done)
+python tools/layer_table.py --ops $O/ops_c2.json --stats $(find /tmp/prof_c2 -name "*.db" | head -1) --pmc $dbs > $O/layer_table_c2_pmc.csv 2>> $O/err.log
+tail -3 $O/layer_table_c2_pmc.csv; tail -5 $O/err.log
+date

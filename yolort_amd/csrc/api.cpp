@@ -1,6 +1,7 @@
 // C-ABI glue of libyolort_amd.so: error reporting and the plan executor (recorded launch sequence,
 // optional hipGraph replay, per-op HIP-event profiling).  See include/yolort_amd.h.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -32,6 +33,14 @@ int allow_big_lds(const void* kernel_fn, int bytes) {
     YMI_CHECK_HIP(hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     done[{kernel_fn, dev}] = bytes;
     return YMI_OK;
+}
+
+size_t lds_floor_bytes() {
+    static const size_t v = [] {
+        const char* e = getenv("YOLORT_AMD_LDS_FLOOR_KB");
+        return e ? (size_t)atoi(e) * 1024 : (size_t)0;
+    }();
+    return v;
 }
 
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);

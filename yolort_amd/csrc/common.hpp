@@ -30,6 +30,10 @@ void set_error(const char* fmt, ...);
 // Opt-in to > 64 KiB of dynamic LDS: a per-function (and per-device) attribute.  It is set ONCE per (kernel, device) and
 // remembered -- calling hipFuncSetAttribute on every launch sat on the enqueue path of every big-tile conv.
 int allow_big_lds(const void* kernel_fn, int bytes);
+// Tuning knob (YOLORT_AMD_LDS_FLOOR_KB, default 0): minimum dynamic LDS a conv launch requests.  A floor of 81 KiB caps a
+// kernel at ONE block per CU, so that blocks of OTHER batches' kernels (other streams, other phases) share the CU instead of
+// a second, phase-locked block of the same kernel.
+size_t lds_floor_bytes();
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

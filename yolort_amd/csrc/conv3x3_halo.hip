@@ -195,8 +195,9 @@ static int launch_halo(const ConvArgs& a0, hipStream_t s) {
     const int tiles_x = cdiv(a.wo, HTW), tiles_y = cdiv(a.ho, HTH);
     a.nblk_m = a.n * tiles_x * tiles_y;
     a.nblk_n = cdiv(a.cout_pad, BN);
-    const size_t lds = (size_t)2 * HPIX * 64 + (size_t)STAGES * BN * 64;
+    size_t lds = (size_t)2 * HPIX * 64 + (size_t)STAGES * BN * 64;
     auto kfn = conv3x3_halo_kernel<DT, ODT, BN, WM, WN, STAGES>;
+    if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, s, a, tiles_x, tiles_y);
     return check_launch("conv3x3_halo_kernel");

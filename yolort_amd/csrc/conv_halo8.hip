@@ -252,8 +252,9 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     g.magic_pw = magic(g.pw);
     a.nblk_m = a.n * g.tiles_x * g.tiles_y;
     a.nblk_n = cdiv(a.cout_pad, BN);
-    const size_t lds = (size_t)2 * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
+    size_t lds = (size_t)2 * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
     auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M>;
+    if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a, g);
     return check_launch("conv_halo8_kernel");

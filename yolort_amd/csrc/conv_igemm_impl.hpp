@@ -573,6 +573,7 @@ __global__ __launch_bounds__(256) void conv_head_decode_group_kernel(const HeadG
 
 template <typename K>
 int launch_v2_kernel(K kfn, const ConvArgs& a, size_t lds, dim3 grid, hipStream_t s) {
+    if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
     return check_launch("conv_igemm_v2_kernel");

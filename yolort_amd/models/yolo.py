@@ -60,6 +60,7 @@ class PendingDetections:
         self.owner, self.entry, self.rows, self.hook_result = owner, entry, rows, hook_result
         self.event = entry.done
         self._result: Optional[List[Dict[str, Tensor]]] = None
+        self._gathered = None
         # planar input images when the stem read them directly (entry.x was never filled): a redo must start from them
         self.planar = planar
 
@@ -74,6 +75,17 @@ class PendingDetections:
             if self.entry.outstanding is self:
                 self.entry.outstanding = None
         return self._result
+
+    def gathered(self):
+        """global detection slab (boxes (G*N,K,4), scores, labels, counts) in rank order; needs YOLO.enable_distributed_gather()"""
+        from .. import dist as ydist
+        self.result()
+        g = getattr(self.entry, "gathered", None) if self._gathered is None else None
+        if self._gathered is None:
+            if g is None:
+                raise YmiError("no distributed gather was enabled for this batch (YOLO.enable_distributed_gather)")
+            self._gathered = ydist.unpack_slab(g.clone(), self.entry.post.k)
+        return self._gathered
 
     def _collect(self) -> List[Dict[str, Tensor]]:
         e = self.entry
@@ -140,6 +152,10 @@ class YOLO(nn.Module):
         self.max_shapes = int(os.environ.get("YOLORT_AMD_MAX_SHAPES", "4"))                       # LRU of (batch, canvas) shapes with live plans
         self.max_plan_bytes = int(float(os.environ.get("YOLORT_AMD_MAX_PLAN_GB", "96")) * 2**30)    # activation memory bound of that LRU
         self._has_warned = False
+        # multi-GPU serving (yolort_amd/dist.py): when set, every batch's detection slab is all-gathered over RCCL from the
+        # post-process stream itself -- no host synchronisation between the post-process and the collective
+        self._gather_group = None
+        self._gather_on = False
         # measurement hook (bench.py): {"pre": ([], []), "conv": ([], []), "post": ([], [])} -> HIP event pairs recorded on
         # the streams the kernels are launched on, around the letterbox launch, the conv launches and the post-process
         self.bracket = None
@@ -152,6 +168,16 @@ class YOLO(nn.Module):
         if dtype not in (torch.float16, torch.bfloat16, torch.float32):
             raise ValueError(f"unsupported compute dtype {dtype}")
         self.compute_dtype = dtype
+        return self
+
+    def enable_distributed_gather(self, group=None, force: bool = False) -> "YOLO":
+        """One process per GPU, the image stream sharded across ranks (dist.shard_range): after this call every submitted
+        batch also all-gathers its fixed-shape detection slab (one `all_gather_into_tensor` of (N, 6K+1) fp32, RCCL when the
+        backend is "nccl"), enqueued behind the post-process on its stream; `PendingDetections.gathered()` returns the global
+        slab in rank order.  No-op for world size 1 unless `force` (tests)."""
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self._gather_group, self._gather_on = group, bool(on)
         return self
 
     def fused(self) -> bool:
@@ -267,6 +293,16 @@ class YOLO(nn.Module):
                 e.plan.run(e.n_conv_ops, -1, stream=side)
         with torch.cuda.stream(side):
             e.result_host.copy_(torch.cat([e.post.status, e.post.count]), non_blocking=True)
+            if self._gather_on:   # the collective waits for the post-process on `side`, and `side` then waits for it (no host sync)
+                import torch.distributed as dist
+
+                from .. import dist as ydist
+                packed = ydist.pack_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count)
+                world = dist.get_world_size(self._gather_group)
+                if getattr(e, "gathered", None) is None or e.gathered.shape[0] != world * packed.shape[0]:
+                    e.gathered = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
+                work = dist.all_gather_into_tensor(e.gathered, packed, group=self._gather_group, async_op=True)
+                work.wait()
         e.done = torch.cuda.Event()
         e.done.record(side)
         if self.pipeline_depth <= 1:
