@@ -313,6 +313,7 @@ def main():
         return dets
 
     if world > 1:
+        run_steps(1)                       # any candidate-capacity growth (a local re-run, no collective) happens before the gather is on
         yolo.enable_distributed_gather()   # the slab all-gather is enqueued behind each batch's post-process (no host sync before it)
 
     def collect(p):

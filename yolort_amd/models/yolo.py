@@ -61,6 +61,7 @@ class PendingDetections:
         self.event = entry.done
         self._result: Optional[List[Dict[str, Tensor]]] = None
         self._gathered = None
+        self.gather_issued = False   # set by YOLO._submit_entry when this batch's slab all-gather was enqueued
         # planar input images when the stem read them directly (entry.x was never filled): a redo must start from them
         self.planar = planar
 
@@ -80,17 +81,20 @@ class PendingDetections:
         """global detection slab (boxes (G*N,K,4), scores, labels, counts) in rank order; needs YOLO.enable_distributed_gather()"""
         from .. import dist as ydist
         self.result()
-        g = getattr(self.entry, "gathered", None) if self._gathered is None else None
         if self._gathered is None:
-            if g is None:
-                raise YmiError("no distributed gather was enabled for this batch (YOLO.enable_distributed_gather)")
-            self._gathered = ydist.unpack_slab(g.clone(), self.entry.post.k)
+            raise YmiError("no global slab for this batch: enable YOLO.enable_distributed_gather() before submitting it; a batch that "
+                           "was re-run locally (candidate capacity / score-prefix redo) has none either -- all-gather its result() "
+                           "with yolort_amd.dist.gather_detections on every rank instead")
+        if isinstance(self._gathered, Tensor):
+            self._gathered = ydist.unpack_slab(self._gathered, self.entry.post.k)
         return self._gathered
 
     def _collect(self) -> List[Dict[str, Tensor]]:
         e = self.entry
         self.event.synchronize()
         host = e.result_host.tolist()
+        if host[1] == 0 and self.gather_issued:   # detach the global slab too: the instance's buffer is rewritten by its next batch
+            self._gathered = e.gathered.clone()
         if host[1] != 0 and e.outstanding is self:
             e.outstanding = None   # a redo below may recycle this very instance: it must not wait for this handle again
         if host[1] & 2 and not host[1] & 1:   # the score prefix of a crowded image gave < detections_per_img survivors: exact full pass
@@ -179,6 +183,8 @@ class YOLO(nn.Module):
         on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self._gather_group, self._gather_on = group, bool(on)
         return self
+
+    _in_redo = False
 
     def fused(self) -> bool:
         return type(self.head) is YOLOHead and type(self.post_process) is PostProcess and type(self.anchor_generator) is AnchorGenerator and hasattr(self.backbone, "emit")
@@ -293,7 +299,8 @@ class YOLO(nn.Module):
                 e.plan.run(e.n_conv_ops, -1, stream=side)
         with torch.cuda.stream(side):
             e.result_host.copy_(torch.cat([e.post.status, e.post.count]), non_blocking=True)
-            if self._gather_on:   # the collective waits for the post-process on `side`, and `side` then waits for it (no host sync)
+            gather = self._gather_on and not self._in_redo
+            if gather:   # the collective waits for the post-process on `side`, and `side` then waits for it (no host sync)
                 import torch.distributed as dist
 
                 from .. import dist as ydist
@@ -308,6 +315,7 @@ class YOLO(nn.Module):
         if self.pipeline_depth <= 1:
             main.wait_event(e.done)
         pd = PendingDetections(self, e, rescale_rows, planar=planar)
+        pd.gather_issued = gather
         e.outstanding = pd
         return pd
 
@@ -326,6 +334,14 @@ class YOLO(nn.Module):
         x_old = e_old.x
         torch.cuda.synchronize(x_old.base.device)
         e2 = self._entry(x_old.n, x_old.h, x_old.w, x_old.base.device)
+        self._in_redo = True   # a local re-run must not issue a collective the other ranks do not (PendingDetections.gathered raises)
+        try:
+            return self._resubmit_on(e_old, e2, rescale_rows, planar)
+        finally:
+            self._in_redo = False
+
+    def _resubmit_on(self, e_old: _PlanEntry, e2: _PlanEntry, rescale_rows, planar) -> List[Dict[str, Tensor]]:
+        x_old = e_old.x
         with torch.cuda.device(x_old.base.device), torch.cuda.stream(e2.main_stream):
             if planar is not None and e2.plan.stem_planar_ok(planar, (x_old.h, x_old.w)):
                 e2.plan.stem_from_planar(planar)
