@@ -261,17 +261,24 @@ arch = "yolov5_darknet_pan_n_r60"
 m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
 m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
 m = m.to("cuda:0").half().eval()
-m.model.enable_distributed_gather(force=True)
 batches = [[synth_images(1, 128, 160, seed=300 + i)[0].to("cuda:0"), synth_images(1, 160, 120, seed=400 + i)[0].to("cuda:0")] for i in range(4)]
+for b in batches:
+    m(b)   # candidate-capacity growth re-runs a batch locally, without a collective (PendingDetections.gathered raises for it): settle it first
+m.model.enable_distributed_gather(force=True)
 pend = [m.forward_async(b) for b in batches]
-ok = True
+ok, total = True, 0
 for p in pend:
     dets = p.result()
     b, s, l, c = p.gathered()
     for i, d in enumerate(dets):
         k = int(c[i])
-        ok = ok and k == len(d["scores"]) and torch.equal(b[i, :k], d["boxes"]) and torch.equal(s[i, :k], d["scores"]) and torch.equal(l[i, :k], d["labels"])
-    ok = ok and int(c.sum()) > 0
+        checks = (k == len(d["scores"]), torch.equal(b[i, :k], d["boxes"]), torch.equal(s[i, :k], d["scores"]), torch.equal(l[i, :k], d["labels"]))
+        if not all(checks):
+            print("mismatch image", i, "count", k, len(d["scores"]), checks, l.dtype, d["labels"].dtype, s.dtype, d["scores"].dtype)
+        ok = ok and all(checks)
+    total += int(c.sum())
+ok = ok and total > 0
+print("total detections", total)
 print("GATHER_OK" if ok else "GATHER_MISMATCH")
 dist.destroy_process_group()
 """

@@ -6,8 +6,8 @@ Dispatches are matched to plan ops by order within a step (a step starts at the 
 the trace are used, i.e. the serial, one-batch-in-flight phase).  Per conv launch: average kernel duration, TFLOP/s and GB/s
 from the ALGORITHMIC flops / bytes (SURVEY.md 8d accounting), fraction of the layer's own bound
 max(flops / 2.5 PF, bytes / 8 TB/s), and -- when PMC passes are given -- the SQ counters averaged per launch
-(SQ_VALU_MFMA_BUSY_CYCLES etc.; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of
-SIMD-cycles, at the clock the kernel actually ran at, in which the matrix pipe was busy).
+(SQ_VALU_MFMA_BUSY_CYCLES etc.; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs): the fraction of
+SIMD-cycles in which the matrix pipe was busy).
 """
 import argparse
 import json
@@ -90,15 +90,15 @@ def main():
                         pmc[k][cn].append(v)
                     k += 1
     counters = sorted({c for d in pmc.values() for c in d})
-    print("# per-launch table, " + meta["config"] + f", batch {meta['batch']}, mean over {len(steps)} serial steps (one batch in flight); durations from rocprofv3 --kernel-trace")
+    print("# per-launch table, " + meta["config"] + f", batch {meta['batch']}, median over {len(steps)} serial steps (one batch in flight); durations from rocprofv3 --kernel-trace; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (median duration x 2.4 GHz x 1024 SIMDs)")
     import csv
     wr = csv.writer(sys.stdout)
-    wr.writerow(["op", "name", "shape", "tile", "kernel", "avg_us", "tflops", "gbps", "bound_us", "frac_of_own_bound"] + counters + (["mfma_busy_frac"] if counters else []))
+    wr.writerow(["op", "name", "shape", "tile", "kernel", "avg_us", "min_us", "tflops", "gbps", "bound_us", "frac_of_own_bound"] + counters + (["mfma_busy_frac"] if counters else []))
     tot_t = tot_b = 0.0
     for k, o in enumerate(ops):
         if not dur[k]:
             continue
-        t = sum(dur[k]) / len(dur[k])
+        t = sorted(dur[k])[len(dur[k]) // 2]   # median: a shared box shows 2x outliers on single launches
         bound = max(o["flops"] / MFMA_PEAK, o["bytes"] / HBM_PEAK) * 1e6
         tot_t += t
         tot_b += bound
@@ -111,18 +111,19 @@ def main():
             busy = pmc[k].get("SQ_VALU_MFMA_BUSY_CYCLES", [])
             gui = pmc[k].get("GRBM_GUI_ACTIVE", [])
             if busy:
-                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (calibrated on the stem: 2.19 M for a 116 us kernel = 8 x 274 k cycles);
-                # SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs (= 32 x SQ_INSTS_MFMA for 32x32x16 f16)
-                denom = (sum(gui) / len(gui)) / 8 * 1024 if gui else t * 1e-6 * 2.4e9 * 1024
+                # SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs (= 32 x SQ_INSTS_MFMA for 32x32x16 f16).  GRBM_GUI_ACTIVE
+                # (summed over the 8 XCDs) also counts ~15 us of dispatch bracket in counter mode, so it over-states short
+                # kernels: the denominator is the kernel-trace duration at the 2.4 GHz peak clock
+                denom = t * 1e-6 * 2.4e9 * 1024
                 extra = [f"{(sum(busy) / len(busy)) / denom:.3f}"]
             else:
                 extra = [""]
-        wr.writerow([k, o["name"], o.get("shape", ""), o.get("tile", ""), names.get(k, ""), f"{t:.2f}", f"{o['flops'] / t / 1e6:.1f}", f"{o['bytes'] / t / 1e3:.1f}",
+        wr.writerow([k, o["name"], o.get("shape", ""), o.get("tile", ""), names.get(k, ""), f"{t:.2f}", f"{min(dur[k]):.2f}", f"{o['flops'] / t / 1e6:.1f}", f"{o['bytes'] / t / 1e3:.1f}",
                      f"{bound:.2f}", f"{bound / t:.3f}"] + cvals + extra)
     print(f"# conv stack: sum of kernel durations {tot_t:.1f} us per step, sum of per-layer bounds {tot_b:.1f} us -> frac {tot_b / max(tot_t, 1e-9):.3f}")
     print("# other kernels of a step (avg us x launches per step):")
     for n, v in sorted(other.items(), key=lambda kv: -sum(kv[1])):
-        print(f"#   {n}: {sum(v) / len(v):.2f} us x {len(v) / max(len(steps), 1):.1f}")
+        print(f"#   {n}: {sorted(v)[len(v) // 2]:.2f} us x {len(v) / max(len(steps), 1):.1f}")
 
 
 if __name__ == "__main__":

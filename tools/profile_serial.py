@@ -22,8 +22,11 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(bench.CONFIGS))
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--ops", default="")
+    ap.add_argument("--score-thresh", type=float, default=None, help="override the config's threshold (e.g. 0.999: a head without candidates)")
     a = ap.parse_args()
-    c = bench.CONFIGS[a.config]
+    c = dict(bench.CONFIGS[a.config])
+    if a.score_thresh is not None:
+        c["score_thresh"] = a.score_thresh
     dev = torch.device("cuda:0")
     dtype = torch.float16 if c["dtype"] == "fp16" else torch.bfloat16
     kw = dict(size_divisible=64) if c["arch"].endswith("6_r60") else {}

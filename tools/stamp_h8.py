@@ -31,9 +31,12 @@ for case in sys.argv[1:]:
     st = st.reshape(2048, 128).astype(np.int64)
     nsteps = cin // 32 * 3
     b = st[st[:, 0] != 0]
+    b = b[b[:, 127] > b[:, 127].max() - (1 << 21)]   # rows of THIS launch only (the device array keeps older launches' stamps)
     rel = lambda i: (b[:, i] - b[:, 0]).mean()
     t0 = b[:, 0].min()
     print(f"== {case}: {ms*1e3:.1f} us (events), {b.shape[0]} stamped blocks, {nsteps} steps; block entry spread {(b[:,0].max()-t0)} cyc, last exit {(b[:,127].max()-t0)} cyc")
+    ent = np.sort(b[:, 0] - t0)
+    print("   block entry times (cycles), deciles:", " ".join(str(int(ent[int(q * (len(ent) - 1))])) for q in np.linspace(0, 1, 11)))
     print(f"   setup {rel(1):.0f}  mainloop end {rel(3):.0f}  kernel end {rel(127):.0f} cycles since block entry (epilogue {rel(127)-rel(3):.0f})")
     ns = min(nsteps, 40)
     vm = np.array([(b[:, 4 + 3 * s_] - (b[:, 6 + 3 * (s_ - 1)] if s_ else b[:, 1])).mean() for s_ in range(ns)])

@@ -43,6 +43,14 @@ size_t lds_floor_bytes() {
     return v;
 }
 
+bool head_anchor_split() {
+    static const bool v = [] {
+        const char* e = getenv("YOLORT_AMD_HEAD_SPLIT");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
+
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);
 int postprocess_launch(const ymi_post_desc* d, hipStream_t s);
 int post_begin_launch(const ymi_post_desc* d, hipStream_t s);

@@ -33,7 +33,11 @@ int allow_big_lds(const void* kernel_fn, int bytes);
 // Tuning knob (YOLORT_AMD_LDS_FLOOR_KB, default 0): minimum dynamic LDS a conv launch requests.  A floor of 81 KiB caps a
 // kernel at ONE block per CU, so that blocks of OTHER batches' kernels (other streams, other phases) share the CU instead of
 // a second, phase-locked block of the same kernel.
+// (measured r02i, C2 bs 32, 4-6 batches in flight: 19.3-19.5 k img/s at 0, 18.6-19.0 k at 54 KiB, 15.7-15.9 k at 81 KiB: the default stays 0)
 size_t lds_floor_bytes();
+// Fused detection head: split the cout axis by anchor (three blocks per 128-pixel tile, >= 3 waves per SIMD) instead of one
+// 400-register wave per 32 pixels x 3 anchors.  YOLORT_AMD_HEAD_SPLIT=0 selects the unsplit form (A/B runs).
+bool head_anchor_split();
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -34,40 +34,30 @@ struct StreamOut {
 
 template <int DT, bool FRAGS>
 __device__ __forceinline__ void stream_store(const StreamOut& o, const f32x16& acc, int64_t m, bool ok, int cbase, int hi, u32x4* frag_out) {
+    u32x2 rv[4] = {};
+    const bool res = o.res != nullptr;   // wave-uniform
+    if (res && ok) {
+        const uint16_t* rp = o.res + m * o.res_cs + cbase + hi * 4;
 #pragma unroll
-    for (int g = 0; g < 4; g += 2) {
-        uint32_t pk[2][2];
+        for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const u32x2*>(rp + g * 8);
+    }
+    u32x4 pkt[2];   // packed math + hardware pair conversion (conv_common.hpp): lanes < 32 hold channels [g*8, g*8+8), lanes >= 32 [(g+1)*8, ..), g = 0, 2
+    if (o.act == YMI_ACT_SILU) {
+        if (res) silu_pack_subtile<DT, true, true>(acc, rv, pkt);
+        else silu_pack_subtile<DT, false, true>(acc, rv, pkt);
+    } else {
+        if (res) silu_pack_subtile<DT, true, false>(acc, rv, pkt);
+        else silu_pack_subtile<DT, false, false>(acc, rv, pkt);
+    }
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[(g + gg) * 4 + e];
-                if (o.act == YMI_ACT_SILU) t = silu(t);
-                v[e] = t;
-            }
-            if (o.res != nullptr) {   // wave-uniform
-                u32x2 r = {0u, 0u};
-                if (ok) r = *reinterpret_cast<const u32x2*>(o.res + m * o.res_cs + cbase + (g + gg) * 8 + hi * 4);
-                v[0] += from16<DT>((uint16_t)(r[0] & 0xffff));
-                v[1] += from16<DT>((uint16_t)(r[0] >> 16));
-                v[2] += from16<DT>((uint16_t)(r[1] & 0xffff));
-                v[3] += from16<DT>((uint16_t)(r[1] >> 16));
-            }
-            pk[gg][0] = (uint32_t)to16<DT>(v[0]) | ((uint32_t)to16<DT>(v[1]) << 16);
-            pk[gg][1] = (uint32_t)to16<DT>(v[2]) | ((uint32_t)to16<DT>(v[3]) << 16);
-        }
-        // after the swap lanes < 32 hold cols [g*8, g*8+8), lanes >= 32 hold [(g+1)*8, (g+1)*8+8)
-        auto rx = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-        auto ry = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-        u32x4 pkt = {rx[0], ry[0], rx[1], ry[1]};
-        if constexpr (FRAGS) frag_out[g >> 1] = pkt;   // the rounded 16-byte packet IS the activation fragment of the chained 1x1 (k16 step 2*tile + g/2)
+    for (int q = 0; q < 2; ++q) {
+        if constexpr (FRAGS) frag_out[q] = pkt[q];   // the rounded 16-byte packet IS the activation fragment of the chained 1x1 (k16 step 2*tile + q)
         if (ok) {
-            const int co = cbase + (g + hi) * 8;
+            const int co = cbase + (2 * q + hi) * 8;
             uint16_t* yp;
             if (o.split > 0 && co >= o.split) yp = o.y2 + m * o.y2_cs + (co - o.split);
             else yp = o.y + m * o.y_cs + co;
-            *reinterpret_cast<u32x4*>(yp) = pkt;
+            *reinterpret_cast<u32x4*>(yp) = pkt[q];
         }
     }
 }

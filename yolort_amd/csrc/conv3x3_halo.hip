@@ -52,8 +52,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a, 
     const int oy0 = ty * HTH, ox0 = tx * HTW, n0 = bn * BN;
     const int nchunks = a.cin / 32;
     const int nsteps = nchunks * 9;
-    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
-    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
 
     // ---- patch DMA geometry: 12 pieces of 16 pixels, 3 per wave; lane (pixel q, position pos) fetches
     //      k-chunk pos ^ ((q>>2)&3) of input pixel (oy0-1+q/18, ox0-1+q%18), or the zero page ----
@@ -98,7 +96,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a, 
     };
 
     f32x16 acc[TN][TM];
-    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     // issue-side position (chunk, tap) of the next weight step to fetch
     int is_step = 0, is_chunk = 0, is_tap = 0;
@@ -112,6 +109,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a, 
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nsteps) issue_next_w();
+    f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
+    // (after the prologue DMA issue: waiting for the bias load first put two cold memory latencies in series at every block start)
 
     // per-lane fragment geometry
     const int frow = lane & 31;

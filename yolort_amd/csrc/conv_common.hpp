@@ -52,7 +52,7 @@ struct ConvArgs {
     int x_zero_off;    // (zeros - x) in elements: out-of-range activation chunks read x + x_zero_off
     int kh, kw;
     unsigned magic_hw, magic_w;   // ceil(2^32 / (ho*wo)), ceil(2^32 / wo): exact floor-division for m < 2^31 / d ... see fast_div
-    int debug;         // tuning aid: bit0 = skip LDS reads + MFMA, bit1 = skip operand loads (results are garbage)
+    int debug;         // tuning aid: bit0 = skip LDS reads + MFMA, bit1 = skip operand loads, bit2 = head: no decode, bit4 = first K step only (results are garbage)
 };
 
 // SiLU with hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each; the result is rounded to fp16/bf16)
@@ -95,6 +95,10 @@ __device__ __forceinline__ void glds16(const uint16_t* g, uint16_t* lds_wave_uni
 //     serialized L2 round trip each (16 per wave for a 64x64 wave tile: measured ~2x the epilogue's math)
 //   * the residual (Bottleneck shortcut) of a whole wave tile is fetched in one batch before the math
 // ---------------------------------------------------------------------------------------------------
+// The bias loads are issued BEHIND the prologue's LDS-DMA and consumed (init_acc) right before the main loop: issued first,
+// their first use drained the vector-memory counter before any operand DMA had been sent -- every block began with two cold
+// memory latencies in series (bias, then operands; 2.9 k cycles from block entry to the first loop iteration).  (A scalar
+// s_load_dwordx8 form was tried: 16 x TN SGPRs at once spill the scalar file of the TN >= 2 kernels.)
 template <int TN>
 __device__ __forceinline__ void load_bias(const ConvArgs& a, int cbase0, int hi, f32x4 (&b)[TN][4]) {
 #pragma unroll
@@ -219,9 +223,154 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LEAN epilogue (round 2).  The general finish_subtile above carries every case (narrow couts, a split inside a channel
+// octet, the upsampled second output, fp32 output, the chained conv's fragments) behind wave-uniform branches; the code
+// was instantiated 4-5 times per kernel (288 v_exp / 324 global_store / 622 branches in a 128x128-tile kernel of 10.7 k
+// instructions) and ONE 64x64 wave tile took ~5 k cycles of issue -- five times the MFMA time of a K = 128 1x1 layer.
+// This path serves the case every backbone / PAN convolution is in -- 16-bit output, SiLU, full 32-cout sub-tiles, a split
+// on a multiple of 16 channels -- with packed fp32 math (v_pk_mul/add_f32), hardware pair conversion
+// (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round-to-nearest-even like the scalar path) and one 32-bit per-lane offset per
+// pixel group against wave-uniform base pointers.  Same operations in the same order as the general path: bit-identical.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int DT>
+__device__ __forceinline__ uint32_t cvt_pk16(f32x2 v) {
+    uint32_t u;
+    if constexpr (DT == YMI_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 h = __builtin_convertvector(v, h2);
+        __builtin_memcpy(&u, &h, 4);
+    } else {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const b2 b = __builtin_convertvector(v, b2);
+        __builtin_memcpy(&u, &b, 4);
+    }
+    return u;
+}
+template <int DT>
+__device__ __forceinline__ f32x2 unpack16(uint32_t u) {
+    f32x2 r = {from16<DT>((uint16_t)(u & 0xffffu)), from16<DT>((uint16_t)(u >> 16))};
+    return r;
+}
+
+// SiLU (+ residual) + rounding + lane swap of one 32x32 sub-tile: o[0] / o[1] are this lane's 16-byte packets of channel
+// octets (0 + hi) and (2 + hi) of the sub-tile (lanes < 32: channels [g*8, g*8+8), lanes >= 32: [(g+1)*8, (g+1)*8+8), g = 0, 2)
+// -- also exactly the activation fragments of v_mfma_f32_32x32x16 for a chained 1x1 convolution
+template <int DT, bool RES, bool ACT = true>
+__device__ __forceinline__ void silu_pack_subtile(const f32x16& acc, const u32x2 (&rv)[4], u32x4 (&o)[2]) {
+    const f32x2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.0f, 1.0f};
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f32x2 v = {acc[(g + h) * 4 + 2 * p], acc[(g + h) * 4 + 2 * p + 1]};
+                if constexpr (ACT) {
+                    const f32x2 t = v * nl2e;
+                    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    e = e + one;
+                    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                    v = v * r;
+                }
+                if constexpr (RES) v = v + unpack16<DT>(rv[g + h][p]);
+                pk[h][p] = cvt_pk16<DT>(v);
+            }
+        const auto rx = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        const u32x4 q = {rx[0], ry[0], rx[1], ry[1]};
+        o[g >> 1] = q;
+    }
+}
+
+// per-lane byte offsets of one pixel group (tensors below 4 GiB: checked by the callers)
+struct LeanPix {
+    unsigned mo, yo, y2o, ro;   // pixel index (0 when !ok) and its byte offsets in y / y2 / res (+ this lane half's 8- / 4-channel step)
+    bool ok;
+};
+template <class PixFn>
+__device__ __forceinline__ LeanPix lean_pix(const ConvArgs& a, int j, int hi, PixFn&& pix) {
+    int64_t m;
+    LeanPix p;
+    pix(j, m, p.ok);
+    const unsigned mo = p.ok ? (unsigned)m : 0u;
+    p.mo = mo;
+    p.yo = (mo * (unsigned)a.y_cs + 8u * (unsigned)hi) * 2u;
+    p.y2o = (mo * (unsigned)a.y2_cs + 8u * (unsigned)hi) * 2u;
+    p.ro = (mo * (unsigned)a.res_cs + 4u * (unsigned)hi) * 2u;
+    if (a.up2) {   // wave-uniform: y2 is the (n, 2ho, 2wo) view; pixel (img, oy, ox) -> top-left of its 2x2 block
+        const int hw = a.ho * a.wo;
+        const int img = fast_div((int)mo, hw, a.magic_hw);
+        const int rem = (int)mo - img * hw;
+        const int oy = fast_div(rem, a.wo, a.magic_w), ox = rem - oy * a.wo;
+        const unsigned m_up = ((unsigned)(img * 2 * a.ho + 2 * oy) * (unsigned)(2 * a.wo) + 2u * (unsigned)ox);
+        p.y2o = (m_up * (unsigned)a.y2_cs + 8u * (unsigned)hi) * 2u;
+    }
+    return p;
+}
+template <int TN>
+__device__ __forceinline__ void lean_load_residual(const ConvArgs& a, int cbase0, const LeanPix& p, u32x2 (&rv)[TN][4]) {
+    const char* const rb = reinterpret_cast<const char*>(a.res + cbase0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rv[i][g] = *reinterpret_cast<const u32x2*>(rb + (size_t)p.ro + (i * 32 + g * 8) * 2);
+}
+// stores the two packets of sub-tile `cb` (first channel, wave-uniform, a multiple of 32) of one pixel group
+__device__ __forceinline__ void lean_store(const ConvArgs& a, const LeanPix& p, int cb, const u32x4 (&o)[2]) {
+    if (!p.ok) return;
+    char* const yb = reinterpret_cast<char*>(a.y);
+    char* const y2b = reinterpret_cast<char*>(a.y2);
+    const unsigned up_px = (unsigned)a.y2_cs * 2u, up_row = (unsigned)(2 * a.wo) * (unsigned)a.y2_cs * 2u;   // byte steps of the upsampled view
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int co = cb + q * 16;   // a multiple of 16: the 16 channels of a packet pair are on one side of the split
+        if (a.split > 0 && co >= a.split) *reinterpret_cast<u32x4*>(y2b + (size_t)(co - a.split) * 2 + (size_t)p.y2o) = o[q];
+        else *reinterpret_cast<u32x4*>(yb + (size_t)co * 2 + (size_t)p.yo) = o[q];
+        if (a.up2) {   // the same 8 channels to the 2x2 pixels of the upsampled view
+            char* up = y2b + (size_t)co * 2 + (size_t)p.y2o;
+            *reinterpret_cast<u32x4*>(up) = o[q];
+            *reinterpret_cast<u32x4*>(up + up_px) = o[q];
+            *reinterpret_cast<u32x4*>(up + up_row) = o[q];
+            *reinterpret_cast<u32x4*>(up + up_row + up_px) = o[q];
+        }
+    }
+}
+
+template <int DT, int TN, int TM, bool RES, class PixFn>
+__device__ __forceinline__ void finish_wave_tile_lean(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int hi, PixFn&& pix) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const LeanPix p = lean_pix(a, j, hi, pix);
+        u32x2 rv[TN][4] = {};
+        if constexpr (RES) lean_load_residual<TN>(a, cbase0, p, rv);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            u32x4 o[2];
+            silu_pack_subtile<DT, RES>(acc[i][j], rv[i], o);
+            lean_store(a, p, cbase0 + i * 32, o);
+        }
+    }
+}
+
+// wave-uniform preconditions of the lean path; 32-bit byte offsets need every addressed tensor below 4 GiB
+__device__ __forceinline__ bool lean_ok(const ConvArgs& a, int cbase0, int tn) {
+    const int64_t cs_max = a.y_cs > a.y2_cs ? (a.y_cs > a.res_cs ? a.y_cs : a.res_cs) : (a.y2_cs > a.res_cs ? a.y2_cs : a.res_cs);
+    return a.act == YMI_ACT_SILU && cbase0 + 32 * tn <= a.cout && (a.split & 15) == 0 && ((int64_t)a.M + 1) * cs_max * (a.up2 ? 4 : 1) < ((int64_t)1 << 31);
+}
+
 // whole wave tile: TM pixel groups x TN cout groups.  pix(j, m, m_ok) yields the output pixel index of this lane in group j.
 template <int DT, int ODT, int TN, int TM, class PixFn>
 __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int hi, PixFn&& pix) {
+    if constexpr (ODT == DT) {
+        if (lean_ok(a, cbase0, TN)) {
+            if (a.res != nullptr) finish_wave_tile_lean<DT, TN, TM, true>(a, acc, cbase0, hi, pix);
+            else finish_wave_tile_lean<DT, TN, TM, false>(a, acc, cbase0, hi, pix);
+            return;
+        }
+    }
     int64_t m[TM], m_up[TM];
     bool m_ok[TM];
 #pragma unroll
@@ -267,6 +416,52 @@ template <int DT, int TN, int TM, class PixFn>
 __device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int hi, int lane, PixFn&& pix) {
     typedef typename Mfma<DT>::frag frag;
     constexpr int S2MAX = 8;   // second-source k16 steps (chain_k2 <= 128)
+    // lean form (the case every chained launch of the YOLOv5 graphs is in): one K source, no shortcut on the producer
+    if (a.res == nullptr && a.chain_x2 == nullptr && !a.up2 && lean_ok(a, 0, TN) && ((int64_t)a.M + 1) * a.chain_y_cs < ((int64_t)1 << 31)) {
+        ConvArgs a2 = a;   // output side of the chained conv
+        a2.y = a.chain_y; a2.y_cs = a.chain_y_cs; a2.split = 0; a2.up2 = 0;
+        const int tn2 = a.chain_cout >> 5;   // 1..4 (wave-uniform)
+        const u32x2 none[4] = {};
+        LeanPix px[TM];
+        u32x4 fr[TM][TN][2];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            px[j] = lean_pix(a, j, hi, pix);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                silu_pack_subtile<DT, false>(acc[i][j], none, fr[j][i]);
+                lean_store(a, px[j], i * 32, fr[j][i]);
+            }
+            px[j].yo = (px[j].mo * (unsigned)a.chain_y_cs + 8u * (unsigned)hi) * 2u;   // the same pixel in chain_y (used with a2 below)
+        }
+        for (int i2 = 0; i2 < tn2; ++i2) {
+            frag wf[2 * TN];
+            const uint16_t* wr = a.chain_w + (int64_t)(i2 * 32 + (lane & 31)) * a.chain_k + 8 * hi;
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * TN; ++s2) wf[s2] = *reinterpret_cast<const frag*>(wr + 16 * s2);
+            f32x4 b2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b2[g] = *reinterpret_cast<const f32x4*>(a.chain_bias + i2 * 32 + g * 8 + hi * 4);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                f32x16 acc2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[g * 4 + e] = b2[g][e];
+#pragma unroll
+                for (int s2 = 0; s2 < 2 * TN; ++s2) {
+                    frag xf;
+                    __builtin_memcpy(&xf, &fr[j][s2 >> 1][s2 & 1], 16);
+                    acc2 = Mfma<DT>::run(wf[s2], xf, acc2);
+                }
+                u32x4 o[2];
+                silu_pack_subtile<DT, false>(acc2, none, o);
+                lean_store(a2, px[j], i2 * 32, o);
+            }
+        }
+        return;
+    }
     int64_t m[TM];
     bool m_ok[TM];
     u32x4 fr[TM][TN][2];

@@ -54,9 +54,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     constexpr int WSTAGE_HALFS = 3 * BN * 32;
     typedef typename Mfma<DT>::frag frag;
 
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1][weight stage 0][weight stage 1]
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1 (cin > 32)][weight stage 0][weight stage 1]
     const int patch_halfs = g.ppieces * 512;
-    uint16_t* wring = smem + 2 * patch_halfs;
+    uint16_t* wring = smem + (a.cin > 32 ? 2 : 1) * patch_halfs;   // a single 32-channel chunk needs no second patch buffer (more blocks per CU)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,8 +75,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     const int nchunks = a.cin / 32;
     const int nsteps = nchunks * 3;                  // one step = one kernel row (3 taps) of one 32-channel chunk
     H8_STAMP(0);
-    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
-    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
 
     // ---- patch DMA geometry: piece pi = 16 patch pixels; wave w owns pieces w, w+8, w+16 (clamped: surplus slots re-send
     //      the last piece, identical bytes).  Lane (pixel q, position pos) fetches k-chunk pos ^ ((q>>2)&3) of input pixel
@@ -121,11 +119,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     };
 
     f32x16 acc[TN][TM];
-    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     // prologue: the whole first patch (3 pieces per wave) and weight stage 0
     static_for<0, 3>([&](auto jt) { issue_patch_piece(0, jt); });
     static_for<0, PW>([&](auto jt) { issue_w_piece(0, 0, jt); });
+    f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
+    // (after the prologue DMA issue: waiting for the bias load first put two cold memory latencies in series at every block start)
 
     // ---- per-lane fragment geometry ----
     const int frow = lane & 31;
@@ -252,7 +253,7 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     g.magic_pw = magic(g.pw);
     a.nblk_m = a.n * g.tiles_x * g.tiles_y;
     a.nblk_n = cdiv(a.cout_pad, BN);
-    size_t lds = (size_t)2 * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
+    size_t lds = (size_t)(a.cin > 32 ? 2 : 1) * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
     auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }

@@ -211,7 +211,8 @@ static int head_decode_prepare(const ymi_conv_desc* d, const ymi_post_desc* post
     YMI_REQUIRE(post->ws_bytes >= w.total, "ymi_conv_head_decode: workspace too small");
     { const int rc_args = fill_conv_args(d, a); if (rc_args != YMI_OK) return rc_args; }
     a.nblk_m = cdiv(a.M, 128);
-    a.nblk_n = 1;
+    a.nblk_n = head_anchor_split() ? 3 : 1;
+    { static const int dbg = [] { const char* e = getenv("YOLORT_AMD_HEAD_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }   // tuning aid (results are garbage when set)
     h.stride = post->stride[level];
     for (int k = 0; k < 6; ++k) h.anc[k] = post->anchors[level][k];
     h.K = K;
@@ -262,7 +263,7 @@ int conv_head_decode_group_launch(const ymi_conv_desc* descs, int n_levels, cons
     // coarse levels first: they have the longest K loops and the fewest blocks, so they should not form the tail
     for (int l = n_levels - 1; l >= 0; --l) {
         g.first_block[l] = blocks;
-        blocks += g.a[l].nblk_m;
+        blocks += g.a[l].nblk_m * g.a[l].nblk_n;
     }
     g.first_block[n_levels] = blocks;
     if (blocks == 0) return YMI_OK;

@@ -44,8 +44,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
     const int m0 = bm * BM, n0 = bn * BN;
     const int nk32 = a.k_pad / 32;                     // k32 sub-stages in total
     const int nsteps = (nk32 + 1) / 2;
-    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
-    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
 
     // ---- per-lane DMA geometry (as conv_igemm_v2_body, UTAP form) ----
     const int sub_row = lane >> 2;
@@ -119,7 +117,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
     constexpr int PS = PA + PWS;   // pieces per wave per sub-stage
 
     f32x16 acc[TN][TM];
-    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     // prologue: stage 0 (both sub-stages, or one when K = 32)
     static_for<0, PS>([&](auto pt) { issue_piece(smem, pt); });
@@ -128,6 +125,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
         static_for<0, PS>([&](auto pt) { issue_piece(smem + SUB_HALFS, pt); });
         advance_sub();
     }
+    f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
+    // (after the prologue DMA issue: waiting for the bias load first put two cold memory latencies in series at every block start)
 
     const int frow = lane & 31;
     const int swz = (lane >> 2) & 3;

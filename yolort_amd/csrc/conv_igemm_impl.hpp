@@ -256,9 +256,7 @@ __device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi,
     const int lb = xcd_remap(block_id, nblk);
     const int bm = lb / a.nblk_n, bn = lb % a.nblk_n;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int nsteps = a.k_pad / BK;
-    f32x4 bias_regs[TN][4];   // issued first: the latency hides behind the geometry math below
-    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+    const int nsteps = (a.debug & 16) ? 1 : a.k_pad / BK;   // bit 4 (tuning aid): first K step only
 
     if constexpr (!IS1X1 && !UTAP) {
         for (int i = tid; i < a.k_pad / 8; i += 256) ktab_lds[i] = a.ktab[i];
@@ -282,6 +280,11 @@ __device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi,
         const int m = m0 + pi * 16 + sub_row;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
+        if constexpr (IS1X1) {   // kh = kw = 1, stride 1, pad 0: the conv reads pixel m itself (no index arithmetic)
+            a_off[j] = mm * a.x_cs;
+            a_aux[j] = ok ? 0 : -1;   // only the sign is read on this path
+            continue;
+        }
         const int hw_o = a.ho * a.wo;
         const int img = fast_div(mm, hw_o, a.magic_hw);
         const int rem = mm - img * hw_o;
@@ -378,7 +381,6 @@ __device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi,
     };
 
     f32x16 acc[TN][TM];
-    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     if constexpr (!IS1X1 && !UTAP) __syncthreads();   // ktab visible (no DMA in flight yet: plain barrier is fine)
     const int frow = lane & 31;
@@ -393,6 +395,10 @@ __device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi,
         static_for<0, STAGES>([&](auto st) {
             if (decltype(st)::value < nsteps) issue(decltype(st)::value);
         });
+        f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
+        load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+        init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
+        // (after the prologue DMA issue: waiting for the bias load first put two cold memory latencies in series at every block start)
         auto wait_pending = [&](int pend) {   // returns once at most `pend` later stages of this wave are in flight
             if (pend >= 3) wait_vmcnt<3 * P>();
             else if (pend == 2) wait_vmcnt<2 * P>();
@@ -465,6 +471,9 @@ __device__ __forceinline__ void conv_igemm_v2_body(const ConvArgs& a, Epi&& epi,
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nsteps && !(a.debug & 2)) issue(s);
+    f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
+    load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+    init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
 
     for (int step = 0; step < nsteps; ++step) {
         // this wave's pieces of stage `step` have landed once at most `ahead` later stages are pending
@@ -525,24 +534,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs a)
 }
 
 // ---- detection head with the decode fused into the epilogue (head_decode.hpp): 128 pixels x (3 anchors x 32*TNA rows) ----
-constexpr int HD_STAGES = 3;   // operand ring depth of the head kernel (its LDS footprint is set by the decode buffers anyway)
+// operand ring depth of the head kernel.  NA = 3: the LDS footprint is set by the decode buffers anyway; NA = 1: two stages
+// (28 KiB, the size of the decode buffers) leave room for five blocks per CU, which hide more latency than a third stage
+template <int NA> constexpr int hd_stages() { return NA == 3 ? 3 : 2; }
 
-template <int TNA>
+template <int TNA, int NA>
 struct DecodeEpilogue {
     const ConvArgs& a;
     const HeadDecodeArgs& h;
-    __device__ __forceinline__ void operator()(const f32x16 (&acc)[3 * TNA][1], int mbase, int, int lane, int wave, uint16_t* smem) const {
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[NA * TNA][1], int mbase, int cbase0, int lane, int wave, uint16_t* smem) const {
+        constexpr int HD_BUF = HdCfg<NA>::BUF, HD_WL = HdCfg<NA>::WL;
+        if (a.debug & 4) return;   // tuning aid: convolution only
         __syncthreads();   // every wave is done with the operand ring: it becomes the record buffers
         uint64_t* bhi = reinterpret_cast<uint64_t*>(smem) + wave * HD_BUF;
         uint32_t* blo = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + 4 * HD_BUF) + wave * HD_BUF;
         u32x4* wl = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(smem) + 4 * HD_BUF * 12) + wave * HD_WL;
-        head_decode_wave<TNA>(a, h, acc, mbase + (lane & 31), lane, bhi, blo, wl);
+        head_decode_wave<TNA, NA>(a, h, acc, mbase + (lane & 31), lane, bhi, blo, wl, NA == 3 ? 0 : cbase0 / (32 * TNA));
     }
 };
 
-template <int DT, int TNA>
-__global__ __launch_bounds__(256) void conv_head_decode_kernel(const ConvArgs a, const HeadDecodeArgs h) {
-    conv_igemm_v2_body<DT, YMI_F32, 128, 96 * TNA, 32, 96 * TNA, HD_STAGES, false, true, true>(a, DecodeEpilogue<TNA>{a, h}, blockIdx.x);
+// NA = 3: one wave per SIMD (400 registers); NA = 1: three blocks per pixel tile, >= 3 waves per SIMD
+template <int DT, int TNA, int NA>
+__global__ __launch_bounds__(256, NA == 3 ? 1 : 3) void conv_head_decode_kernel(const ConvArgs a, const HeadDecodeArgs h) {
+    conv_igemm_v2_body<DT, YMI_F32, 128, 32 * TNA * NA, 32, 32 * TNA * NA, hd_stages<NA>(), true, false, true>(a, DecodeEpilogue<TNA, NA>{a, h}, blockIdx.x);
 }
 
 // every pyramid level's head in ONE launch: the levels are independent and the coarse ones have few blocks (100 for a
@@ -554,21 +568,22 @@ struct HeadGroupArgs {
     int n;
 };
 
-template <int DT, int TNA>
-__global__ __launch_bounds__(256) void conv_head_decode_group_kernel(const HeadGroupArgs g) {
-    // constant indices only: a runtime index into the by-value argument block would copy it to scratch
-    ConvArgs a = g.a[0];
-    HeadDecodeArgs h = g.h[0];
-    int first = g.first_block[0];
+template <int DT, int TNA, int NA>
+__global__ __launch_bounds__(256, NA == 3 ? 1 : 3) void conv_head_decode_group_kernel(const HeadGroupArgs g) {
+    // The level is a wave-uniform index into the argument block.  Indexing the by-value parameter copies the block to
+    // scratch, and copying the selected level's structs with selects cost ~250 SALU per wave; reading the block through the
+    // kernarg segment pointer (constant address space; the block is the kernel's only parameter, offset 0) makes every field
+    // read one scalar load at a dynamic offset.
+    int l = 0;
     static_for<1, YMI_MAX_LEVELS>([&](auto lt) {
-        constexpr int l = decltype(lt)::value;
-        if (l < g.n && (int)blockIdx.x >= g.first_block[l] && (int)blockIdx.x < g.first_block[l] + g.a[l].nblk_m) {   // wave-uniform
-            a = g.a[l];
-            h = g.h[l];
-            first = g.first_block[l];
-        }
+        constexpr int lv = decltype(lt)::value;
+        if (lv < g.n && (int)blockIdx.x >= g.first_block[lv] && (int)blockIdx.x < g.first_block[lv] + g.a[lv].nblk_m * g.a[lv].nblk_n) l = lv;
     });
-    conv_igemm_v2_body<DT, YMI_F32, 128, 96 * TNA, 32, 96 * TNA, HD_STAGES, false, true, true>(a, DecodeEpilogue<TNA>{a, h}, (int)blockIdx.x - first);
+    const HeadGroupArgs* gp = (const HeadGroupArgs*)(const __attribute__((address_space(4))) HeadGroupArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const ConvArgs& a = gp->a[l];
+    const HeadDecodeArgs& h = gp->h[l];
+    const int first = gp->first_block[l];
+    conv_igemm_v2_body<DT, YMI_F32, 128, 32 * TNA * NA, 32, 32 * TNA * NA, hd_stages<NA>(), true, false, true>(a, DecodeEpilogue<TNA, NA>{a, h}, (int)blockIdx.x - first);
 }
 
 template <typename K>
@@ -684,16 +699,25 @@ int launch_tile_group(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) {
 
 inline int tile_group_of(int tile) { return (tile <= 5 || (tile >= 11 && tile <= 15)) ? 0 : (tile >= 21 && tile <= 27) ? 1 : (tile >= 61 && tile <= 70) ? 2 : 3; }
 
+template <int NA>
 inline size_t head_decode_lds(int tna) {
-    size_t lds = (size_t)HD_STAGES * (128 + 96 * tna) * 64 + 16;
-    const size_t need = (size_t)HD_LDS_BYTES + 16;   // the ring doubles as the per-wave record buffers and worklists
+    size_t lds = (size_t)hd_stages<NA>() * (128 + 32 * tna * NA) * 64 + 16;
+    const size_t need = (size_t)HdCfg<NA>::LDS_BYTES + 16;   // the ring doubles as the per-wave record buffers and worklists
     return lds < need ? need : lds;
 }
 
+// the launchers take the anchor split from ConvArgs::nblk_n (1: a wave holds all three anchors, 3: one anchor per block)
 template <int DT, int TNA>
 int launch_head_decode(const ConvArgs& a, const HeadDecodeArgs& h, hipStream_t s) {
-    const size_t lds = head_decode_lds(TNA);
-    auto kfn = conv_head_decode_kernel<DT, TNA>;
+    if (a.nblk_n == 3) {
+        const size_t lds = head_decode_lds<1>(TNA);
+        auto kfn = conv_head_decode_kernel<DT, TNA, 1>;
+        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+        hipLaunchKernelGGL(kfn, dim3(a.nblk_m * 3), dim3(256), lds, s, a, h);
+        return check_launch("conv_head_decode_kernel");
+    }
+    const size_t lds = head_decode_lds<3>(TNA);
+    auto kfn = conv_head_decode_kernel<DT, TNA, 3>;
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m), dim3(256), lds, s, a, h);
     return check_launch("conv_head_decode_kernel");
@@ -701,8 +725,15 @@ int launch_head_decode(const ConvArgs& a, const HeadDecodeArgs& h, hipStream_t s
 
 template <int DT, int TNA>
 int launch_head_group(const HeadGroupArgs& g, hipStream_t s) {
-    const size_t lds = head_decode_lds(TNA);
-    auto kfn = conv_head_decode_group_kernel<DT, TNA>;
+    if (g.a[0].nblk_n == 3) {
+        const size_t lds = head_decode_lds<1>(TNA);
+        auto kfn = conv_head_decode_group_kernel<DT, TNA, 1>;
+        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+        hipLaunchKernelGGL(kfn, dim3(g.first_block[g.n]), dim3(256), lds, s, g);
+        return check_launch("conv_head_decode_group_kernel");
+    }
+    const size_t lds = head_decode_lds<3>(TNA);
+    auto kfn = conv_head_decode_group_kernel<DT, TNA, 3>;
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(g.first_block[g.n]), dim3(256), lds, s, g);
     return check_launch("conv_head_decode_group_kernel");

@@ -103,90 +103,126 @@ struct PlanarArgs {
     const uint16_t* img[PL_MAX];
 };
 
+// Persistent form (round 2): the first version gave every 8 x 32 tile its own block, and each block paid the patch DMA
+// latency, a private copy of the weights from L2 (36 KiB per block against a 9.6 KiB patch) and the store acknowledgements
+// of its epilogue in sequence -- 116 us per 32-image batch at 640 x 640 against a 46 us HBM bound.  Now a block keeps the
+// weights in registers and walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the patch of tile i+1 is DMA'd into the
+// other LDS buffer while tile i is computed and stored.
 template <int DT, int ODT, int TN>
 __global__ __launch_bounds__(256, 2) void conv_stem_planar_kernel(const ConvArgs a, const PlanarArgs pl, int tiles_x, int tiles_y) {
     typedef typename Mfma<DT>::frag frag;
-    __shared__ __attribute__((aligned(16))) uint16_t patch[12 * 512];   // [3 planes][20 rows][80 px] = 9600 B used
+    __shared__ __attribute__((aligned(16))) uint16_t patch2[2][12 * 512];   // 2 x [3 planes][20 rows][80 px] (9600 B used of each)
+    __shared__ __attribute__((aligned(16))) uint16_t wl[TN * 9 * 64 * 8];   // weights in fragment order: [(i, s)][lane] x 16 B (registers would hold them across the epilogue: 2 waves / SIMD)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = a.nblk_m;
-    int t = xcd_remap(blockIdx.x, nblk);
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int img = t / tiles_y;
-    const int oy0 = ty * STH, ox0 = tx * STW;
     const int H = a.h, W = 2 * a.w_in;           // image size in pixels (the conv geometry counts super-pixels)
 
-    f32x4 bias_regs[TN][4];
-    load_bias<TN>(a, 0, lane >> 5, bias_regs);
-    // ---- patch: entry e = (plane, row, seg) -> 8 pixels starting at (2*oy0 - 2 + row, 2*ox0 - 8 + 8*seg) ----
-    const uint16_t* base = pl.img[img];
+    // ---- patch DMA: entry e = (plane, row, seg) -> 8 pixels starting at (2*oy0 - 2 + row, 2*ox0 - 8 + 8*seg); the per-lane
+    //      (plane, row, seg) never changes, only the tile origin does ----
+    int e_off[3];        // element offset of the lane's entry relative to the tile origin, or -1 (no entry: zero page)
+    int e_row[3], e_col[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int pi = wave * 3 + j;
-        if (pi * 64 < PL_LANES) {                // wave-uniform
-            const int e = pi * 64 + lane;
-            const int ec = e < PL_LANES ? e : PL_LANES - 1;
-            const int plane = ec / (SPH * (PPW / 8));
-            const int rem = ec - plane * (SPH * (PPW / 8));
-            const int pr = rem / (PPW / 8), seg = rem - pr * (PPW / 8);
-            const int iy = 2 * oy0 - 2 + pr, ix = 2 * ox0 - 8 + 8 * seg;
-            const bool ok = (e < PL_LANES) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);   // W % 8 == 0: a segment is in or out as a whole
-            const uint16_t* src = ok ? base + ((int64_t)plane * H + iy) * W + ix : a.zeros;
-            glds16(src, patch + pi * 512);
-        }
+        const int e = pi * 64 + lane;
+        const int ec = e < PL_LANES ? e : PL_LANES - 1;
+        const int plane = ec / (SPH * (PPW / 8));
+        const int rem = ec - plane * (SPH * (PPW / 8));
+        const int pr = rem / (PPW / 8), seg = rem - pr * (PPW / 8);
+        e_row[j] = pr - 2;
+        e_col[j] = 8 * seg - 8;
+        e_off[j] = e < PL_LANES ? plane : -1;
     }
-    // ---- weights: all 9 k16-steps of this lane's cout row(s) into registers (L2-resident, 16 B loads) ----
-    frag wf[TN][9];
+    auto tile_origin = [&](int idx, int& img, int& oy0, int& ox0) {
+        int t = xcd_remap(idx, nblk);
+        const int tx = t % tiles_x;
+        t /= tiles_x;
+        const int ty = t % tiles_y;
+        img = t / tiles_y;
+        oy0 = ty * STH;
+        ox0 = tx * STW;
+    };
+    auto issue_patch = [&](int idx, uint16_t* dst) {
+        int img, oy0, ox0;
+        tile_origin(idx, img, oy0, ox0);
+        const uint16_t* base = pl.img[img];      // wave-uniform index into the kernel arguments: one scalar load
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int pi = wave * 3 + j;
+            if (pi * 64 < PL_LANES) {            // wave-uniform
+                const int iy = 2 * oy0 + e_row[j], ix = 2 * ox0 + e_col[j];
+                const bool ok = (e_off[j] >= 0) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);   // W % 8 == 0: a segment is in or out as a whole
+                const uint16_t* src = ok ? base + ((int64_t)e_off[j] * H + iy) * W + ix : a.zeros;
+                glds16(src, dst + pi * 512);
+            }
+        }
+    };
+    int idx = blockIdx.x;
+    if (idx < nblk) issue_patch(idx, patch2[0]);
+    // ---- weights: all 9 k16-steps of every cout row into LDS, ONCE per block (wave w copies the steps s = w, w+4, ...) ----
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
         const uint16_t* wr = a.w + (int64_t)(i * 32 + (lane & 31)) * a.k_pad + 8 * (lane >> 5);
-#pragma unroll
-        for (int s = 0; s < 9; ++s) wf[i][s] = *reinterpret_cast<const frag*>(wr + 16 * s);
+        for (int s = wave; s < 9; s += 4)
+            *reinterpret_cast<frag*>(wl + ((i * 9 + s) * 64 + lane) * 8) = *reinterpret_cast<const frag*>(wr + 16 * s);
     }
-    f32x16 acc[TN][2];
-    init_acc<TN, 2>(acc, bias_regs);   // accumulate on top of the bias
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     // wave w owns output rows 2w, 2w+1 of the tile (two groups of 32 pixels)
     const int hi = lane >> 5, px = lane & 31;
     constexpr int PLANE_HALFS = SPH * PPW;
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        // tap = 2s + hi -> (ky, kx') = (tap / 3, tap % 3): compile-time per half; super-pixel column c = px + kx' sits at
-        // pixels 2*(ox0 - 1 + c) .. +1 = patch pixels 2c + 6, 2c + 7
-        const int tap0 = 2 * s, tap1 = 2 * s + 1;
-        const int o0 = (tap0 / 3) * PPW + 2 * (tap0 % 3), o1 = (tap1 / 3) * PPW + 2 * (tap1 % 3);
-        const int toff = hi ? o1 : o0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 2 * (2 * wave + j);   // patch row of output row (2w + j) at ky = 0
-            const uint16_t* p0 = patch + row * PPW + 2 * px + 6 + toff;
-            const uint32_t r = *reinterpret_cast<const uint32_t*>(p0);
-            const uint32_t g = *reinterpret_cast<const uint32_t*>(p0 + PLANE_HALFS);
-            const uint32_t b = *reinterpret_cast<const uint32_t*>(p0 + 2 * PLANE_HALFS);
-            u32x4 q;
-            q[0] = (r & 0xffffu) | (g << 16);        // R0 G0
-            q[1] = b & 0xffffu;                      // B0 0
-            q[2] = (r >> 16) | (g & 0xffff0000u);    // R1 G1
-            q[3] = b >> 16;                          // B1 0
-            frag af;
-            __builtin_memcpy(&af, &q, 16);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) acc[i][j] = Mfma<DT>::run(wf[i][s], af, acc[i][j]);
-        }
-    }
+    int buf = 0;
+    for (; idx < nblk; idx += gridDim.x) {
+        // this tile's patch (issued one tile ago) has landed, and so have the stores of the previous tile; after the barrier
+        // nobody reads the other buffer any more: it takes the next tile's patch while this one is computed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (idx + (int)gridDim.x < nblk) issue_patch(idx + gridDim.x, patch2[buf ^ 1]);
+        const uint16_t* patch = patch2[buf];
+        int img, oy0, ox0;
+        tile_origin(idx, img, oy0, ox0);
 
-    finish_wave_tile<DT, ODT, TN, 2>(a, acc, 0, hi, [&](int j, int64_t& m, bool& ok) {
-        const int oy = oy0 + 2 * wave + j, ox = ox0 + px;
-        ok = oy < a.ho && ox < a.wo;
-        m = ((int64_t)img * a.ho + oy) * a.wo + ox;
-    });
+        f32x4 bias_regs[TN][4];
+        load_bias<TN>(a, 0, lane >> 5, bias_regs);
+        f32x16 acc[TN][2];
+        init_acc<TN, 2>(acc, bias_regs);   // accumulate on top of the bias
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            frag wf[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(wl + ((i * 9 + s) * 64 + lane) * 8);
+            // tap = 2s + hi -> (ky, kx') = (tap / 3, tap % 3): compile-time per half; super-pixel column c = px + kx' sits at
+            // pixels 2*(ox0 - 1 + c) .. +1 = patch pixels 2c + 6, 2c + 7
+            const int tap0 = 2 * s, tap1 = 2 * s + 1;
+            const int o0 = (tap0 / 3) * PPW + 2 * (tap0 % 3), o1 = (tap1 / 3) * PPW + 2 * (tap1 % 3);
+            const int toff = hi ? o1 : o0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 2 * (2 * wave + j);   // patch row of output row (2w + j) at ky = 0
+                const uint16_t* p0 = patch + row * PPW + 2 * px + 6 + toff;
+                const uint32_t r = *reinterpret_cast<const uint32_t*>(p0);
+                const uint32_t g = *reinterpret_cast<const uint32_t*>(p0 + PLANE_HALFS);
+                const uint32_t b = *reinterpret_cast<const uint32_t*>(p0 + 2 * PLANE_HALFS);
+                u32x4 q;
+                q[0] = (r & 0xffffu) | (g << 16);        // R0 G0
+                q[1] = b & 0xffffu;                      // B0 0
+                q[2] = (r >> 16) | (g & 0xffff0000u);    // R1 G1
+                q[3] = b >> 16;                          // B1 0
+                frag af;
+                __builtin_memcpy(&af, &q, 16);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) acc[i][j] = Mfma<DT>::run(wf[i], af, acc[i][j]);
+            }
+        }
+
+        finish_wave_tile<DT, ODT, TN, 2>(a, acc, 0, hi, [&](int j, int64_t& m, bool& ok) {
+            const int oy = oy0 + 2 * wave + j, ox = ox0 + px;
+            ok = oy < a.ho && ox < a.wo;
+            m = ((int64_t)img * a.ho + oy) * a.wo + ox;
+        });
+        buf ^= 1;
+    }
 }
 
 template <int DT, int ODT>
@@ -203,9 +239,17 @@ static int stem_planar_launch_t(const ConvArgs& a0, const void* const* imgs, hip
         a.nblk_m = a.n * tiles_x * tiles_y;
         a.nblk_n = 1;
         a.M = a.n * a.ho * a.wo;
-        dim3 grid(a.nblk_m), block(256);
-        if (a.cout_pad <= 32) hipLaunchKernelGGL((conv_stem_planar_kernel<DT, ODT, 1>), grid, block, 0, s, a, pl, tiles_x, tiles_y);
-        else hipLaunchKernelGGL((conv_stem_planar_kernel<DT, ODT, 2>), grid, block, 0, s, a, pl, tiles_x, tiles_y);
+        // persistent blocks: as many as are resident at once (registers: 3 per CU at cout <= 32, 2 above); 256 CUs, a multiple
+        // of 8 so that a block stays on one XCD's tile range
+        auto launch = [&](auto kfn) {
+            static int per_cu = 0;
+            if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 0) != hipSuccess || per_cu < 1)) per_cu = 2;
+            const int resident = per_cu * 256;
+            dim3 grid(a.nblk_m < resident ? a.nblk_m : resident), block(256);
+            hipLaunchKernelGGL(kfn, grid, block, 0, s, a, pl, tiles_x, tiles_y);
+        };
+        if (a.cout_pad <= 32) launch(conv_stem_planar_kernel<DT, ODT, 1>);
+        else launch(conv_stem_planar_kernel<DT, ODT, 2>);
     }
     return check_launch("conv_stem_planar_kernel");
 }

@@ -21,9 +21,16 @@
 
 namespace ymi {
 
-constexpr int HD_BUF = 1024;   // records per wave buffer (12 KiB); one append adds at most 64
-constexpr int HD_WL = 512;     // worklist entries per wave (8 KiB): pre-filter survivors waiting for their exact score
-constexpr int HD_LDS_BYTES = 4 * (HD_BUF * 12 + HD_WL * 16);   // per block (4 waves); overlays the dead operand ring
+// NA = anchors per wave.  NA = 3: the original form, one wave holds all 3 x RA logits of its 32 pixels (9 x 16 accumulator
+// registers at K = 85 -> 400 VGPR + AGPR, ONE wave per SIMD: nothing hides the operand DMA, the MFMA chain and the decode
+// of a wave behind another's -- 97 us per 32-image batch, 7x its HBM bound).  NA = 1: the cout axis is split by anchor
+// (three blocks per pixel tile, each wave 32 pixels x RA rows, 48 accumulator registers, >= 3 waves per SIMD); the x tile
+// is fetched by three neighbouring blocks (L2 hits), the weights by a third as many pixels each.
+template <int NA> struct HdCfg {
+    static constexpr int BUF = NA == 3 ? 1024 : 256;   // records per wave buffer (12 B each); one append adds at most 64
+    static constexpr int WL = NA == 3 ? 512 : 256;     // worklist entries per wave (16 B each): pre-filter survivors waiting for their exact score
+    static constexpr int LDS_BYTES = 4 * (BUF * 12 + WL * 16);   // per block (4 waves); overlays the dead operand ring
+};
 
 struct HeadDecodeArgs {
     float stride;
@@ -33,11 +40,12 @@ struct HeadDecodeArgs {
     CandSink sink;
 };
 
-// acc[3*TNA][1]: sub-tile s of anchor q is acc[q*TNA + s][0]; register g*4+e of lane (px, hi) is channel
-// c = s*32 + g*8 + hi*4 + e of that anchor (c < K real, else zero padding)
-template <int TNA>
-__device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDecodeArgs& h, const f32x16 (&acc)[3 * TNA][1], int m, int lane,
-                                                 uint64_t* bhi, uint32_t* blo, u32x4* wl) {
+// acc[NA*TNA][1]: sub-tile s of the wave's anchor qi is acc[qi*TNA + s][0] (anchor q = q_base + qi; q_base is wave-uniform,
+// 0 when NA = 3); register g*4+e of lane (px, hi) is channel c = s*32 + g*8 + hi*4 + e of that anchor (c < K real, else padding)
+template <int TNA, int NA>
+__device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDecodeArgs& h, const f32x16 (&acc)[NA * TNA][1], int m, int lane,
+                                                 uint64_t* bhi, uint32_t* blo, u32x4* wl, int q_base) {
+    constexpr int HD_BUF = HdCfg<NA>::BUF, HD_WL = HdCfg<NA>::WL;
     const CandSink& k_ = h.sink;
     const int hi = lane >> 5;
     const bool m_ok = m < a.M;
@@ -108,16 +116,20 @@ __device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDe
     };
 
     // compile-time indices everywhere: the accumulators must stay in registers (a runtime index sends them to scratch)
-    static_for<0, 3>([&](auto qt) {
-        constexpr int q = decltype(qt)::value;
+    static_for<0, NA>([&](auto qt) {
+        constexpr int qi = decltype(qt)::value;
+        constexpr int q = qi;                 // accumulator sub-array of this anchor
+        const int qa = q_base + qi;           // anchor index within the level (wave-uniform)
+        const float anc_w = qa == 0 ? h.anc[0] : (qa == 1 ? h.anc[2] : h.anc[4]);   // selects, not a runtime index: the by-value args stay in SGPRs
+        const float anc_h = qa == 0 ? h.anc[1] : (qa == 1 ? h.anc[3] : h.anc[5]);
         // channels 0..3 (box) live on the hi = 0 lane, 4..7 (objectness, first classes) on the hi = 1 lane
         const float t0 = acc[q * TNA][0][0], t1 = acc[q * TNA][0][1], t2 = acc[q * TNA][0][2], t3 = acc[q * TNA][0][3];
         const float u0 = __shfl_xor(t0, 32, 64), u1 = __shfl_xor(t1, 32, 64), u2 = __shfl_xor(t2, 32, 64), u3 = __shfl_xor(t3, 32, 64);
         const float lx = hi ? u0 : t0, ly = hi ? u1 : t1, lw = hi ? u2 : t2, lh = hi ? u3 : t3;
         const float lobj = hi ? t0 : u0;
-        const int anchor = h.level_off + (q * a.ho + y) * a.wo + x;
+        const int anchor = h.level_off + (qa * a.ho + y) * a.wo + x;
         if (hi == 0 && m_ok) {
-            const f32x4 b = decode_box(lx, ly, lw, lh, x, y, h.stride, h.anc[2 * q], h.anc[2 * q + 1]);
+            const f32x4 b = decode_box(lx, ly, lw, lh, x, y, h.stride, anc_w, anc_h);
             *reinterpret_cast<f32x4*>(k_.boxes_all + ((int64_t)img * k_.total_anchors + anchor) * 4) = b;
         }
         const float o = sigmoid_acc(lobj);

@@ -292,8 +292,12 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, int np2) {
     // Compare-exchange steps with distance j < chunk stay inside one wave's contiguous chunk of the array, so they need
     // no block-wide barrier (the wave's own LDS accesses are ordered): with 16 waves on 4096 keys that is 68 of the 78
     // steps -- the sort was barrier-latency bound (~1.5 us per __syncthreads of 16 waves), not work bound.
+    // Small arrays (the common case: ~1000 candidates per image at score_thresh 0.25) keep 128-key chunks on the first
+    // np2 / 128 waves and leave the others idle: with 16 x 64-key chunks every one of the 55 steps of a 1024-key sort was a
+    // 1024-thread barrier (197 us for two sorts); 8 x 128 leaves 6 block-level steps.
     const int nwaves = blockDim.x >> 6;
-    const int chunk = np2 / nwaves >= 128 ? np2 / nwaves : 0;   // keys per wave (power of two); tiny arrays: block steps only
+    const int min_chunk = np2 < 128 ? np2 : 128;
+    const int chunk = np2 / nwaves >= min_chunk ? np2 / nwaves : min_chunk;   // keys per wave (power of two)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int k = 2; k <= np2; k <<= 1) {
         int j = k >> 1;
@@ -311,7 +315,8 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, int np2) {
         if (j > 0) {                              // the remaining distances: this wave sorts within its own chunk
             uint64_t* mine = key + wave * chunk;
             const int base = wave * chunk;
-            for (; j > 0; j >>= 1) {
+            const bool active = base < np2;       // waves past the array idle (wave-uniform)
+            for (; active && j > 0; j >>= 1) {
                 for (int t = lane; t < chunk; t += 64) {
                     const int txj = t ^ j;
                     if (txj > t) {
@@ -380,6 +385,7 @@ __device__ void sort_runs(uint64_t* keys, int n, uint64_t* lds_key, int lds_keys
 // front of the image's region and flags the image as truncated; gather_topk_kernel raises YMI_STATUS_PREFIX_SHORT
 // if such an image ends with fewer than K survivors (the host then re-runs with YMI_POST_EXACT_FULL).
 constexpr int SEL_BINS = 4096;
+constexpr int RANK_MAX = 6144;   // images with at most this many records (after the prefix selection) are sorted by multi-block ranking
 
 __device__ __forceinline__ int score_bin(uint64_t hi) {
     const float s = __uint_as_float(~(uint32_t)hi);
@@ -388,12 +394,16 @@ __device__ __forceinline__ int score_bin(uint64_t hi) {
 }
 
 __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, int cap_img, int n_img, int sel_t,
-                                                             int* sel_count) {
+                                                             int* sel_count, uint32_t* rank_g, uint32_t* rank_p) {
     __shared__ int hist[SEL_BINS];
     __shared__ int s_bstar, s_nsel, s_fill;
     const int img = blockIdx.x;
     const int raw = img_count[img];
     const int n_i = raw < cap_img ? raw : cap_img;
+    if (rank_g != nullptr) {   // rank counters of the multi-block ranking sort (rank_image_kernel adds into them)
+        const int nz = n_i < RANK_MAX ? n_i : RANK_MAX;
+        for (int i = threadIdx.x; i < nz; i += blockDim.x) { rank_g[(int64_t)img * cap_img + i] = 0u; rank_p[(int64_t)img * cap_img + i] = 0u; }
+    }
     if (sel_t <= 0 || n_i <= sel_t + sel_t / 2) {
         if (threadIdx.x == 0) { sel_count[img] = n_i; sel_count[n_img + img] = 0; }
         return;
@@ -461,14 +471,100 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
     if (threadIdx.x == 0) { sel_count[img] = nsel; sel_count[n_img + img] = 1; }
 }
 
+// ------------------------------------------------------------------------------------------
+// 2c. multi-block sort by RANKING (images of <= RANK_MAX records -- every image after the score-prefix selection, which
+//     keeps <= 1.5 x 4096).  One 1024-thread block per image made the batch wait for its most crowded image (C2: 32 images,
+//     1 k records on average but 5 k in one of them: 194 us for two bitonic sorts of 8192 keys on ONE CU while 255 idled).
+//     Keys are unique, so the position of a key is the number of keys below it: block (bi, bj, img) counts, for its 256 keys,
+//     the keys of j-slice bj that are smaller -- under BOTH orders at once (G: ~score << 32 | cand; P: label, then G order,
+//     i.e. label << (64-L) | G >> L) -- and adds the counts to the keys' rank counters; scatter_ranks_kernel then writes G and
+//     P directly in place.  n^2 / 64 wave-iterations of two 64-bit compares: 25 M pairs for 5 k records = ~10 us on a few
+//     hundred blocks, and no block-wide barrier in the loop.
+// ------------------------------------------------------------------------------------------
+constexpr int RANK_IT = 256;    // keys ranked per block
+constexpr int RANK_JT = 1024;   // keys of a j-slice (16 KiB of LDS: G and P key of each)
+
+__device__ __forceinline__ uint64_t p_key_of(uint64_t g, int label_bits) {
+    return ((g & ((1ull << label_bits) - 1ull)) << (64 - label_bits)) | (g >> label_bits);
+}
+
+__global__ __launch_bounds__(RANK_IT) void rank_image_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* sel_count, int cap_img, int label_bits,
+                                                             uint32_t* rank_g, uint32_t* rank_p) {
+    __shared__ __attribute__((aligned(16))) uint64_t keys[RANK_JT][2];
+    const int img = blockIdx.z;
+    const int n_i = sel_count[img];
+    const int i0 = blockIdx.x * RANK_IT, j0 = blockIdx.y * RANK_JT;
+    if (n_i > RANK_MAX || i0 >= n_i || j0 >= n_i) return;   // block-uniform
+    const int64_t base = (int64_t)img * cap_img;
+    const int jn = n_i - j0 < RANK_JT ? n_i - j0 : RANK_JT;
+    for (int t = threadIdx.x; t < jn; t += RANK_IT) {
+        const uint64_t g = ((uint64_t)(uint32_t)in_hi[base + j0 + t] << 32) | in_lo[base + j0 + t];   // ~score << 32 | cand
+        keys[t][0] = g;
+        keys[t][1] = p_key_of(g, label_bits);
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    uint64_t gi = 0ull, pi = 0ull;   // threads past the end count nothing
+    if (i < n_i) {
+        gi = ((uint64_t)(uint32_t)in_hi[base + i] << 32) | in_lo[base + i];
+        pi = p_key_of(gi, label_bits);
+    }
+    uint32_t cg = 0u, cp = 0u;
+#pragma unroll 8
+    for (int t = 0; t < jn; ++t) {   // wave-uniform LDS address: one broadcast 16-byte read per key
+        const uint64_t kg = keys[t][0], kp = keys[t][1];
+        cg += kg < gi ? 1u : 0u;
+        cp += kp < pi ? 1u : 0u;
+    }
+    if (i < n_i) {
+        atomicAdd(&rank_g[base + i], cg);
+        atomicAdd(&rank_p[base + i], cp);
+    }
+}
+
+__global__ __launch_bounds__(RANK_IT) void scatter_ranks_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* img_count, const int* sel_count, int cap_img,
+                                                                int label_bits, const uint32_t* rank_g, const uint32_t* rank_p, uint64_t* ghi, uint32_t* glo,
+                                                                uint64_t* phi, uint32_t* plo, uint8_t* keep, int* status) {
+    __shared__ int s_off;
+    const int img = blockIdx.y;
+    const int n_i = sel_count[img];
+    if (n_i > RANK_MAX) return;   // sort_image_kernel's image
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int raw = img_count[img];
+        atomicAdd(&status[ST_NCAND], n_i);
+        if (raw > cap_img) { atomicOr(&status[ST_OVERFLOW], YMI_STATUS_OVERFLOW_CAPACITY); atomicMax(&status[ST_RSV], raw); }
+    }
+    const int i = blockIdx.x * RANK_IT + threadIdx.x;
+    if (blockIdx.x * RANK_IT >= n_i) return;
+    if (threadIdx.x < 64) {   // first wave: offset of this image in the compact arrays = sum of the counts before it
+        int part = 0;
+        for (int j = threadIdx.x; j < img; j += 64) part += sel_count[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (threadIdx.x == 0) s_off = part;
+    }
+    __syncthreads();
+    if (i >= n_i) return;
+    const int off = s_off;
+    const int64_t base = (int64_t)img * cap_img;
+    const uint64_t g = ((uint64_t)(uint32_t)in_hi[base + i] << 32) | in_lo[base + i];
+    const uint32_t r = rank_g[base + i], p = rank_p[base + i];
+    ghi[off + r] = ((uint64_t)(unsigned)img << 32) | (g >> 32);
+    glo[off + r] = (uint32_t)g;
+    keep[off + r] = 0;
+    phi[off + p] = ((uint64_t)(unsigned)img << 16) | (g & ((1ull << label_bits) - 1ull));
+    plo[off + p] = (uint32_t)off + r;
+}
+
 __global__ __launch_bounds__(1024) void sort_image_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, const int* sel_count, int cap_img, int n_img,
-                                                          int label_bits, int lds_keys, uint64_t* ghi, uint32_t* glo, uint64_t* phi, uint32_t* plo,
+                                                          int label_bits, int lds_keys, int rank_max, uint64_t* ghi, uint32_t* glo, uint64_t* phi, uint32_t* plo,
                                                           uint8_t* keep, int* status) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_key[];
     __shared__ int s_off;
     const int img = blockIdx.x;
     const int raw = img_count[img];
     const int n_i = sel_count[img];   // records that take part (== min(raw, cap_img) unless the prefix selection cut the image)
+    if (n_i <= rank_max) return;      // sorted by rank_image_kernel / scatter_ranks_kernel
     if (threadIdx.x < 64) {   // first wave: offset of this image in the compact arrays = sum of the counts before it
         int part = 0;
         for (int j = threadIdx.x; j < img; j += 64) part += sel_count[j];
@@ -868,7 +964,15 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
         const int cap_img = L.cap_img;
         const bool exact_full = (d->flags & YMI_POST_EXACT_FULL) != 0;
         const int sel_t = exact_full ? 0 : (4 * d->detections_per_img > 4096 ? 4 * d->detections_per_img : 4096);
-        hipLaunchKernelGGL(select_prefix_kernel, dim3(d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, sel_t, w.sel_count);
+        // rank counters live in seg_start / kept_box, which are not in use before find_segments
+        uint32_t* rank_g = w.seg_start;
+        uint32_t* rank_p = reinterpret_cast<uint32_t*>(w.kept_box);
+        hipLaunchKernelGGL(select_prefix_kernel, dim3(d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, sel_t, w.sel_count, rank_g, rank_p);
+        const int rank_cap = cap_img < RANK_MAX ? cap_img : RANK_MAX;   // no image holds more than cap_img records
+        hipLaunchKernelGGL(rank_image_kernel, dim3(cdiv(rank_cap, RANK_IT), cdiv(rank_cap, RANK_JT), d->n), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.sel_count, cap_img,
+                           L.label_bits, rank_g, rank_p);
+        hipLaunchKernelGGL(scatter_ranks_kernel, dim3(cdiv(rank_cap, RANK_IT), d->n), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.img_count, w.sel_count, cap_img, L.label_bits,
+                           rank_g, rank_p, w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);
         // LDS run length of the sort: with the prefix selection images rarely exceed 8192 records (longer ones take the
         // multi-run merge path), and 64 KiB instead of 128 leaves room for a convolution block on the same CU
         const int run_max = exact_full ? IMG_SORT_MAX : IMG_SORT_MAX / 2;
@@ -876,8 +980,9 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
         const size_t lds = (size_t)lds_keys * 8;
         if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)sort_image_kernel, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
         // the producers wrote arrays [0] (per-image regions); G goes to arrays [1] (compact), P to its own pair
-        hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, w.sel_count, cap_img, d->n, L.label_bits, lds_keys,
-                           w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);
+        if (cap_img > RANK_MAX)   // only then can an image exceed the ranking path
+            hipLaunchKernelGGL(sort_image_kernel, dim3(d->n), dim3(1024), lds, s, w.hi[0], w.lo[0], w.img_count, w.sel_count, cap_img, d->n, L.label_bits, lds_keys,
+                               RANK_MAX, w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);
         if ((rc = check_launch("select_prefix/sort_image")) != YMI_OK) return rc;
         return nms_gather(w, 1, w.p_hi, w.p_lo, d->status, d->cand_cap, d->n, L.label_bits, L.total_anchors, d->nms_thresh, d->detections_per_img, d->rescale,
                           d->out_boxes, d->out_scores, d->out_labels, d->out_count, s, w.sel_count + d->n);
