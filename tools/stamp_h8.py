@@ -31,7 +31,24 @@ for case in sys.argv[1:]:
     st = st.reshape(2048, 128).astype(np.int64)
     nsteps = cin // 32 * 3
     b = st[st[:, 0] != 0]
-    b = b[b[:, 127] > b[:, 127].max() - (1 << 21)]   # rows of THIS launch only (the device array keeps older launches' stamps)
+    nblk = int(os.environ.get("NBLK", "0")) or b.shape[0]
+    b = st[:nblk]                                      # rows of this launch's blocks (clocks of different XCDs are not comparable: no time filter)
+    hw = b[:, 126]
+    cu_key = ((hw >> 32) & 0xf) * 4096 + ((hw >> 13) & 0x7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 0xf)   # xcc, se, sh, cu
+    per_cu = {}
+    for k, t0_, t1_ in zip(cu_key, b[:, 0], b[:, 127]):
+        per_cu.setdefault(int(k), []).append((int(t0_), int(t1_)))
+    n_over = n_seq = 0
+    for k, iv in per_cu.items():
+        iv.sort()
+        for (a0, a1), (b0, b1) in zip(iv, iv[1:]):
+            if b0 < a1: n_over += 1
+            else: n_seq += 1
+    import collections
+    rt = (b[:, 125] - b[:, 124]).astype(float)
+    ok_rt = rt > 0
+    print(f"   shader clock from s_memtime / s_memrealtime (100 MHz): {((b[ok_rt, 127] - b[ok_rt, 0]) / rt[ok_rt]).mean() * 100:.0f} MHz; block life {rt[ok_rt].mean() / 100:.2f} us; first start -> last end {(b[:, 125].max() - b[:, 124].min()) / 100:.2f} us")
+    print(f"   {len(per_cu)} CUs used; blocks per CU histogram {sorted(collections.Counter(len(v) for v in per_cu.values()).items())}; consecutive block pairs on one CU: {n_over} overlapping, {n_seq} sequential")
     rel = lambda i: (b[:, i] - b[:, 0]).mean()
     t0 = b[:, 0].min()
     print(f"== {case}: {ms*1e3:.1f} us (events), {b.shape[0]} stamped blocks, {nsteps} steps; block entry spread {(b[:,0].max()-t0)} cyc, last exit {(b[:,127].max()-t0)} cyc")

@@ -199,7 +199,7 @@ static int launch_halo(const ConvArgs& a0, hipStream_t s) {
     size_t lds = (size_t)2 * HPIX * 64 + (size_t)STAGES * BN * 64;
     auto kfn = conv3x3_halo_kernel<DT, ODT, BN, WM, WN, STAGES>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
-    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, s, a, tiles_x, tiles_y);
     return check_launch("conv3x3_halo_kernel");
 }

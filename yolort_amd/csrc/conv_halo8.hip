@@ -20,6 +20,8 @@
 // accumulate on top of the folded-BN bias, SiLU (+ residual) epilogue of conv_common.hpp, channel-slice views).
 // Replaces yolort/v5/models/common.py:69-70,115-116 for the Bottleneck.cv2 convolutions (k=3, s=1, p=1, cin % 32 == 0).
 #include "conv_common.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace ymi {
 
@@ -75,6 +77,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     const int nchunks = a.cin / 32;
     const int nsteps = nchunks * 3;                  // one step = one kernel row (3 taps) of one 32-channel chunk
     H8_STAMP(0);
+#ifdef YMI_STAMPS   // slot 126: where the block runs (HW_ID: wave / simd / cu / sh / se; XCC_ID)
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ymi_stamps_h8[blockIdx.x * 128 + 126] = ((unsigned long long)xcc << 32) | hw;
+        ymi_stamps_h8[blockIdx.x * 128 + 124] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz counter: ticks of slot 0 / 127 vs these give the shader clock
+    }
+#endif
 
     // ---- patch DMA geometry: piece pi = 16 patch pixels; wave w owns pieces w, w+8, w+16 (clamped: surplus slots re-send
     //      the last piece, identical bytes).  Lane (pixel q, position pos) fetches k-chunk pos ^ ((q>>2)&3) of input pixel
@@ -217,6 +228,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     };
     finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, pix);
     H8_STAMP(127);
+#ifdef YMI_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 2048) ymi_stamps_h8[blockIdx.x * 128 + 125] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // patch shape for a ho x wo map: th * tw <= 256, (th+2) * (tw+2) <= 24 * 16 patch pixels; maximise the fraction of the 256
@@ -256,7 +270,15 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     size_t lds = (size_t)(a.cin > 32 ? 2 : 1) * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
     auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
-    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
+    if (getenv("YOLORT_AMD_DEBUG_OCC")) {   // tuning aid
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 512, lds);
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, (const void*)kfn);
+        fprintf(stderr, "[halo8 BN=%d WM=%d] patch %dx%d lds %zu B grid %d: occupancy %d blocks/CU (err %d), regs %d, static lds %zu, max dyn %d\n", BN, WAVES_M, g.th, g.tw, lds,
+                a.nblk_m * a.nblk_n, nb, (int)e, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+    }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a, g);
     return check_launch("conv_halo8_kernel");
 }

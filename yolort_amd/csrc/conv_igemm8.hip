@@ -195,7 +195,7 @@ static int launch_igemm8(const ConvArgs& a0, hipStream_t s) {
     size_t lds = (size_t)2 * 2 * (256 + BN) * 64;
     auto kfn = conv_igemm8_kernel<DT, ODT, BN, WAVES_M>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
-    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a);
     return check_launch("conv_igemm8_kernel");
 }

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256, NA == 3 ? 1 : 3) void conv_head_decode_group_k
 template <typename K>
 int launch_v2_kernel(K kfn, const ConvArgs& a, size_t lds, dim3 grid, hipStream_t s) {
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
-    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
     return check_launch("conv_igemm_v2_kernel");
 }
@@ -712,13 +712,13 @@ int launch_head_decode(const ConvArgs& a, const HeadDecodeArgs& h, hipStream_t s
     if (a.nblk_n == 3) {
         const size_t lds = head_decode_lds<1>(TNA);
         auto kfn = conv_head_decode_kernel<DT, TNA, 1>;
-        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
         hipLaunchKernelGGL(kfn, dim3(a.nblk_m * 3), dim3(256), lds, s, a, h);
         return check_launch("conv_head_decode_kernel");
     }
     const size_t lds = head_decode_lds<3>(TNA);
     auto kfn = conv_head_decode_kernel<DT, TNA, 3>;
-    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m), dim3(256), lds, s, a, h);
     return check_launch("conv_head_decode_kernel");
 }
@@ -728,13 +728,13 @@ int launch_head_group(const HeadGroupArgs& g, hipStream_t s) {
     if (g.a[0].nblk_n == 3) {
         const size_t lds = head_decode_lds<1>(TNA);
         auto kfn = conv_head_decode_group_kernel<DT, TNA, 1>;
-        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+        if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
         hipLaunchKernelGGL(kfn, dim3(g.first_block[g.n]), dim3(256), lds, s, g);
         return check_launch("conv_head_decode_group_kernel");
     }
     const size_t lds = head_decode_lds<3>(TNA);
     auto kfn = conv_head_decode_group_kernel<DT, TNA, 3>;
-    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, 160 * 1024); if (rc_lds != YMI_OK) return rc_lds; }
+    if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(g.first_block[g.n]), dim3(256), lds, s, g);
     return check_launch("conv_head_decode_group_kernel");
 }
