@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     constexpr int WSTAGE_HALFS = 3 * BN * 32;
     typedef typename Mfma<DT>::frag frag;
 
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1 (cin > 32)][weight stage 0][weight stage 1]
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [patch buffer 0][patch buffer 1 (cin > 32)][weight stages 0, 1, 2]
     const int patch_halfs = g.ppieces * 512;
     uint16_t* wring = smem + (a.cin > 32 ? 2 : 1) * patch_halfs;   // a single 32-channel chunk needs no second patch buffer (more blocks per CU)
 
@@ -75,7 +75,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     const int img = t / g.tiles_y;
     const int oy0 = ty * g.th, ox0 = tx * g.tw, n0 = bn * BN;
     const int nchunks = a.cin / 32;
-    const int nsteps = nchunks * 3;                  // one step = one kernel row (3 taps) of one 32-channel chunk
     H8_STAMP(0);
 #ifdef YMI_STAMPS   // slot 126: where the block runs (HW_ID: wave / simd / cu / sh / se; XCC_ID)
     if (threadIdx.x == 0 && blockIdx.x < 2048) {
@@ -134,86 +133,101 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
     // prologue: the whole first patch (3 pieces per wave) and weight stage 0
     static_for<0, 3>([&](auto jt) { issue_patch_piece(0, jt); });
     static_for<0, PW>([&](auto jt) { issue_w_piece(0, 0, jt); });
+    static_for<0, PW>([&](auto jt) { issue_w_piece(3 * a.cin, 1, jt); });   // stage 1 = (chunk 0, dy 1): nsteps >= 3 always
     f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
     load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
     init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
     // (after the prologue DMA issue: waiting for the bias load first put two cold memory latencies in series at every block start)
 
-    // ---- per-lane fragment geometry ----
+    // ---- per-lane fragment geometry: LDS byte offsets of the nine taps' activation fragments (k16 half 0; half 1 = ^ 32),
+    //      relative to the current patch buffer -- computed once, not per sub-step (the q -> swizzle arithmetic was ~6 VALU
+    //      per fragment read, 970 VALU per wave against 144 MFMAs on a 128 -> 128 layer) ----
     const int frow = lane & 31;
     const int hi = lane >> 5;
     const int npix = g.th * g.tw;
-    int q0[TM];   // patch pixel of this lane's output pixel at tap (0,0)
+    int ea[TM][9];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int p = wave_m + j * 32 + frow;
         const int pc = p < npix ? p : 0;
         const int r = fast_div(pc, g.tw, g.magic_tw), c = pc - r * g.tw;
-        q0[j] = r * g.pw + c;
+        const int q00 = r * g.pw + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int q = q00 + (t / 3) * g.pw + (t % 3);
+            ea[j][t] = (q * 32 + ((hi ^ ((q >> 2) & 3)) * 8)) * 2;
+        }
     }
     const int wswz = (lane >> 2) & 3;
-    int wpos[2];
-    wpos[0] = ((0 + hi) ^ wswz) * 8;
-    wpos[1] = ((2 + hi) ^ wswz) * 8;
+    // weight fragments: byte offset of (row frow, k16 half ks) inside a stage, relative to wring + wave_n rows
+    const int wb0 = ((wave_n + frow) * 32 + ((0 + hi) ^ wswz) * 8) * 2;
+    const int wb1 = ((wave_n + frow) * 32 + ((2 + hi) ^ wswz) * 8) * 2;
+    const unsigned char* const lds = reinterpret_cast<const unsigned char*>(smem);
+    const int wring_b = (int)((a.cin > 32 ? 2 : 1) * patch_halfs) * 2;
+    const int patch_b = patch_halfs * 2;
 
-    int chunk = 0, dy = 0;
-    H8_STAMP(1);
-    for (int step = 0; step < nsteps; ++step) {
-        const int slot = step & 1;
-        // Two-deep ring with LONG steps (24 MFMAs per wave at BN = 128): the loads of stage step were issued one whole step
-        // (>= 1.5k cycles) ago, so a plain vmcnt(0) costs nothing, and one barrier per step is amortised over 3 taps.
-        wait_vmcnt<0>();
-        H8_STAMP(4 + step * 3);
-        __builtin_amdgcn_s_barrier();          // every wave's pieces of this stage landed; everyone is done with stage step-1
+    // One step = one kernel row dy (3 taps) of one 32-channel chunk; stage index s = 3*chunk + dy, so the weight ring slot of a
+    // step is dy itself (three-deep ring).  The stage of step s+2 is issued during step s: with a two-deep ring the loads of
+    // the next stage had ONE step (~2 k cycles) to come back from L2 and the top-of-step wait + barrier cost 720 of the
+    // 2280 cycles of a step (measured, 128 -> 128 at 40x40, two blocks per CU).
+    int pbuf = 0;   // byte offset of the current patch buffer
+    auto do_step = [&](auto dyt, int chunk, bool more_chunks) {
+        constexpr int dy = decltype(dyt)::value;
+        // what may still be in flight when stage s (and, at dy == 0, this chunk's patch) must have landed: the pieces this wave
+        // issued during the previous step after them -- PW weight pieces of stage s+1 (if there is one) and, inside a chunk,
+        // the patch piece of the next chunk (issued BEFORE those weights at dy >= 1; at dy == 0 it is awaited itself)
+        if constexpr (dy == 0) {
+            wait_vmcnt<PW>();
+        } else if constexpr (dy == 1) {
+            if (more_chunks) wait_vmcnt<PW + 1>(); else wait_vmcnt<PW>();
+        } else {
+            if (more_chunks) wait_vmcnt<PW + 1>(); else wait_vmcnt<0>();
+        }
+        H8_STAMP(4 + (chunk * 3 + dy) * 3);
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of this stage landed; everyone is done with stage s-1
         __builtin_amdgcn_sched_barrier(0);
-        H8_STAMP(5 + step * 3);
-        // next step's position (wave-uniform scalars)
-        const bool more = step + 1 < nsteps;
-        const int ndy = dy == 2 ? 0 : dy + 1;
-        const int nchunk = dy == 2 ? chunk + 1 : chunk;
-        const int nkbase = ndy * 3 * a.cin + nchunk * 32;
-        const bool patch_now = chunk + 1 < nchunks;   // piece set `dy` of the next chunk's patch: its buffer was last read in chunk-1
-
-        const uint16_t* pb = smem + (chunk & 1) * patch_halfs;
-        const uint16_t* ws = wring + slot * WSTAGE_HALFS + wave_n * 32;
-        const int rowoff = dy * g.pw;
+        H8_STAMP(5 + (chunk * 3 + dy) * 3);
+        // stage s+2: (chunk, 2) | (chunk+1, 0) | (chunk+1, 1), ring slot (dy + 2) % 3
+        constexpr int ndy = (dy + 2) % 3;
+        const bool issue_w = dy == 0 ? true : more_chunks;
+        const int nkbase = ndy * 3 * a.cin + (dy == 0 ? chunk : chunk + 1) * 32;
+        const unsigned char* pb = lds + pbuf;
+        const unsigned char* ws = lds + wring_b + dy * (WSTAGE_HALFS * 2);
         frag fa[2][TM], fw[2][TN];
         auto read_frags = [&](auto subt, auto buft) {   // sub-step = (tap, k16 half)
             constexpr int sub = decltype(subt)::value, buf = decltype(buft)::value;
             constexpr int tap = sub >> 1, ks = sub & 1;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int q = q0[j] + rowoff + tap;
-                const int e0 = q * 32 + ((hi ^ ((q >> 2) & 3)) * 8);
-                fa[buf][j] = *reinterpret_cast<const frag*>(pb + (ks ? (e0 ^ 16) : e0));   // k-chunk (2+hi)^swz = flip bit 1
-            }
+            for (int j = 0; j < TM; ++j) fa[buf][j] = *reinterpret_cast<const frag*>(pb + (ks ? (ea[j][dy * 3 + tap] ^ 32) : ea[j][dy * 3 + tap]));
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fw[buf][i] = *reinterpret_cast<const frag*>(ws + (tap * BN + i * 32 + frow) * 32 + wpos[ks]);
+            for (int i = 0; i < TN; ++i) fw[buf][i] = *reinterpret_cast<const frag*>(ws + (ks ? wb1 : wb0) + (tap * BN + i * 32) * 64);
         };
         read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 6>([&](auto subt) {
             constexpr int sub = decltype(subt)::value;
             // fragments of the next sub-step first (their latency hides under this sub-step's MFMAs) ...
             if constexpr (sub + 1 < 6) read_frags(std::integral_constant<int, sub + 1>{}, std::integral_constant<int, (sub + 1) & 1>{});
-            // ... then one slice of next stage's DMA issue (spread over the sub-steps instead of a burst at the step's head)
+            // ... then one slice of the DMA issue (spread over the sub-steps instead of a burst at the step's head)
             if constexpr (sub == 0) {
-                if (patch_now) {
-                    if (dy == 0) issue_patch_piece(chunk + 1, std::integral_constant<int, 0>{});
-                    else if (dy == 1) issue_patch_piece(chunk + 1, std::integral_constant<int, 1>{});
-                    else issue_patch_piece(chunk + 1, std::integral_constant<int, 2>{});
-                }
+                if (more_chunks) issue_patch_piece(chunk + 1, std::integral_constant<int, dy>{});
             } else if constexpr (sub - 1 < PW) {
-                if (more) issue_w_piece(nkbase, slot ^ 1, std::integral_constant<int, sub - 1>{});
+                if (issue_w) issue_w_piece(nkbase, ndy, std::integral_constant<int, sub - 1>{});
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(fw[sub & 1][i], fa[sub & 1][j], acc[i][j]);
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `step` before it reaches the next barrier
-        H8_STAMP(6 + step * 3);
-        dy = ndy;
-        chunk = nchunk;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage s before it reaches the next barrier
+        H8_STAMP(6 + (chunk * 3 + dy) * 3);
+    };
+    H8_STAMP(1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more_chunks = chunk + 1 < nchunks;
+        do_step(std::integral_constant<int, 0>{}, chunk, more_chunks);
+        do_step(std::integral_constant<int, 1>{}, chunk, more_chunks);
+        do_step(std::integral_constant<int, 2>{}, chunk, more_chunks);
+        pbuf = patch_b - pbuf;   // the other patch buffer (a single-chunk launch never gets here twice)
     }
 
     // ---- epilogue: SiLU (+ residual), 16-byte stores straight from the MFMA layout (conv_common.hpp) ----
@@ -267,7 +281,7 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     g.magic_pw = magic(g.pw);
     a.nblk_m = a.n * g.tiles_x * g.tiles_y;
     a.nblk_n = cdiv(a.cout_pad, BN);
-    size_t lds = (size_t)(a.cin > 32 ? 2 : 1) * g.ppieces * 1024 + (size_t)2 * 3 * BN * 64;
+    size_t lds = (size_t)(a.cin > 32 ? 2 : 1) * g.ppieces * 1024 + (size_t)3 * 3 * BN * 64;
     auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
@@ -275,7 +289,7 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
         int nb = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 512, lds);
         hipFuncAttributes fa;
-        hipFuncGetAttributes(&fa, (const void*)kfn);
+        (void)hipFuncGetAttributes(&fa, (const void*)kfn);
         fprintf(stderr, "[halo8 BN=%d WM=%d] patch %dx%d lds %zu B grid %d: occupancy %d blocks/CU (err %d), regs %d, static lds %zu, max dyn %d\n", BN, WAVES_M, g.th, g.tw, lds,
                 a.nblk_m * a.nblk_n, nb, (int)e, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
     }
