@@ -284,6 +284,18 @@ def test_conv_halo8_kernel(dev, variant, shape):
     _run_conv(dev, torch.bfloat16, k=3, s=1, p=1, tile=variant, seed=variant + 1, **shape)
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("cout", [32, 64])
+@pytest.mark.parametrize("shape", [dict(n=2, h=40, w=40), dict(n=1, h=33, w=21), dict(n=3, h=8, w=16), dict(n=2, h=5, w=7), dict(n=9, h=64, w=96), dict(n=1, h=160, w=160)])
+def test_conv3x3_c32_kernel(dev, stride, cout, shape):
+    """resident-weights persistent 3x3 kernel for cin = 32 (conv3x3_c32.hip, tile 131): stride 1 / 2 (parity-split patch columns),
+    cout 32 / 64, ragged sizes (partial tiles, odd widths), more tiles than resident blocks (the persistent loop), residual
+    (stride 1) and channel-slice views"""
+    _run_conv(dev, torch.float16, cin=32, cout=cout, k=3, s=stride, p=1, tile=131, residual=(stride == 1 and cout == 32), x_cs_extra=32, y_cs_extra=64,
+              seed=131 + stride + cout, **shape)
+    _run_conv(dev, torch.bfloat16, cin=32, cout=cout, k=3, s=stride, p=1, tile=131, seed=132 + stride + cout, **shape)
+
+
 @pytest.mark.parametrize("tile", [121, 122, 123, 124])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv1x1_stream_kernel(dev, dtype, tile):

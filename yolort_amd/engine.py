@@ -355,6 +355,9 @@ class Plan:
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
             if chain is None:   # 8-wave halo kernel (conv_halo8.hip): 256-pixel patches, <= 2 DMA pieces per wave per step
                 cands = cands + ([94] if d.cout_pad <= 32 else ([92, 93] if d.cout_pad <= 64 else [91, 92, 93, 95]))
+        if d.kh == 3 and d.kw == 3 and d.sh == d.sw and d.sh in (1, 2) and d.ph == 1 and d.pw == 1 and d.cin == 32 and d.cout in (32, 64) and d.k_pad == 288 and \
+                d.out_dtype == d.dtype and d.y2_mode != 2 and chain is None:
+            cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
         if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
             cands = cands + [41]   # dedicated stem kernel
         best, best_ms = 0, float("inf")
