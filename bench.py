@@ -316,10 +316,13 @@ def main():
         run_steps(1)                       # any candidate-capacity growth (a local re-run, no collective) happens before the gather is on
         yolo.enable_distributed_gather()   # the slab all-gather is enqueued behind each batch's post-process (no host sync before it)
 
+    second_rounds = [0]
+
     def collect(p):
         dets = p.result()
         if world > 1:
-            p.gathered()
+            p.gathered()   # every rank, every batch, in submission order: collective when some rank re-ran the batch (dist.resolve_stale)
+            second_rounds[0] += int(p.second_round)
         return dets
 
     dets = run_steps(max(args.warmup, 1))
@@ -408,11 +411,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
                        "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
+                       "gather_second_rounds_rank0": second_rounds[0],
                        "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                        "candidates_per_step_rank0": n_cand, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
                          "traffic": traffic,
-                         "kernel": "conv family: conv_igemm_v2_kernel, conv3x3_halo_kernel, conv_halo8_kernel, conv_stem_planar_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
+                         "kernel": "conv family: conv_igemm_v2_kernel, conv_igemm8_kernel, conv_halo8_kernel, conv3x3_c32_kernel, conv1x1_stream_kernel, conv_stem_planar_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
                          "launches_per_step": n_conv, "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2), "conv_ms_per_step": round(conv_s * 1e3, 4),
                          "timing": f"HIP events on the plan's stream around the conv launches, one batch in flight, mean of {n_excl} steps right after the timed region",
                          "algorithmic_bytes_per_step": bytes_step, "algorithmic_bytes_per_launch": round(bytes_step / max(n_conv, 1)), "algorithmic_flops_per_step": flops_step,

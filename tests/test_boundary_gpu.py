@@ -279,6 +279,20 @@ for p in pend:
     total += int(c.sum())
 ok = ok and total > 0
 print("total detections", total)
+# a batch that has to be re-run locally AFTER the gather was switched on (candidate capacity too small): its shard of the first
+# exchange is marked stale on the device, gathered() takes the second round (dist.resolve_stale) and returns the final results
+m.model.cand_cap_per_image = 64
+p = m.forward_async(batches[0])
+dets = p.result()
+b, s, l, c = p.gathered()
+print("second round taken:", p.second_round, "capacity now", m.model.cand_cap_per_image, "counts", c.tolist())
+ok = ok and p.second_round and m.model.cand_cap_per_image > 64 and int(c.min()) >= 0
+for i, d in enumerate(dets):
+    k = int(c[i])
+    ok = ok and k == len(d["scores"]) and k > 0 and torch.equal(b[i, :k], d["boxes"]) and torch.equal(s[i, :k], d["scores"]) and torch.equal(l[i, :k], d["labels"])
+p = m.forward_async(batches[1])   # the grown capacity holds: first round only
+p.result(); p.gathered()
+ok = ok and not p.second_round
 print("GATHER_OK" if ok else "GATHER_MISMATCH")
 dist.destroy_process_group()
 """

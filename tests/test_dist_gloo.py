@@ -34,6 +34,23 @@ def _worker(rank, world, port, q):
         dets = [{"boxes": boxes[i, : count[i]], "scores": scores[i, : count[i]], "labels": labels[i, : count[i]]} for i in range(lo, hi)]
         full = yd.gather_detections(dets, k)
         ok = ok and len(full) == n and all(torch.equal(full[i]["labels"], labels[i, : count[i]]) and torch.equal(full[i]["boxes"], boxes[i, : count[i]]) for i in range(n))
+        # stale-shard protocol (yolort_amd/models/yolo.py PendingDetections.gathered): rank 1 marks its shard of the first exchange
+        # stale (it has to re-run the batch locally); both ranks see it in their copy and both take the second round
+        stale = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
+        wrong = torch.full_like(scores[lo:hi], -7.0)   # what a truncated first pass might have left in the slab
+        local = yd.pack_slab(boxes[lo:hi], wrong if rank == 1 else scores[lo:hi], labels[lo:hi], count[lo:hi], stale=stale)
+        out = torch.empty(world * local.shape[0], local.shape[1])
+        dist.all_gather_into_tensor(out, local)
+        first = yd.unpack_slab(out, k)
+        ok = ok and first[3].tolist() == [5, 0, 3, -1, -1, -1]
+        calls = []
+        def final():
+            calls.append(1)
+            return boxes[lo:hi], scores[lo:hi], labels[lo:hi], count[lo:hi]
+        (b, s, l, c), second = yd.resolve_stale(first, final)
+        ok = ok and second and len(calls) == 1 and torch.equal(b, boxes) and torch.equal(s, scores) and torch.equal(l, labels) and torch.equal(c, count)
+        (b, s, l, c), second = yd.resolve_stale((b, s, l, c), final)   # nothing stale: no collective, no call
+        ok = ok and not second and len(calls) == 1
         q.put((rank, bool(ok), (lo, hi)))
     finally:
         dist.destroy_process_group()

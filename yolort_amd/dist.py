@@ -10,7 +10,7 @@ into one fp32 buffer so a batch costs a single collective (latency-bound: ~0.3 M
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -24,15 +24,50 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def pack_slab(boxes: Tensor, scores: Tensor, labels: Tensor, count: Tensor) -> Tensor:
-    """(n,K,4)+(n,K)+(n,K)+(n) -> one fp32 buffer (n, K*6 + 1); labels/counts travel exactly (ints < 2^24)"""
+SLAB_STALE = -1   # count column of a shard whose rank has to re-run the batch locally (see resolve_stale)
+
+
+def pack_slab(boxes: Tensor, scores: Tensor, labels: Tensor, count: Tensor, stale: Optional[Tensor] = None) -> Tensor:
+    """(n,K,4)+(n,K)+(n,K)+(n) -> one fp32 buffer (n, K*6 + 1); labels/counts travel exactly (ints < 2^24).
+    `stale`: optional 0-d / 1-element tensor on the same device (no host sync); when non-zero the shard's count column is
+    SLAB_STALE -- the sender will re-run this batch (candidate capacity / score-prefix redo) and every rank learns it from the
+    collective itself."""
     n, k = scores.shape
     buf = torch.empty(n, k * 6 + 1, device=scores.device, dtype=torch.float32)
     buf[:, : 4 * k] = boxes.reshape(n, 4 * k)
     buf[:, 4 * k: 5 * k] = scores
     buf[:, 5 * k: 6 * k] = labels.to(torch.float32)
-    buf[:, 6 * k] = count.to(torch.float32)
+    cnt = count.to(torch.float32)
+    if stale is not None:
+        cnt = torch.where(stale.reshape(-1)[:1] != 0, torch.full_like(cnt, float(SLAB_STALE)), cnt)
+    buf[:, 6 * k] = cnt
     return buf
+
+
+def dets_to_slab(dets: List[Dict[str, Tensor]], k: int, device=None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """List[Dict] (the model's output) -> the fixed-shape slab (n,K,4) fp32, (n,K) fp32, (n,K) int64, (n) int32"""
+    dev = device if device is not None else (dets[0]["scores"].device if dets else torch.device("cpu"))
+    n = len(dets)
+    boxes = torch.zeros(n, k, 4, device=dev)
+    scores = torch.zeros(n, k, device=dev)
+    labels = torch.zeros(n, k, dtype=torch.int64, device=dev)
+    count = torch.zeros(n, dtype=torch.int32, device=dev)
+    for i, d in enumerate(dets):
+        m = min(k, d["scores"].shape[0])
+        boxes[i, :m], scores[i, :m], labels[i, :m], count[i] = d["boxes"][:m].float(), d["scores"][:m].float(), d["labels"][:m], m
+    return boxes, scores, labels, count
+
+
+def resolve_stale(gathered: Tuple[Tensor, Tensor, Tensor, Tensor], local_final: Callable[[], Tuple[Tensor, Tensor, Tensor, Tensor]],
+                  group=None) -> Tuple[Tuple[Tensor, Tensor, Tensor, Tensor], bool]:
+    """Second round of the per-batch exchange, taken by EVERY rank iff any shard of the first round is marked SLAB_STALE.
+    All ranks hold the same gathered counts, so they agree on whether to enter without talking to each other; the ranks
+    that re-ran the batch contribute their final results, the others re-send theirs.  Returns (global slab, second_round)."""
+    counts = gathered[3]
+    if not bool((counts < 0).any().item()):
+        return gathered, False
+    b, s, l, c = local_final()
+    return all_gather_slab(b, s, l, c, group), True
 
 
 def unpack_slab(buf: Tensor, k: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
@@ -54,15 +89,7 @@ def all_gather_slab(boxes: Tensor, scores: Tensor, labels: Tensor, count: Tensor
 
 def gather_detections(dets: List[Dict[str, Tensor]], k: int, group=None) -> List[Dict[str, Tensor]]:
     """List[Dict] convenience form: pads each image's detections to K, all-gathers, slices back."""
-    dev = dets[0]["scores"].device if dets else torch.device("cpu")
-    n = len(dets)
-    boxes = torch.zeros(n, k, 4, device=dev)
-    scores = torch.zeros(n, k, device=dev)
-    labels = torch.zeros(n, k, dtype=torch.int64, device=dev)
-    count = torch.zeros(n, dtype=torch.int32, device=dev)
-    for i, d in enumerate(dets):
-        m = min(k, d["scores"].shape[0])
-        boxes[i, :m], scores[i, :m], labels[i, :m], count[i] = d["boxes"][:m].float(), d["scores"][:m].float(), d["labels"][:m], m
+    boxes, scores, labels, count = dets_to_slab(dets, k)
     b, s, l, c = all_gather_slab(boxes, scores, labels, count, group)
     cl = c.cpu().tolist()
     return [{"scores": s[i, : cl[i]], "labels": l[i, : cl[i]], "boxes": b[i, : cl[i]]} for i in range(len(cl))]

@@ -62,6 +62,7 @@ class PendingDetections:
         self._result: Optional[List[Dict[str, Tensor]]] = None
         self._gathered = None
         self.gather_issued = False   # set by YOLO._submit_entry when this batch's slab all-gather was enqueued
+        self.second_round = False    # gathered(): a stale shard made every rank exchange this batch again
         # planar input images when the stem read them directly (entry.x was never filled): a redo must start from them
         self.planar = planar
 
@@ -78,23 +79,29 @@ class PendingDetections:
         return self._result
 
     def gathered(self):
-        """global detection slab (boxes (G*N,K,4), scores, labels, counts) in rank order; needs YOLO.enable_distributed_gather()"""
+        """global detection slab (boxes (G*N,K,4), scores, labels, counts) in rank order; needs YOLO.enable_distributed_gather().
+        COLLECTIVE in one case: when some rank had to re-run this batch locally (candidate capacity / score-prefix redo) its shard
+        of the first exchange is marked stale (dist.SLAB_STALE in the count column, set on the device), every rank sees that in
+        its own copy of the slab and all of them take a second all-gather with their final results (dist.resolve_stale) -- so
+        call it for every batch, in submission order, on every rank."""
         from .. import dist as ydist
         self.result()
         if self._gathered is None:
-            raise YmiError("no global slab for this batch: enable YOLO.enable_distributed_gather() before submitting it; a batch that "
-                           "was re-run locally (candidate capacity / score-prefix redo) has none either -- all-gather its result() "
-                           "with yolort_amd.dist.gather_detections on every rank instead")
+            raise YmiError("no global slab for this batch: enable YOLO.enable_distributed_gather() before submitting it")
         if isinstance(self._gathered, Tensor):
-            self._gathered = ydist.unpack_slab(self._gathered, self.entry.post.k)
+            k = self.entry.post.k
+            first = ydist.unpack_slab(self._gathered, k)
+            dev = self._gathered.device
+            with torch.cuda.device(dev):
+                self._gathered, self.second_round = ydist.resolve_stale(first, lambda: ydist.dets_to_slab(self._result, k, dev), self.owner._gather_group)
         return self._gathered
 
     def _collect(self) -> List[Dict[str, Tensor]]:
         e = self.entry
         self.event.synchronize()
         host = e.result_host.tolist()
-        if host[1] == 0 and self.gather_issued:   # detach the global slab too: the instance's buffer is rewritten by its next batch
-            self._gathered = e.gathered.clone()
+        if self.gather_issued:   # detach the global slab too: the instance's buffer is rewritten by its next batch
+            self._gathered = e.gathered.clone()   # (this rank's own shard is marked stale when host[1] != 0: see gathered())
         if host[1] != 0 and e.outstanding is self:
             e.outstanding = None   # a redo below may recycle this very instance: it must not wait for this handle again
         if host[1] & 2 and not host[1] & 1:   # the score prefix of a crowded image gave < detections_per_img survivors: exact full pass
@@ -304,7 +311,7 @@ class YOLO(nn.Module):
                 import torch.distributed as dist
 
                 from .. import dist as ydist
-                packed = ydist.pack_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count)
+                packed = ydist.pack_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count, stale=e.post.status[1:2])
                 world = dist.get_world_size(self._gather_group)
                 if getattr(e, "gathered", None) is None or e.gathered.shape[0] != world * packed.shape[0]:
                     e.gathered = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
