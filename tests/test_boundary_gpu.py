@@ -266,10 +266,11 @@ for b in batches:
     m(b)   # candidate-capacity growth re-runs a batch locally, without a collective (PendingDetections.gathered raises for it): settle it first
 m.model.enable_distributed_gather(force=True)
 pend = [m.forward_async(b) for b in batches]
-ok, total = True, 0
+ok, total, per_batch = True, 0, []
 for p in pend:
     dets = p.result()
     b, s, l, c = p.gathered()
+    per_batch.append(int(c.max()))
     for i, d in enumerate(dets):
         k = int(c[i])
         checks = (k == len(d["scores"]), torch.equal(b[i, :k], d["boxes"]), torch.equal(s[i, :k], d["scores"]), torch.equal(l[i, :k], d["labels"]))
@@ -281,8 +282,10 @@ ok = ok and total > 0
 print("total detections", total)
 # a batch that has to be re-run locally AFTER the gather was switched on (candidate capacity too small): its shard of the first
 # exchange is marked stale on the device, gathered() takes the second round (dist.resolve_stale) and returns the final results
+crowded = max(range(len(batches)), key=lambda i: per_batch[i])   # > 64 detections in one image: more than 64 candidates for sure
+ok = ok and per_batch[crowded] > 64
 m.model.cand_cap_per_image = 64
-p = m.forward_async(batches[0])
+p = m.forward_async(batches[crowded])
 dets = p.result()
 b, s, l, c = p.gathered()
 print("second round taken:", p.second_round, "capacity now", m.model.cand_cap_per_image, "counts", c.tolist())
@@ -290,8 +293,9 @@ ok = ok and p.second_round and m.model.cand_cap_per_image > 64 and int(c.min()) 
 for i, d in enumerate(dets):
     k = int(c[i])
     ok = ok and k == len(d["scores"]) and k > 0 and torch.equal(b[i, :k], d["boxes"]) and torch.equal(s[i, :k], d["scores"]) and torch.equal(l[i, :k], d["labels"])
-p = m.forward_async(batches[1])   # the grown capacity holds: first round only
+p = m.forward_async(batches[crowded])   # the grown capacity holds for the same batch: first round only
 p.result(); p.gathered()
+print("repeat: second round", p.second_round)
 ok = ok and not p.second_round
 print("GATHER_OK" if ok else "GATHER_MISMATCH")
 dist.destroy_process_group()

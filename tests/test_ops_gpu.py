@@ -408,35 +408,45 @@ def test_letterbox_vs_oracle(dev):
     assert (nt8.nchw().float().cpu() - ref8).abs().max().item() <= 5e-5
 
 
+@pytest.mark.parametrize("kernel", ["default", "1", "2", "4", "tile1", "2+cg2", "4+cg2", "1+cg2"])
 @pytest.mark.parametrize("in_dtype,hwc", [(torch.float16, False), (torch.bfloat16, False), (torch.float32, False), (torch.uint8, False), (torch.uint8, True)])
-def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc):
-    """round 2: the tiled, LDS-staged letterbox (16-byte source loads, two pixels per store) must reproduce the per-pixel kernel
-    bit for bit -- up / down scaling, odd sizes, rows that are not 16-byte aligned, every input type; the 8-channel output form
-    still takes the per-pixel kernel and serves as the reference"""
+def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kernel, monkeypatch):
+    """round 2: the tiled, LDS-staged letterbox kernels (16-byte source loads, two pixels per store; the lean one with 1 / 2 / 4
+    rows per wave and the first tiled kernel) must reproduce the per-pixel kernel bit for bit -- up / down scaling, odd sizes,
+    rows that are not 16-byte aligned, every input type; the 8-channel output form still takes the per-pixel kernel and serves as
+    the reference"""
+    monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
+    monkeypatch.delenv("YOLORT_AMD_LB_CG", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("YOLORT_AMD_LETTERBOX", kernel.split("+")[0])
+        monkeypatch.setenv("YOLORT_AMD_LB_CG", "2" if kernel.endswith("cg2") else "1")
     from yolort_amd.engine import View
     from yolort_amd.models.transform import YOLOTransform
     from yolort_amd.utils.synth import synth_images
     tr = YOLOTransform(320, 320)
-    shapes = [(641, 479), (97, 311), (320, 320), (333, 251), (1080, 1920), (75, 100)]
-    imgs = []
-    for i, (h, w) in enumerate(shapes):
-        im = synth_images(1, h, w, seed=60 + i)[0]
-        if in_dtype == torch.uint8:
-            im = (im * 255).round().to(torch.uint8)
-            im = im.permute(1, 2, 0).contiguous() if hwc else im
-        else:
-            im = im.to(in_dtype)
-        imgs.append(im.to(dev))
-    (hb, wb), sizes, pads = tr.geometry([tr.image_hw(im) for im in imgs])
-    outs = []
-    for c_out in (4, 8):
-        t = torch.full((len(imgs) * hb * wb * c_out,), 7.0, device=dev, dtype=torch.float16)
-        v = View(t, 0, len(imgs), hb, wb, c_out, c_out)
-        tr.letterbox_into(imgs, v, sizes, pads)
-        torch.cuda.synchronize()
-        outs.append(v.as_tensor().clone())
-    assert torch.equal(outs[0][..., :3], outs[1][..., :3])
-    assert bool((outs[0][..., 3] == 0).all())
+    # first list: every image fits the LDS budget of the tiled kernels (scale factors <= 2.1: they run); second list: the 6x
+    # down-scale of the 1080x1920 image does not (the whole launch falls back to the per-pixel kernel)
+    for shapes in ([(641, 479), (97, 311), (320, 320), (333, 251), (75, 100), (500, 641), (640, 333)],
+                   [(641, 479), (97, 311), (320, 320), (333, 251), (1080, 1920), (75, 100)]):
+        imgs = []
+        for i, (h, w) in enumerate(shapes):
+            im = synth_images(1, h, w, seed=60 + i)[0]
+            if in_dtype == torch.uint8:
+                im = (im * 255).round().to(torch.uint8)
+                im = im.permute(1, 2, 0).contiguous() if hwc else im
+            else:
+                im = im.to(in_dtype)
+            imgs.append(im.to(dev))
+        (hb, wb), sizes, pads = tr.geometry([tr.image_hw(im) for im in imgs])
+        outs = []
+        for c_out in (4, 8):
+            t = torch.full((len(imgs) * hb * wb * c_out,), 7.0, device=dev, dtype=torch.float16)
+            v = View(t, 0, len(imgs), hb, wb, c_out, c_out)
+            tr.letterbox_into(imgs, v, sizes, pads)
+            torch.cuda.synchronize()
+            outs.append(v.as_tensor().clone())
+        assert torch.equal(outs[0][..., :3], outs[1][..., :3])
+        assert bool((outs[0][..., 3] == 0).all())
 
 
 @pytest.mark.parametrize("hw,S", [((640, 640), 640), ((480, 640), 640), ((320, 256), 320)])

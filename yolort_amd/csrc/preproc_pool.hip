@@ -1,6 +1,9 @@
 // HBM-bound helper kernels of the conv stack edges: letterbox, layout changes, SPP max-pool
 // pyramid, nearest x2 upsample and channel-slice copy.  All move 16 bytes per lane where the
 // layout allows (cdna_hip_programming.md G13) and are launched with >> 256 workgroups.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.hpp"
 
 namespace ymi {
@@ -156,10 +159,13 @@ __global__ __launch_bounds__(256) void letterbox_copy_kernel(const LetterboxArgs
 // each thread writes TWO pixels = one 16-byte store (a wave covers 1 KiB of a canvas row).  Same arithmetic as
 // letterbox_kernel, operation for operation: results are bit-identical.
 constexpr int LB_TH = 4, LB_TW = 128;
+constexpr int LB_RPW_DEFAULT = 4;
+constexpr int LB_CG_DEFAULT = 1;    // 128-pixel column groups per tile of letterbox_tile2_kernel   // rows per wave of letterbox_tile2_kernel (tile = 4 * RPW rows x 128 columns)
 
 struct LetterboxTileArgs {
     LetterboxArgs base;
     int tiles_x, tiles_y;
+    int debug;   // tuning aid (YOLORT_AMD_LB_DEBUG): bit 0 = skip the staging loads, bit 1 = skip the resampling (fill only)
 };
 
 template <int IDT>
@@ -288,21 +294,197 @@ __global__ __launch_bounds__(256) void letterbox_tile_kernel(const LetterboxTile
     }
 }
 
-// LDS bytes the tiled kernel needs for this launch (max over its images); 0 = some image does not fit (huge down-scale)
+// Lean form of the tiled letterbox (round 2, second pass).  letterbox_tile_kernel issues ~560 vector instructions per thread for
+// 16 output bytes (ISA count: ~100 per staged 16-byte chunk -- three runtime divisions in the chunk -> (plane, row, column)
+// mapping and 64-bit address chains --, ~275 for the two pixels: the row alignment of each of the twelve taps recomputed with
+// 64-bit multiplies).  Same data flow, same arithmetic, bit-identical results (tests/test_ops_gpu.py, every variant):
+//   * a block owns (4 * RPW) x (128 * CG) output pixels; wave w produces rows w, w + 4, ... : the column taps (source offsets
+//     and weights of the thread's two pixels) are computed once and reused for RPW rows, and the staged source rows are shared
+//     by 4 * RPW output rows (fewer rows staged twice by vertically adjacent tiles);
+//   * staging keeps the flat chunk order (every lane of every load busy) but decodes a chunk with one multiply-high by the
+//     reciprocal of the row pitch (one division per block instead of three per chunk), four unconditional loads in flight
+//     per thread, then four predicated LDS stores;
+//   * the 16-byte alignment shift of a staged row is (A + plane * P + row * R) & 15 in 32-bit arithmetic;
+//   * the taps are branch-free (a pixel outside the resized region reads offset 0 and keeps the fill value).
+// Measured on the C3 batch (64 images, 8 shapes -> 1280x1280 bf16, 1.29 GB; tools/letterbox_bench.py, profiles/r02z_letterbox.txt):
+// first tiled kernel 494 us; this kernel with row-per-wave staging (26 of 64 lanes busy per load on a 1.5x down-scale) 475 us --
+// 2.3x fewer VALU instructions bought 4 %: the vector-memory pipe spends its address cycles per INSTRUCTION, not per lane;
+// flat staging: RPW 2 -> 399 us, RPW 4 -> 374 us = 3.44 TB/s (0.43 of the 8 TB/s peak, 0.69 of a device-to-device copy of the
+// canvas on the same box, 4.99 TB/s).  With the staging loads removed 281 us, with the resampling removed 375 us, stores alone
+// 179 us: what remains is the load -> LDS -> barrier latency of a block, not instruction issue.
+template <int IDT, int ODT, int RPW, int CG>
+__global__ __launch_bounds__(256) void letterbox_tile2_kernel(const LetterboxTileArgs t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lb_sm[];
+    const LetterboxArgs& a = t.base;
+    constexpr int TH = 4 * RPW;
+    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
+    constexpr bool HWC = IDT == YMI_U8_HWC;
+    constexpr int BPP = HWC ? 3 : ESZ;
+    constexpr int PLANES = HWC ? 1 : 3;
+    constexpr int TW = LB_TW * CG;
+    // (an XCD-aware tile order -- a contiguous run of tiles per XCD -- was measured: 0 .. -2 %, dropped)
+    const int img = blockIdx.y, tile = blockIdx.x;
+    const int ty = tile / t.tiles_x, tx = tile - ty * t.tiles_x;
+    const int y0t = ty * TH, x0t = tx * TW;
+    const int hin = a.geom[img][0], win = a.geom[img][1], hr = a.geom[img][2], wr = a.geom[img][3];
+    const int pt = a.geom[img][4], pl = a.geom[img][5];
+    const float sy = (float)hin / (float)hr, sx = (float)win / (float)wr;
+    auto src = [](float s, int d, int n_in, int& i0, int& i1, float& l1) {   // exactly the arithmetic of letterbox_kernel
+        float f = __fsub_rn(__fmul_rn(s, (float)d + 0.5f), 0.5f);
+        f = f < 0.f ? 0.f : f;
+        i0 = (int)f;
+        i0 = i0 > n_in - 1 ? n_in - 1 : i0;
+        i1 = i0 + 1 > n_in - 1 ? n_in - 1 : i0 + 1;
+        l1 = f - (float)i0;
+        l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    };
+    const int ya = max(y0t, pt), yb = min(y0t + TH, min(pt + hr, a.hb));
+    const int xa = max(x0t, pl), xb = min(x0t + TW, min(pl + wr, a.wb));
+    const bool any = ya < yb && xa < xb;
+    int ry0 = 0, ry1 = -1, cx0 = 0, cx1 = -1;
+    if (any) {
+        int i0, i1;
+        float l;
+        src(sy, ya - pt, hin, ry0, i1, l);
+        src(sy, yb - 1 - pt, hin, i0, ry1, l);
+        src(sx, xa - pl, win, cx0, i1, l);
+        src(sx, xb - 1 - pl, win, i0, cx1, l);
+    }
+    const int nrows = ry1 - ry0 + 1;
+    const int span = (cx1 - cx0 + 1) * BPP;
+    const int pitch = ((span + 15 + 15) >> 4) << 4;
+    const unsigned char* base = (const unsigned char*)a.img[img];
+    const int64_t plane_b = (int64_t)hin * win * ESZ;
+    const int64_t row_b = (int64_t)win * BPP;
+    // 16-byte alignment of the first needed byte of (plane c, source row r): (al_a + c * al_p + r * al_r) & 15
+    const int al_a = (int)(((uintptr_t)base + (uintptr_t)((int64_t)cx0 * BPP)) & 15);
+    const int al_p = (int)(plane_b & 15), al_r = (int)(row_b & 15);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (any && !(t.debug & 1)) {
+        // Flat chunk order: chunk i of the tile is 16-byte column (i % cpr) of staged row (i / cpr) and lands at LDS byte 16 * i
+        // (pitch = 16 * cpr), so every load / LDS-store instruction has all 64 lanes busy -- the vector-memory pipe spends its
+        // 16 address cycles per instruction whatever the number of active lanes, and a row-per-wave mapping (26 of 64 lanes
+        // on a 1.5x down-scale) measured 1.35x slower.  One division per block (the reciprocal of cpr), none per chunk.
+        const unsigned cpr = (unsigned)pitch >> 4;
+        const unsigned total = (unsigned)(PLANES * nrows) * cpr;
+        const unsigned magic = 0xffffffffu / cpr + 1u;            // i / cpr == mulhi(i, magic) for i < 2^16 (total <= 60 KiB / 16)
+        const unsigned char* gb = base + (int64_t)cx0 * BPP;
+        const unsigned char* safe = (const unsigned char*)((uintptr_t)base & ~(uintptr_t)15);   // a chunk that is not needed reads this one instead (never stored)
+        for (unsigned i0 = threadIdx.x; i0 < total; i0 += 1024) {
+            u32x4 buf[4];
+            bool have[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // four unconditional loads in flight per thread, then four predicated LDS stores
+                const unsigned i = i0 + 256u * u;
+                const unsigned job = __umulhi(i, magic), k = i - job * cpr;
+                const int c = PLANES == 1 ? 0 : ((int)job >= 2 * nrows ? 2 : ((int)job >= nrows ? 1 : 0));
+                const int r = ry0 + (int)job - c * nrows;
+                const int sh = (al_a + c * al_p + r * al_r) & 15;
+                have[u] = i < total && (int)(k << 4) < sh + span;   // aligned 16-byte chunks holding at least one needed byte (an aligned chunk never crosses a page)
+                const unsigned char* g = gb + c * plane_b + (int64_t)r * row_b + (int64_t)((int)(k << 4) - sh);
+                buf[u] = *reinterpret_cast<const u32x4*>(have[u] ? g : safe);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (have[u]) *reinterpret_cast<u32x4*>(lb_sm + (size_t)(i0 + 256u * u) * 16) = buf[u];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int cg = 0; cg < CG; ++cg) {
+    const int x = x0t + cg * LB_TW + (threadIdx.x & 63) * 2;
+    if (x >= a.wb) break;
+    // column taps of the thread's two pixels: byte offsets inside a staged row, weights
+    bool inx[2];
+    int ox0[2], ox1[2];
+    float lx0[2], lx1[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int xx = x + p - pl;
+        inx[p] = (unsigned)xx < (unsigned)wr && x + p < a.wb;
+        ox0[p] = ox1[p] = 0;
+        lx0[p] = lx1[p] = 0.f;
+        if (inx[p]) {
+            int sx0, sx1;
+            src(sx, xx, win, sx0, sx1, lx1[p]);
+            lx0[p] = 1.f - lx1[p];
+            ox0[p] = (sx0 - cx0) * BPP;
+            ox1[p] = (sx1 - cx0) * BPP;
+        }
+    }
+    const bool two = x + 1 < a.wb;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int y = y0t + 4 * j + wv;
+        if (y >= a.hb) break;   // wave-uniform
+        float v[2][3];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) v[p][0] = v[p][1] = v[p][2] = a.fill;
+        const int yy = y - pt;
+        if ((unsigned)yy < (unsigned)hr && (inx[0] || inx[1]) && !(t.debug & 2)) {
+            int sy0, sy1;
+            float ly1;
+            src(sy, yy, hin, sy0, sy1, ly1);
+            const float ly0 = 1.f - ly1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int pc = HWC ? 0 : c;
+                const int sub = HWC ? c : 0;
+                const unsigned char* r0 = lb_sm + (pc * nrows + (sy0 - ry0)) * pitch + ((al_a + pc * al_p + sy0 * al_r) & 15) + sub;
+                const unsigned char* r1 = lb_sm + (pc * nrows + (sy1 - ry0)) * pitch + ((al_a + pc * al_p + sy1 * al_r) & 15) + sub;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {   // branch-free: a pixel outside the resized region reads offset 0 of the rows and keeps the fill value
+                    const float p00 = lds_elem<IDT>(r0 + ox0[p]), p01 = lds_elem<IDT>(r0 + ox1[p]);
+                    const float p10 = lds_elem<IDT>(r1 + ox0[p]), p11 = lds_elem<IDT>(r1 + ox1[p]);
+                    const float top = __fadd_rn(__fmul_rn(p00, lx0[p]), __fmul_rn(p01, lx1[p]));
+                    const float bot = __fadd_rn(__fmul_rn(p10, lx0[p]), __fmul_rn(p11, lx1[p]));
+                    const float val = __fadd_rn(__fmul_rn(top, ly0), __fmul_rn(bot, ly1));
+                    v[p][c] = inx[p] ? val : a.fill;
+                }
+            }
+        }
+        const int64_t o = (((int64_t)img * a.hb + y) * a.wb + x) * 4;
+        if constexpr (ODT == YMI_F32) {
+            float* op = (float*)a.out + o;
+            f32x4 q0 = {v[0][0], v[0][1], v[0][2], 0.f};
+            *reinterpret_cast<f32x4*>(op) = q0;
+            if (two) {
+                f32x4 q1 = {v[1][0], v[1][1], v[1][2], 0.f};
+                *reinterpret_cast<f32x4*>(op + 4) = q1;
+            }
+        } else {
+            uint16_t* op = (uint16_t*)a.out + o;
+            u32x4 q;
+            q[0] = (uint32_t)to16<ODT>(v[0][0]) | ((uint32_t)to16<ODT>(v[0][1]) << 16);
+            q[1] = (uint32_t)to16<ODT>(v[0][2]);
+            q[2] = (uint32_t)to16<ODT>(v[1][0]) | ((uint32_t)to16<ODT>(v[1][1]) << 16);
+            q[3] = (uint32_t)to16<ODT>(v[1][2]);
+            if (two && (a.wb & 1) == 0) *reinterpret_cast<u32x4*>(op) = q;
+            else {
+                u32x2 h0 = {q[0], q[1]};
+                *reinterpret_cast<u32x2*>(op) = h0;
+                if (two) { u32x2 h1 = {q[2], q[3]}; *reinterpret_cast<u32x2*>(op + 4) = h1; }
+            }
+        }
+    }
+    }   // column groups
+}
+
+// LDS bytes a tiled kernel with th-row tiles needs for this launch (max over its images); 0 = some image does not fit (huge down-scale)
 template <int IDT>
-static size_t letterbox_tile_lds(const LetterboxArgs& a) {
+static size_t letterbox_tile_lds(const LetterboxArgs& a, int th = LB_TH, int tw = LB_TW) {
     constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
     constexpr int BPP = IDT == YMI_U8_HWC ? 3 : ESZ;
     constexpr int PLANES = IDT == YMI_U8_HWC ? 1 : 3;
     size_t need = 16;
     for (int i = 0; i < a.n; ++i) {
         const double sy = (double)a.geom[i][0] / a.geom[i][2], sx = (double)a.geom[i][1] / a.geom[i][3];
-        const int rows = (int)(LB_TH * sy) + 3, cols = (int)(LB_TW * sx) + 3;
+        const int rows = (int)(th * sy) + 3, cols = (int)(tw * sx) + 3;
         const size_t pitch = (((size_t)(cols < a.geom[i][1] ? cols : a.geom[i][1]) * BPP + 30) >> 4) << 4;
         const size_t b = (size_t)PLANES * (rows < a.geom[i][0] ? rows : a.geom[i][0]) * pitch;
         need = b > need ? b : need;
     }
-    return need <= 60 * 1024 ? need : 0;
+    return need <= 64 * 1024 ? need : 0;   // the largest dynamic LDS request that needs no opt-in
 }
 
 template <int IDT>
@@ -325,12 +507,50 @@ static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t
 #undef YMI_LBC
         return check_launch("letterbox_copy_kernel");
     }
-    const size_t tile_lds = a.c_out == 4 ? letterbox_tile_lds<IDT>(a) : 0;
-    if (tile_lds > 0) {   // tiled, LDS-staged kernel (bit-identical to letterbox_kernel)
+    // tuning aid: YOLORT_AMD_LETTERBOX = "pixel" (per-pixel kernel), "tile1" (first tiled kernel), "1" / "2" / "4" (rows per wave
+    // of the lean tiled kernel; default: the largest of 4, 2, 1 whose staged rows fit the LDS budget)
+    const char* lb_env = getenv("YOLORT_AMD_LETTERBOX");   // read per call (one launch per batch): tests switch kernels in-process
+    const bool lb_pixel = lb_env && !strcmp(lb_env, "pixel"), lb_tile1 = lb_env && !strcmp(lb_env, "tile1");
+    const int rpw_max = (lb_env && (lb_env[0] == '1' || lb_env[0] == '2' || lb_env[0] == '4') && lb_env[1] == 0) ? lb_env[0] - '0' : LB_RPW_DEFAULT;
+    if (a.c_out == 4 && !lb_pixel && !lb_tile1) {
+        const char* dbg = getenv("YOLORT_AMD_LB_DEBUG");
+        const char* cge = getenv("YOLORT_AMD_LB_CG");
+        const int cg_max = cge ? (atoi(cge) >= 2 ? 2 : 1) : LB_CG_DEFAULT;
+        for (int rpw = rpw_max; rpw >= 1; rpw >>= 1) {
+            int cg = cg_max;
+            size_t lds = letterbox_tile_lds<IDT>(a, 4 * rpw, LB_TW * cg);
+            if (lds == 0 && cg > 1) lds = letterbox_tile_lds<IDT>(a, 4 * rpw, LB_TW * (cg = 1));
+            if (lds == 0) continue;
+            LetterboxTileArgs t;
+            t.base = a;
+            t.tiles_x = cdiv(a.wb, LB_TW * cg);
+            t.tiles_y = cdiv(a.hb, 4 * rpw);
+            t.debug = dbg ? atoi(dbg) : 0;
+            dim3 gt((unsigned)(t.tiles_x * t.tiles_y), (unsigned)a.n), bt(256);
+#define YMI_LBT2C(ODT_, CG_)                                                                                        \
+    if (rpw == 4) hipLaunchKernelGGL((letterbox_tile2_kernel<IDT, ODT_, 4, CG_>), gt, bt, lds, s, t);                \
+    else if (rpw == 2) hipLaunchKernelGGL((letterbox_tile2_kernel<IDT, ODT_, 2, CG_>), gt, bt, lds, s, t);           \
+    else hipLaunchKernelGGL((letterbox_tile2_kernel<IDT, ODT_, 1, CG_>), gt, bt, lds, s, t);
+#define YMI_LBT2(ODT_)                                  \
+    if (cg == 2) { YMI_LBT2C(ODT_, 2) } else { YMI_LBT2C(ODT_, 1) }
+            switch (out_dtype) {
+                case YMI_F16: YMI_LBT2(YMI_F16) break;
+                case YMI_BF16: YMI_LBT2(YMI_BF16) break;
+                case YMI_F32: YMI_LBT2(YMI_F32) break;
+                default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
+            }
+#undef YMI_LBT2
+#undef YMI_LBT2C
+            return check_launch("letterbox_tile2_kernel");
+        }
+    }
+    const size_t tile_lds = (a.c_out == 4 && lb_tile1) ? letterbox_tile_lds<IDT>(a) : 0;
+    if (tile_lds > 0) {   // first tiled kernel (kept for A/B)
         LetterboxTileArgs t;
         t.base = a;
         t.tiles_x = cdiv(a.wb, LB_TW);
         t.tiles_y = cdiv(a.hb, LB_TH);
+        t.debug = 0;
         dim3 gt((unsigned)(t.tiles_x * t.tiles_y), (unsigned)a.n), bt(256);
         switch (out_dtype) {
             case YMI_F16: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_F16>), gt, bt, tile_lds, s, t); break;
