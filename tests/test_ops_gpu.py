@@ -106,7 +106,7 @@ def test_conv_tiles(dev, tile):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=64, h=37, w=29, k=1, s=1, p=0, tile=tile, residual=True)
 
 
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 111, 112, 113, 114, 115, 116])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 111, 112, 113, 114, 115, 116, 117, 118, 119])
 def test_conv_software_pipelined_tiles(dev, tile):
     """v2 tiles with the software-pipelined main loop (fragment double-buffering, DMA issue between MFMAs):
     short K (1..2 steps, fewer than the ring depth), long K (3x3, 3x3 stride 2), residual, views, ragged M / cout"""
@@ -119,7 +119,7 @@ def test_conv_software_pipelined_tiles(dev, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 61, 75, 77, 111, 112])
+@pytest.mark.parametrize("tile", [0, 61, 75, 77, 111, 112, 117, 119])
 def test_conv_upsampled_second_output(dev, dtype, tile):
     """y2_mode 1: one launch writes the conv output and its nearest x2 upsample (into a channel slice of a wider buffer):
     both must equal the plain conv followed by the upsample kernel, bit for bit"""

@@ -1,5 +1,15 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x --timeout 600 -p no:cacheprovider -k "halo8 or halo" 2>&1 | tail -3
-TILES=93,91,92,94,95 timeout 200 python tools/conv_bench.py 32,128,128,40,40,3,1,1 32,64,64,80,80,3,1,1 32,256,256,20,20,3,1,1 32,32,32,160,160,3,1,1 64,96,96,160,160,3,1,1 2>&1 | grep -v amdgpu.ids
+run() { # label, env...
+  lbl=$1; shift
+  env "$@" timeout 200 python bench.py --config c2 --no-cpu-baseline --steps 200 2>/dev/null | grep '^{"metric' | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$lbl: c2', d['value'], d['ms_per_step'], d['roofline']['conv_ms_per_step'])"
+}
+for rep in 1 2; do
+for q in 2 4 8 16; do for p in 4 8; do run "hwq $q pipeline $p" GPU_MAX_HW_QUEUES=$q YOLORT_AMD_PIPELINE=$p; done; done
+run "post hi, pipeline 8" YOLORT_AMD_POST_PRIORITY=-1 YOLORT_AMD_PIPELINE=8
+run "post hi, pipeline 4" YOLORT_AMD_POST_PRIORITY=-1 YOLORT_AMD_PIPELINE=4
+run "conv hi, pipeline 8" YOLORT_AMD_CONV_PRIORITY=-1 YOLORT_AMD_PIPELINE=8
+done

@@ -17,8 +17,9 @@
 
 namespace ymi {
 
-template <int DT, int ODT, int BN, int WAVES_M>
-__global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
+template <int DT, int ODT, int BN, int WAVES_M, int RING>
+__global__ __launch_bounds__(512, RING == 2 ? 2 : 1) void conv_igemm8_kernel(const ConvArgs a) {
+    static_assert(RING == 2 || RING == 3, "two- or three-deep stage ring");
     constexpr int WAVES_N = 8 / WAVES_M;
     constexpr int BM = 256;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
     constexpr int STAGE_HALFS = 2 * SUB_HALFS;
     typedef typename Mfma<DT>::frag frag;
 
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [stage 0][stage 1]
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [stage 0][stage 1]([stage 2])
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -127,6 +128,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
     }
     f32x4 bias_regs[TN][4];   // issued behind the prologue DMA (conv_common.hpp)
     load_bias<TN>(a, n0 + wave_n, lane >> 5, bias_regs);
+    if constexpr (RING == 3) {
+        // three-deep ring: stage 1 leaves in the prologue as well, BEHIND the bias loads -- the vector-memory counter retires in
+        // order, so init_acc's wait for the bias then covers stage 0 and leaves stage 1 in flight
+        if (nk32 > 2) {
+            static_for<0, PS>([&](auto pt) { issue_piece(smem + STAGE_HALFS, pt); });
+            advance_sub();
+        }
+        if (nk32 > 3) {
+            static_for<0, PS>([&](auto pt) { issue_piece(smem + STAGE_HALFS + SUB_HALFS, pt); });
+            advance_sub();
+        }
+    }
     init_acc<TN, TM>(acc, bias_regs);   // accumulate on top of the bias
     // (after the prologue DMA issue: waiting for the bias load first put two cold memory latencies in series at every block start)
 
@@ -136,14 +149,25 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
     pos[0] = ((0 + (lane >> 5)) ^ swz) * 8;
     pos[1] = ((2 + (lane >> 5)) ^ swz) * 8;
 
+    int slot = 0;                              // step % RING
     for (int step = 0; step < nsteps; ++step) {
-        const int slot = step & 1;
-        wait_vmcnt<0>();                       // the stage was issued one whole step ago
+        if constexpr (RING == 2) {
+            wait_vmcnt<0>();                   // the stage was issued one whole step ago
+        } else {
+            // stage `step` was issued two steps ago; stage step+1 (issued during the previous step, or in the prologue) may stay
+            // in flight: exactly the pieces this wave sent for it are newer than everything of stage `step`
+            const int n1 = nk32 - 2 * (step + 1);   // k32 sub-stages of stage step+1 (>= 2: a full stage)
+            if (n1 >= 2) wait_vmcnt<2 * PS>();
+            else if (n1 == 1) wait_vmcnt<PS>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone is done with stage step-1
         __builtin_amdgcn_sched_barrier(0);
         const int subs_here = (2 * step + 1 < nk32) ? 2 : 1;            // k32 sub-stages of this step
-        const int next_subs = nk32 - 2 * (step + 1);                     // sub-stages still to issue (for step+1): >= 2, 1 or <= 0
-        uint16_t* nstage = smem + (slot ^ 1) * STAGE_HALFS;
+        // sub-stages still to issue, for the stage that leaves during this step (step+1, or step+2 with the three-deep ring): >= 2, 1 or <= 0
+        const int next_subs = nk32 - 2 * (step + RING - 1);
+        const int nslot = RING == 2 ? (slot ^ 1) : (slot == 0 ? 2 : slot - 1);   // (slot + RING - 1) % RING: the stage consumed in step-1
+        uint16_t* nstage = smem + nslot * STAGE_HALFS;
         const uint16_t* as = smem + slot * STAGE_HALFS + wave_m * 32;
         const uint16_t* ws = smem + slot * STAGE_HALFS + (BM + wave_n) * 32;
         frag fa[2][TM], fw[2][TN];
@@ -178,12 +202,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs a) {
             }
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // done reading this stage before the next barrier
+        slot = slot + 1 == RING ? 0 : slot + 1;
     }
 
     StoreEpilogue<DT, ODT>{a}(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem);
 }
 
-template <int DT, int ODT, int BN, int WAVES_M>
+template <int DT, int ODT, int BN, int WAVES_M, int RING = 2>
 static int launch_igemm8(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, 256);
@@ -192,8 +217,8 @@ static int launch_igemm8(const ConvArgs& a0, hipStream_t s) {
         set_error("ymi_conv2d: this tile does not fit the chained 1x1 convolution (pixel-major waves, cout width %d)", a.chain_k);
         return YMI_EINVAL;
     }
-    size_t lds = (size_t)2 * 2 * (256 + BN) * 64;
-    auto kfn = conv_igemm8_kernel<DT, ODT, BN, WAVES_M>;
+    size_t lds = (size_t)RING * 2 * (256 + BN) * 64;
+    auto kfn = conv_igemm8_kernel<DT, ODT, BN, WAVES_M, RING>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a);
@@ -209,6 +234,11 @@ static int igemm8_variant(const ConvArgs& a, int variant, hipStream_t s) {
         case 4: return launch_igemm8<DT, ODT, 32, 8>(a, s);    // 8x1 waves of 32 px x 32 cout (chained 1x1 with K1 = 32)
         case 5: return launch_igemm8<DT, ODT, 256, 4>(a, s);   // 4x2 waves of 64 px x 128 cout
         case 6: return launch_igemm8<DT, ODT, 128, 8>(a, s);   // 8x1 waves of 32 px x 128 cout
+        // three-deep stage ring (one block per CU: 120 / 144 KiB of LDS): two steps of DMA in flight -- the small-M, deep-K layers
+        // (one wave of <= 256 blocks, K = 256 .. 1152) spent a full memory latency per step behind the two-deep ring
+        case 7: return launch_igemm8<DT, ODT, 128, 4, 3>(a, s);
+        case 8: return launch_igemm8<DT, ODT, 128, 8, 3>(a, s);
+        case 9: return launch_igemm8<DT, ODT, 64, 4, 3>(a, s);
         default: set_error("ymi_conv2d: unknown igemm8 variant %d", variant); return YMI_EINVAL;
     }
 }

@@ -46,10 +46,12 @@ class _PlanEntry:
         self.result_host = torch.zeros(4 + n, dtype=torch.int32).pin_memory() if post is not None else None
         self.done = None        # event recorded after the post-process + result copy of the last submit
         self.outstanding = None  # the PendingDetections of the last submit while the host has not collected it yet
-        self.post_stream = torch.cuda.Stream(device=x.base.device) if post is not None else None
+        # stream priorities (tuning aid, default 0 / 0): YOLORT_AMD_POST_PRIORITY / YOLORT_AMD_CONV_PRIORITY, -1 = high
+        pp, cp = int(os.environ.get("YOLORT_AMD_POST_PRIORITY", "0")), int(os.environ.get("YOLORT_AMD_CONV_PRIORITY", "0"))
+        self.post_stream = torch.cuda.Stream(device=x.base.device, priority=pp) if post is not None else None
         # each plan instance runs its conv stack on its own stream: consecutive batches overlap on the GPU
         # (the tail of one batch's kernels is filled by the next batch's), measured +12 % on yolov5s bs 32
-        self.main_stream = torch.cuda.Stream(device=x.base.device)
+        self.main_stream = torch.cuda.Stream(device=x.base.device, priority=cp)
 
 
 class PendingDetections:
