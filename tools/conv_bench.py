@@ -35,7 +35,7 @@ def run(case, tiles, iters=20):
             wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
             pc = engine.PackedConv(wt, None, None, torch.float16, dev)
             try:
-                plan.conv(x, pc, s, p, tile=tile)
+                plan.conv(x, pc, s, p, tile=tile, act=int(os.environ.get('ACT', '1')))
             except Exception as e:
                 res.append((tile, None, str(e)[:60])); continue
         try:
