@@ -2,7 +2,7 @@
 HBM bytes of the conv + fused-head launches of one C2 step = sum over launches of FETCH_SIZE x 2 (gfx950 correction,
 MI355X_MICROARCH.md HBM section; the counter is in KiB-like units of 1000 B as rocprofv3 reports it) + WRITE_SIZE.
 
-    python tools/conv_traffic.py profiles/r02s_layer_table_c2_pmc.csv > profiles/conv_traffic.json
+    python tools/conv_traffic.py profiles/r02z_layer_table_c2_pmc.csv > profiles/conv_traffic.json
 """
 import csv
 import json

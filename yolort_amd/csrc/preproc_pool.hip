@@ -309,9 +309,10 @@ __global__ __launch_bounds__(256) void letterbox_tile_kernel(const LetterboxTile
 // Measured on the C3 batch (64 images, 8 shapes -> 1280x1280 bf16, 1.29 GB; tools/letterbox_bench.py, profiles/r02z_letterbox.txt):
 // first tiled kernel 494 us; this kernel with row-per-wave staging (26 of 64 lanes busy per load on a 1.5x down-scale) 475 us --
 // 2.3x fewer VALU instructions bought 4 %: the vector-memory pipe spends its address cycles per INSTRUCTION, not per lane;
-// flat staging: RPW 2 -> 399 us, RPW 4 -> 374 us = 3.44 TB/s (0.43 of the 8 TB/s peak, 0.69 of a device-to-device copy of the
-// canvas on the same box, 4.99 TB/s).  With the staging loads removed 281 us, with the resampling removed 375 us, stores alone
-// 179 us: what remains is the load -> LDS -> barrier latency of a block, not instruction issue.
+// flat staging: RPW 2 -> 399 us, RPW 4 -> 374-380 us = 3.4 TB/s (0.43 of the 8 TB/s peak, 0.69 of a device-to-device copy of the
+// canvas on the same box, 4.99 TB/s).  Final kernel with the staging loads removed 279 us, with the resampling removed 290 us,
+// stores alone 178 us (YOLORT_AMD_LB_DEBUG = 1 / 2 / 3): loads and arithmetic each add ~100 us to the store stream of a block
+// and do not overlap each other -- a block is load -> barrier -> compute -> store, overlap comes only from its neighbours.
 template <int IDT, int ODT, int RPW, int CG>
 __global__ __launch_bounds__(256) void letterbox_tile2_kernel(const LetterboxTileArgs t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_sm[];
