@@ -267,13 +267,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("YOLORT_AMD_BENCH_DEVICE", local_rank))   # default: one GPU per rank (LOCAL_RANK)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("YOLORT_AMD_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only for the two-ranks-on-one-GPU control-flow test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from yolort_amd import dist as ydist
     from yolort_amd.models import YOLOv5
@@ -302,6 +307,15 @@ def main():
     # the host-side result handling is hidden.  Every submitted batch is collected inside the timed region.
     depth = max(1, yolo.pipeline_depth - 1)   # batches in flight before the oldest is collected
 
+    gather_on, second_rounds = [False], [0]
+
+    def collect(p):
+        dets = p.result()
+        if gather_on[0]:
+            p.gathered()   # every rank, every batch, in submission order: collective when some rank re-ran the batch (dist.resolve_stale)
+            second_rounds[0] += int(p.second_round)
+        return dets
+
     def run_steps(k):
         pending, dets = [], None
         for _ in range(k):
@@ -313,17 +327,9 @@ def main():
         return dets
 
     if world > 1:
-        run_steps(1)                       # any candidate-capacity growth (a local re-run, no collective) happens before the gather is on
+        run_steps(1)                       # plan build and the first candidate-capacity growth happen locally, before the gather is on
         yolo.enable_distributed_gather()   # the slab all-gather is enqueued behind each batch's post-process (no host sync before it)
-
-    second_rounds = [0]
-
-    def collect(p):
-        dets = p.result()
-        if world > 1:
-            p.gathered()   # every rank, every batch, in submission order: collective when some rank re-ran the batch (dist.resolve_stale)
-            second_rounds[0] += int(p.second_round)
-        return dets
+        gather_on[0] = True
 
     dets = run_steps(max(args.warmup, 1))
     torch.cuda.synchronize()
@@ -433,7 +439,7 @@ def main():
             k_par = 4 if args.size <= 640 else 2
             out["parity"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
-        if args.per_op:
+        if args.per_op and world == 1:
             # the per-op profile replays the recorded plan from its NHWC4 input buffer: fill it through the letterbox
             # path first (identity-size batches normally feed the stem from the planar images and never touch it)
             yolo.stem_from_planar = False

@@ -313,3 +313,26 @@ def test_slab_all_gather_is_enqueued_behind_the_post_process(dev):
     sock.close()
     r = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT % (ROOT, port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GATHER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu(dev):
+    """bench.py's N > 1 path (per-rank shard, warm-up before the gather is switched on, slab all-gather per batch, gathered() for
+    every batch, barrier + max-over-ranks timing, one JSON line from rank 0) run as TWO ranks under torch.distributed.run.  The box
+    has one GPU, so both ranks use cuda:0 and the process group is gloo (RCCL refuses two ranks on one device) -- the collectives
+    are the same calls, only the transport differs; the RCCL transport itself is covered by the one-rank test above."""
+    import json
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, YOLORT_AMD_BENCH_BACKEND="gloo", YOLORT_AMD_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c1", "--steps", "6", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-800:], r.stderr[-2500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("dp2") and d["config"]["gather_second_rounds_rank0"] == 0
+    assert "cpu_baseline" not in d   # rank 0 at N = 1 only
