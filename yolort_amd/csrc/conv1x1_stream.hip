@@ -16,6 +16,8 @@
 // No activation staging, no barrier in the loop; persistent grid (waves stride over the groups).
 //
 // Replaces yolort/v5/models/common.py:69-70 (Conv.forward) / :172-173 (C3: cv1 and cv2 read the same input) for these shapes.
+#include <cstdlib>
+
 #include "conv_common.hpp"
 
 namespace ymi {
@@ -181,14 +183,28 @@ static int launch_stream(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     const int ngroups = cdiv(a.M, 32);
     const int ncb = cdiv(a.cout_pad, 32 * TNW);
-    // persistent grid: enough waves to keep every CU's memory pipe full (<= 16 waves / CU at these register counts), a multiple of ncb
-    int blocks = 256 * 4;
+    size_t lds = (size_t)(a.cout_pad / 32) * KS * 1024 + (size_t)(a.cout_pad / 32) * 8 * 16;
+    if (a.chain_w != nullptr) lds += (size_t)(a.chain_cout / 32) * (2 * TNW) * 1024 + (size_t)(a.chain_cout / 32) * 8 * 16;
+    // persistent grid = the blocks that are RESIDENT at once (register count and LDS decide: 3 or 4 per CU for these
+    // instantiations), a multiple of ncb.  A fixed 4 blocks per CU left the 158-VGPR instances (3 blocks per CU) with a
+    // fourth, non-resident quarter of the grid that started only when the first blocks had finished their whole share.
+    const bool chain = a.chain_w != nullptr;
+    static size_t occ_lds[2] = {0, 0};
+    static int occ_blocks[2] = {0, 0};
+    if (occ_blocks[chain] == 0 || occ_lds[chain] != lds) {
+        int per_cu = 0;
+        const hipError_t e = chain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_stream_kernel<DT, TNW, KS, true>, 256, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1x1_stream_kernel<DT, TNW, KS, false>, 256, lds);
+        if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
+        occ_blocks[chain] = per_cu > 4 ? 4 : per_cu;   // 16 waves per CU already cover the latency x bandwidth product
+        occ_lds[chain] = lds;
+    }
+    static const char* fixed_env = getenv("YOLORT_AMD_STREAM_BLOCKS");   // tuning aid: blocks per CU of the persistent grid (A/B against the occupancy-sized grid)
+    int blocks = 256 * (fixed_env ? atoi(fixed_env) : occ_blocks[chain]);
     const int need = cdiv(ngroups * ncb, 4);
     if (blocks > need) blocks = need;
     blocks = cdiv(blocks * 4, ncb * 4) * ncb;             // waves = 4 * blocks: multiple of ncb
     if (blocks < 1) blocks = ncb;
-    size_t lds = (size_t)(a.cout_pad / 32) * KS * 1024 + (size_t)(a.cout_pad / 32) * 8 * 16;
-    if (a.chain_w != nullptr) lds += (size_t)(a.chain_cout / 32) * (2 * TNW) * 1024 + (size_t)(a.chain_cout / 32) * 8 * 16;
     if (a.chain_w != nullptr) hipLaunchKernelGGL((conv1x1_stream_kernel<DT, TNW, KS, true>), dim3(blocks), dim3(256), lds, s, a, ngroups, ncb);
     else hipLaunchKernelGGL((conv1x1_stream_kernel<DT, TNW, KS, false>), dim3(blocks), dim3(256), lds, s, a, ngroups, ncb);
     return check_launch("conv1x1_stream_kernel");
