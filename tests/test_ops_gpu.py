@@ -365,8 +365,12 @@ def test_bn_fold(dev):
     assert (got - ref).abs().max().item() < 3e-2
 
 
-def test_spp_pool_and_upsample_exact(dev):
+@pytest.mark.parametrize("spp_g", ["default", "1", "4"])
+def test_spp_pool_and_upsample_exact(dev, spp_g, monkeypatch):
     from yolort_amd import engine
+    monkeypatch.delenv("YOLORT_AMD_SPP_G", raising=False)
+    if spp_g != "default":
+        monkeypatch.setenv("YOLORT_AMD_SPP_G", spp_g)   # channel groups per block of the LDS cascade kernel
     g = torch.Generator().manual_seed(7)
     x = torch.randn(2, 64, 20, 17, generator=g).half()
     plan = engine.Plan(dev, torch.float16)

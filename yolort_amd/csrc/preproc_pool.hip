@@ -889,6 +889,7 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
     // (yolov5m/l at 1280x1280: 40x40 maps -- round 1 fell back to the 169-tap direct kernel there: 1.75 ms per step at C3)
     int G = (c % 32 == 0) ? 4 : 1;
     if ((size_t)h * w * G * 16 * 3 > 160 * 1024 - 512) G = 1;
+    if (const char* ge = getenv("YOLORT_AMD_SPP_G")) { const int g = atoi(ge); if (g == 1 || (g == 4 && G == 4)) G = g; }   // tuning aid
     const size_t lds = (size_t)h * w * G * 16 * 3;
     if (lds <= 160 * 1024 - 512) {
         dim3 g((unsigned)(n * (c / (8 * G)))), b(256);
