@@ -34,7 +34,8 @@ struct StreamOut {
     int y_cs, y2_cs, split, res_cs, act;
 };
 
-template <int DT, bool FRAGS>
+// STORE = false: bias / SiLU / residual / rounding only, the packets come back through frag_out (the row-transposed store below)
+template <int DT, bool FRAGS, bool STORE = true>
 __device__ __forceinline__ void stream_store(const StreamOut& o, const f32x16& acc, int64_t m, bool ok, int cbase, int hi, u32x4* frag_out) {
     u32x2 rv[4] = {};
     const bool res = o.res != nullptr;   // wave-uniform
@@ -54,7 +55,7 @@ __device__ __forceinline__ void stream_store(const StreamOut& o, const f32x16& a
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if constexpr (FRAGS) frag_out[q] = pkt[q];   // the rounded 16-byte packet IS the activation fragment of the chained 1x1 (k16 step 2*tile + q)
-        if (ok) {
+        if (STORE && ok) {
             const int co = cbase + (2 * q + hi) * 8;
             uint16_t* yp;
             if (o.split > 0 && co >= o.split) yp = o.y2 + m * o.y2_cs + (co - o.split);
@@ -64,8 +65,17 @@ __device__ __forceinline__ void stream_store(const StreamOut& o, const f32x16& a
     }
 }
 
+// Row-transposed store of a wave's 32-pixel x (32 * TNW)-cout block (tp_off >= 0): the epilogue packets (lanes l / l + 32 hold
+// adjacent 16 bytes of pixel l & 31: one store instruction would write 32 bytes into each of 32 lines -- measured -11 % of the
+// streaming bandwidth, tools/partial_line_bench.hip) go through a wave-private LDS tile [32 pixels][64 * TNW + 16 bytes] (the
+// 16-byte pad makes the column-wise ds_write_b128 conflict-free) and leave as whole rows: 64 lanes x 16 bytes = 16 / TNW full rows
+// per instruction.  No barrier: writer and reader are the same wave.
+template <int TNW> constexpr int STREAM_TP_PITCH = 64 * TNW + 16;
+template <int TNW> constexpr int STREAM_TP_BYTES = 32 * STREAM_TP_PITCH<TNW>;
+template <int TNW> constexpr bool STREAM_TP_OK = (TNW == 1 || TNW == 2 || TNW == 4);
+
 template <int DT, int TNW, int KS, bool CHAIN>
-__global__ __launch_bounds__(256, 3) void conv1x1_stream_kernel(const ConvArgs a, int ngroups, int ncb) {
+__global__ __launch_bounds__(256, 3) void conv1x1_stream_kernel(const ConvArgs a, int ngroups, int ncb, int tp_off) {
     typedef typename Mfma<DT>::frag frag;
     // The whole folded weight matrix (<= 128 x 128 x 2 B = 32 KiB) and the bias sit in LDS in FRAGMENT order: fragment
     // (cout tile t, k16 step s) is 64 lanes x 16 B contiguous, so a wave's read is one conflict-free 1 KiB sweep.  (Keeping the
@@ -168,6 +178,30 @@ __global__ __launch_bounds__(256, 3) void conv1x1_stream_kernel(const ConvArgs a
                     stream_store<DT, false>(o2, acc2, m, ok, i2 * 32, hi, nullptr);
                 }
             }
+        } else if (STREAM_TP_OK<TNW> && tp_off >= 0 && c0 < a.cout) {   // (blocks past cout exist when cout_pad > cout: never stored, below)
+            constexpr int PITCH = STREAM_TP_PITCH<TNW>, LPR = 4 * TNW, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+            unsigned char* tw = st_sm + tp_off + (threadIdx.x >> 6) * STREAM_TP_BYTES<TNW>;
+#pragma unroll
+            for (int i = 0; i < TNW; ++i) {
+                u32x4 pk[2];
+                stream_store<DT, true, false>(o1, acc[i][0], m, ok, c0 + i * 32, hi, pk);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(tw + frow * PITCH + (i * 4 + 2 * q + hi) * 16) = pk[q];
+            }
+            __builtin_amdgcn_wave_barrier();   // (scheduling fence only: the LDS executes a wave's operations in order)
+            // the wave's whole cout block has ONE destination (the launcher requires split % block width == 0)
+            const bool second = o1.split > 0 && c0 >= o1.split;
+            uint16_t* yb = second ? o1.y2 + (c0 - o1.split) : o1.y + c0;
+            const int ycs = second ? o1.y2_cs : o1.y_cs;
+            const int row_l = lane / LPR, chunk = lane - row_l * LPR;
+#pragma unroll
+            for (int j = 0; j < 2 * TNW; ++j) {
+                const int row = j * RPI + row_l;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tw + row * PITCH + chunk * 16);
+                const int64_t mr = (int64_t)g * 32 + row;
+                if (mr < a.M) *reinterpret_cast<u32x4*>(yb + mr * ycs + chunk * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         } else {
 #pragma unroll
             for (int i = 0; i < TNW; ++i)
@@ -188,6 +222,13 @@ static int launch_stream(const ConvArgs& a0, hipStream_t s) {
     // persistent grid = the blocks that are RESIDENT at once (register count and LDS decide: 3 or 4 per CU for these
     // instantiations), a multiple of ncb.  A fixed 4 blocks per CU left the 158-VGPR instances (3 blocks per CU) with a
     // fourth, non-resident quarter of the grid that started only when the first blocks had finished their whole share.
+    // row-transposed stores: whole cout blocks only (a ragged last block keeps the per-packet stores)
+    static const char* tp_env = getenv("YOLORT_AMD_STREAM_TP");   // A/B: "0" = per-packet stores everywhere
+    int tp_off = -1;
+    if (STREAM_TP_OK<TNW> && a.cout % (32 * TNW) == 0 && !(tp_env && tp_env[0] == '0')) {
+        tp_off = (int)lds;
+        lds += (size_t)4 * STREAM_TP_BYTES<TNW>;
+    }
     const bool chain = a.chain_w != nullptr;
     static size_t occ_lds[2] = {0, 0};
     static int occ_blocks[2] = {0, 0};
@@ -205,8 +246,8 @@ static int launch_stream(const ConvArgs& a0, hipStream_t s) {
     if (blocks > need) blocks = need;
     blocks = cdiv(blocks * 4, ncb * 4) * ncb;             // waves = 4 * blocks: multiple of ncb
     if (blocks < 1) blocks = ncb;
-    if (a.chain_w != nullptr) hipLaunchKernelGGL((conv1x1_stream_kernel<DT, TNW, KS, true>), dim3(blocks), dim3(256), lds, s, a, ngroups, ncb);
-    else hipLaunchKernelGGL((conv1x1_stream_kernel<DT, TNW, KS, false>), dim3(blocks), dim3(256), lds, s, a, ngroups, ncb);
+    if (a.chain_w != nullptr) hipLaunchKernelGGL((conv1x1_stream_kernel<DT, TNW, KS, true>), dim3(blocks), dim3(256), lds, s, a, ngroups, ncb, tp_off);
+    else hipLaunchKernelGGL((conv1x1_stream_kernel<DT, TNW, KS, false>), dim3(blocks), dim3(256), lds, s, a, ngroups, ncb, tp_off);
     return check_launch("conv1x1_stream_kernel");
 }
 
