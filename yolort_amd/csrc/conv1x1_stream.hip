@@ -225,7 +225,9 @@ static int launch_stream(const ConvArgs& a0, hipStream_t s) {
     // row-transposed stores: whole cout blocks only (a ragged last block keeps the per-packet stores)
     static const char* tp_env = getenv("YOLORT_AMD_STREAM_TP");   // A/B: "0" = per-packet stores everywhere
     int tp_off = -1;
-    if (STREAM_TP_OK<TNW> && a.cout % (32 * TNW) == 0 && !(tp_env && tp_env[0] == '0')) {
+    // (and only while the block stays inside the 64 KiB of dynamic LDS a launch gets without the opt-in: 128 -> 128 with
+    // 128-wide blocks would not)
+    if (STREAM_TP_OK<TNW> && a.cout % (32 * TNW) == 0 && lds + (size_t)4 * STREAM_TP_BYTES<TNW> <= 64 * 1024 && !(tp_env && tp_env[0] == '0')) {
         tp_off = (int)lds;
         lds += (size_t)4 * STREAM_TP_BYTES<TNW>;
     }
