@@ -138,6 +138,39 @@ int ymi_conv2d(const ymi_conv_desc* d, void* stream);
 int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_pad, int32_t* ktab_host);
 
 /* ------------------------------------------------------------------------------------------
+ * A whole C3 block in one launch: y = cv3(cat(m(cv1(x)), cv2(x))), m = ONE Bottleneck
+ * x1 + cv2(cv1(x1)) -- yolort/v5/models/common.py:172-173 (C3.forward) with :115-116
+ * (Bottleneck.forward) inlined, every Conv being :69-70 with BatchNorm folded into W/bias.
+ * Intermediates never reach memory; results are bit-identical to the separate ymi_conv2d launches.
+ * This build holds ONE instance: c_in = 64, c_hidden = 32, c_out = 64, one shortcut Bottleneck
+ * (yolov5s backbone.body.2); anything else returns YMI_EINVAL.  OPT-IN (YOLORT_AMD_FUSE_C3=1 on the
+ * Python side): written at the end of round 2 without GPU time left, see DESIGN.md section 4.
+ *   x / y       NHWC views (n,h,w,c_in) / (n,h,w,c_out), 16-bit, pixel strides x_cstride / y_cstride
+ *   w12, b12    cv1 and cv2 stacked along cout: packed [>= 2*c_hidden][k12_pad] like ymi_conv_desc.w
+ *               (rows 0..c_hidden-1 = cv1), fp32 bias [2*c_hidden]
+ *   wm1, bm1    Bottleneck.cv1 (1x1, c_hidden -> c_hidden);  wm2, bm2  Bottleneck.cv2 (3x3 pad 1,
+ *               k = (ky*3 + kx)*c_hidden + c);  w3, b3  cv3 (1x1, 2*c_hidden -> c_out)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ymi_c3_desc {
+    const void* x;
+    void* y;
+    const void* w12;
+    const float* b12;
+    const void* wm1;
+    const float* bm1;
+    const void* wm2;
+    const float* bm2;
+    const void* w3;
+    const float* b3;
+    int32_t n, h, w, x_cstride, y_cstride, dtype;
+    int32_t c_in, c_hidden, c_out, n_bottlenecks, shortcut;
+    int32_t k12_pad, km1_pad, km2_pad, k3_pad;
+    int32_t reserved0;
+} ymi_c3_desc;
+
+int ymi_c3_fused(const ymi_c3_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * SPP max-pool pyramid: given x = channels [0,c) of a (n,h,w,4c) concat buffer, writes
  * maxpool5(x), maxpool9(x), maxpool13(x) (stride 1, "same", -inf padding) into channel slices
  * [c,2c) [2c,3c) [3c,4c).  Replaces common.py:183-187 (SPP.forward: cat([x]+[m(x) for m in self.m])).
@@ -252,6 +285,7 @@ typedef struct ymi_plan ymi_plan;
 ymi_plan* ymi_plan_create(void);
 void ymi_plan_destroy(ymi_plan* p);
 int ymi_plan_add_conv(ymi_plan* p, const ymi_conv_desc* d);
+int ymi_plan_add_c3_fused(ymi_plan* p, const ymi_c3_desc* d);
 int ymi_plan_add_spp_pool(ymi_plan* p, void* buf, int n, int h, int w, int c, int cstride, int dtype);
 int ymi_plan_add_upsample2x(ymi_plan* p, const void* x, int x_cstride, int n, int h, int w, int c, void* y,
                             int y_cstride, int dtype);

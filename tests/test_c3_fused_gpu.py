@@ -1,0 +1,118 @@
+"""First GPU run of the fused one-Bottleneck C3 launch (csrc/c3_fused32.hip, ymi_c3_fused).
+
+The kernel was written at the end of round 2 with no GPU time left: it cross-compiles (122 VGPRs, no scratch, 63.5 KB of LDS)
+and its book-keeping agrees with a lane-level model (tools/c3_fused_index_model.py), but it has NOT run on an MI355X yet.  It is
+opt-in in the product (YOLORT_AMD_FUSE_C3=1) and these tests are opt-in too (YOLORT_AMD_EXPERIMENTAL=1) so that an unverified
+kernel cannot take the GPU suite down; tools/gpu_calls/gpu_r3_c3fused.sh runs them and the A/B bench.
+
+What they pin once enabled: the fused launch is BIT-IDENTICAL to the three separate launches (same rounding points, same k
+order on top of the bias) on ragged sizes, channel-slice views and both 16-bit types, agrees with the fp32 torch evaluation of
+common.py:172-173 / :115-116 within the per-launch tolerance, and leaves yolov5s detections unchanged end to end.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("YOLORT_AMD_EXPERIMENTAL", "0") != "1", reason="unverified kernel: set YOLORT_AMD_EXPERIMENTAL=1")]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from yolort_amd import _lib
+    _lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _make_c3(seed):
+    from yolort_amd.v5.models.common import C3
+    torch.manual_seed(seed)
+    m = C3(64, 64, n=1).eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.6, 1.4)
+                mod.bias.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m
+
+
+def _torch_c3(m, x, dtype):
+    """fp32 evaluation of the reference forward on operands rounded like the HIP path rounds them (weights after the BN fold,
+    every layer output to the storage dtype)"""
+    def conv(c, t, res=None):
+        bn = c.bn
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = (c.conv.weight * scale.view(-1, 1, 1, 1)).to(dtype).float()
+        b = bn.bias - bn.running_mean * scale
+        y = F.silu(F.conv2d(t, w, b, c.conv.stride, c.conv.padding))
+        if res is not None:
+            y = y + res
+        return y.to(dtype).float()
+    with torch.no_grad():
+        x1, x2 = conv(m.cv1, x), conv(m.cv2, x)
+        v = conv(m.m[0].cv2, conv(m.m[0].cv1, x1), res=x1)
+        return conv(m.cv3, torch.cat([v, x2], 1))
+
+
+def _run(dev, m, x, dtype, fuse, x_extra=0, y_extra=0):
+    from yolort_amd import engine
+    plan = engine.Plan(dev, dtype)
+    plan.fuse_c3 = fuse
+    n, _, h, w = x.shape
+    xb = plan.alloc(n, h, w, 64 + x_extra, zero=True)
+    xv = xb.slice_c(x_extra // 2, 64) if x_extra else xb
+    xv.as_tensor().copy_(x.permute(0, 2, 3, 1).to(dev, dtype))
+    yb = plan.alloc(n, h, w, 64 + y_extra, zero=True)
+    yv = yb.slice_c(y_extra // 2, 64) if y_extra else yb
+    m.emit(plan, xv, out=yv, name="c3")
+    assert (plan.num_ops == 1) == fuse
+    plan.run()
+    torch.cuda.synchronize()
+    return yv.as_tensor().cpu(), yb.as_tensor().cpu()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 16, 16), (2, 21, 37), (1, 5, 3), (3, 33, 16), (2, 160, 160), (9, 48, 80)])
+def test_fused_c3_equals_the_separate_launches(dev, dtype, shape):
+    n, h, w = shape
+    m = _make_c3(seed=h * 7 + w)
+    x = torch.randn(n, 64, h, w, generator=torch.Generator().manual_seed(n + h)).to(dtype).float()
+    sep, _ = _run(dev, m, x, dtype, fuse=False)
+    fused, _ = _run(dev, m, x, dtype, fuse=True)
+    assert torch.equal(sep.view(torch.int16), fused.view(torch.int16)), f"{(sep.float() - fused.float()).abs().max().item()} max difference"
+    ref = _torch_c3(m, x, dtype).permute(0, 2, 3, 1)
+    tol = 4e-3 if dtype == torch.float16 else 3.2e-2   # five chained layers: twice the per-launch bound of test_ops_gpu.py
+    err = (fused.float() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+def test_fused_c3_on_channel_slice_views(dev):
+    """input and output as 64-channel slices of wider buffers (pixel strides 96 / 128): nothing outside the slice is written"""
+    m = _make_c3(seed=5)
+    x = torch.randn(2, 64, 19, 23, generator=torch.Generator().manual_seed(9)).half().float()
+    sep, _ = _run(dev, m, x, torch.float16, fuse=False, x_extra=32, y_extra=64)
+    fused, whole = _run(dev, m, x, torch.float16, fuse=True, x_extra=32, y_extra=64)
+    assert torch.equal(sep.view(torch.int16), fused.view(torch.int16))
+    assert whole[..., :32].abs().max().item() == 0 and whole[..., 96:].abs().max().item() == 0
+
+
+def test_yolov5s_detections_unchanged_by_the_fused_c3(dev, monkeypatch):
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_s_r60"
+    imgs = [im.to(dev) for im in synth_images(2, 640, 640, seed=3)]
+    outs = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("YOLORT_AMD_FUSE_C3", knob)
+        model = YOLOv5(arch=arch, size=(640, 640), score_thresh=0.25)
+        model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.4))
+        model = model.to(dev).half().eval()
+        outs.append(model.predict(imgs))
+        torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        for k in ("scores", "labels", "boxes"):
+            assert torch.equal(a[k], b[k]), k

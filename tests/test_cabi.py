@@ -64,13 +64,14 @@ def test_struct_layouts_match_header(lib):
     """ctypes mirrors of the descriptors must have the C layout (sizes computed from the header with gcc)"""
     import subprocess, tempfile
     from yolort_amd import _lib
-    src = '#include <stdio.h>\n#include "yolort_amd.h"\nint main(){printf("%zu %zu\\n", sizeof(ymi_conv_desc), sizeof(ymi_post_desc));return 0;}\n'
+    src = '#include <stdio.h>\n#include "yolort_amd.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(ymi_conv_desc), sizeof(ymi_post_desc), sizeof(ymi_c3_desc));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
         out = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()
     assert int(out[0]) == C.sizeof(_lib.ConvDesc)
     assert int(out[1]) == C.sizeof(_lib.PostDesc)
+    assert int(out[2]) == C.sizeof(_lib.C3Desc)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 3, first call: the kernels written blind at the end of round 2 (no GPU minutes were left).
+#   1. the gated tests of the fused C3 launch (bit-identity with the separate launches, torch fp32, end to end)
+#   2. only if they pass: same-box A/B of the C2 bench, three interleaved repeats, plus the per-op table with the knob on
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r03a
+mkdir -p $O
+YOLORT_AMD_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_c3_fused_gpu.py -m gpu -x -q --timeout 500 -p no:cacheprovider > $O/pytest_c3fused.log 2>&1
+rc=$?
+tail -15 $O/pytest_c3fused.log
+[ $rc -ne 0 ] && { echo "fused C3: tests FAILED (rc $rc) -- no A/B"; exit 0; }
+run() { lbl=$1; shift
+  env "$@" timeout 200 python bench.py --config c2 --no-cpu-baseline --steps 200 2>/dev/null | grep '^{"metric' | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$lbl: c2', d['value'], d['ms_per_step'], d['roofline']['conv_ms_per_step'], d.get('parity'))"
+}
+for rep in 1 2 3; do
+run "separate launches" YOLORT_AMD_FUSE_C3=0
+run "fused C3" YOLORT_AMD_FUSE_C3=1
+done
+YOLORT_AMD_FUSE_C3=1 timeout 200 python bench.py --config c2 --no-cpu-baseline --steps 50 --per-op $O/perop_c3fused.json > $O/bench_c3fused.log 2>&1
+python - <<'P'
+import json
+for r in json.load(open('gpurun_out/r03a/perop_c3fused.json'))[:8]:
+    print(r)
+P

@@ -42,6 +42,16 @@ class ConvDesc(C.Structure):
     ]
 
 
+class C3Desc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("w12", C.c_void_p), ("b12", C.c_void_p), ("wm1", C.c_void_p), ("bm1", C.c_void_p),
+        ("wm2", C.c_void_p), ("bm2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("x_cstride", C.c_int32), ("y_cstride", C.c_int32), ("dtype", C.c_int32),
+        ("c_in", C.c_int32), ("c_hidden", C.c_int32), ("c_out", C.c_int32), ("n_bottlenecks", C.c_int32), ("shortcut", C.c_int32),
+        ("k12_pad", C.c_int32), ("km1_pad", C.c_int32), ("km2_pad", C.c_int32), ("k3_pad", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
 ABI_VERSION = 2   # include/yolort_amd.h YMI_ABI_VERSION
 POST_EXACT_FULL = 1
 
@@ -72,6 +82,8 @@ _SIGS = {
     "ymi_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ymi_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ymi_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ymi_c3_fused": (C.c_int, [C.POINTER(C3Desc), C.c_void_p]),
+    "ymi_plan_add_c3_fused": (C.c_int, [C.c_void_p, C.POINTER(C3Desc)]),
     "ymi_conv_stem_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "ymi_conv_build_ktab": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "ymi_spp_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -52,19 +52,21 @@ bool head_anchor_split() {
 }
 
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);
+int c3_fused_launch(const ymi_c3_desc* d, hipStream_t s);
 int postprocess_launch(const ymi_post_desc* d, hipStream_t s);
 int post_begin_launch(const ymi_post_desc* d, hipStream_t s);
 int post_finish_launch(const ymi_post_desc* d, hipStream_t s);
 int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s);
 int conv_head_decode_group_launch(const ymi_conv_desc* descs, int n_levels, const ymi_post_desc* post, hipStream_t s);
 
-enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_HEAD_GROUP, OP_POST_FINISH };
+enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_HEAD_GROUP, OP_POST_FINISH, OP_C3_FUSED };
 
 struct Op {
     OpKind kind;
     ymi_conv_desc conv;
     ymi_conv_desc convs[YMI_MAX_LEVELS];   // OP_HEAD_GROUP: one head per pyramid level
     ymi_post_desc post;
+    ymi_c3_desc c3;
     // generic small-op arguments
     const void* x;
     void* y;
@@ -82,6 +84,7 @@ static int run_op(const Op& op, hipStream_t s) {
         case OP_HEAD_DECODE: return conv_head_decode_launch(&op.conv, &op.post, op.i[0], s);
         case OP_HEAD_GROUP: return conv_head_decode_group_launch(op.convs, op.i[0], &op.post, s);
         case OP_POST_FINISH: return post_finish_launch(&op.post, s);
+        case OP_C3_FUSED: return c3_fused_launch(&op.c3, s);
     }
     set_error("unknown op kind");
     return YMI_EINVAL;
@@ -133,6 +136,17 @@ extern "C" int ymi_plan_add_conv(ymi_plan* p, const ymi_conv_desc* d) {
     memset(&op, 0, sizeof(op));
     op.kind = OP_CONV;
     op.conv = *d;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_c3_fused(ymi_plan* p, const ymi_c3_desc* d) {
+    YMI_REQUIRE(p && d, "ymi_plan_add_c3_fused: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_C3_FUSED;
+    op.c3 = *d;
     p->ops.push_back(op);
     drop_graph(p);
     return (int)p->ops.size() - 1;

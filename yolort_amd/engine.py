@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SILU, ConvDesc, PostDesc, YmiError, check, dtype_code
+from ._lib import ACT_NONE, ACT_SILU, C3Desc, ConvDesc, PostDesc, YmiError, check, dtype_code
 
 
 def _round_up(v: int, m: int) -> int:
@@ -170,6 +170,10 @@ class Plan:
         # +-0 end to end (the pixel-major producer tiles it needs cost what the saved launch gains) -> off by default
         self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
+        # a whole one-Bottleneck C3 of 32 hidden channels in ONE launch (csrc/c3_fused32.hip; yolov5s backbone.body.2).  OPT-IN:
+        # written at the end of round 2 with no GPU time left -- cross-compiled and checked against a lane-level index model
+        # (tools/c3_fused_index_model.py) only; tests/test_c3_fused_gpu.py and tools/gpu_calls/gpu_r3_c3fused.sh are its first GPU run
+        self.fuse_c3 = os.environ.get("YOLORT_AMD_FUSE_C3", "0") == "1"
         # Tile selection is DETERMINISTIC: a pinned per-(shape, dtype) table for gfx950 committed in-tree
         # (yolort_amd/data/tiles_gfx950.json, produced by tools/tune_tiles.py on an MI355X) and, for shapes it does not hold,
         # the library's shape heuristic (tile 0).  Different tiles accumulate K in different orders, so a timing-based choice
@@ -184,6 +188,7 @@ class Plan:
         self.fp32 = dtype == torch.float32
         if self.fp32:
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
+            self.fuse_c3 = False
 
     def __del__(self):
         try:
@@ -388,6 +393,36 @@ class Plan:
         Plan._TUNE_CACHE[key] = best
         Plan._TUNE_TIMES[tile_key_str(key[:-1], key[-1])] = {str(t): round(times[t] * 1e3, 2) for t in ok}   # us per candidate (tools/tune_tiles.py)
         return best
+
+    def c3_fused(self, x: View, pc12: PackedConv, pcm1: PackedConv, pcm2: PackedConv, pc3: PackedConv, out: Optional[View] = None,
+                 name: str = "c3.fused") -> View:
+        """cv3(cat(x1 + m.cv2(m.cv1(x1)), cv2(x))), x1 = cv1(x), in ONE launch (ymi_c3_fused; reference common.py:172-173 with
+        :115-116 inlined).  `pc12` = cv1 and cv2 stacked along cout (C3.packed_pair).  Bit-identical to the separate launches."""
+        c_ = pcm1.cout
+        if out is None:
+            out = self.alloc(x.n, x.h, x.w, pc3.cout)
+        if ((pc12.kh, pc12.kw, pcm1.kh, pcm1.kw, pcm2.kh, pcm2.kw, pc3.kh, pc3.kw) != (1, 1, 1, 1, 3, 3, 1, 1) or pc12.cin != x.c or pc12.cout != 2 * c_
+                or pcm1.cin != c_ or pcm2.cin != c_ or pcm2.cout != c_ or pc3.cin != 2 * c_ or (out.n, out.h, out.w, out.c) != (x.n, x.h, x.w, pc3.cout)
+                or out.dtype != self.dtype or x.dtype != self.dtype):
+            raise YmiError(f"{name}: the packed convolutions do not form a one-Bottleneck C3 over the given views")
+        d = C3Desc()
+        d.x, d.y = x.ptr, out.ptr
+        d.w12, d.b12, d.wm1, d.bm1 = pc12.w.data_ptr(), pc12.bias.data_ptr(), pcm1.w.data_ptr(), pcm1.bias.data_ptr()
+        d.wm2, d.bm2, d.w3, d.b3 = pcm2.w.data_ptr(), pcm2.bias.data_ptr(), pc3.w.data_ptr(), pc3.bias.data_ptr()
+        d.n, d.h, d.w, d.x_cstride, d.y_cstride, d.dtype = x.n, x.h, x.w, x.cs, out.cs, dtype_code(self.dtype)
+        d.c_in, d.c_hidden, d.c_out, d.n_bottlenecks, d.shortcut = x.c, c_, pc3.cout, 1, 1
+        d.k12_pad, d.km1_pad, d.km2_pad, d.k3_pad = pc12.k_pad, pcm1.k_pad, pcm2.k_pad, pc3.k_pad
+        self.keep.extend([pc12, pcm1, pcm2, pc3, d])
+        npix, esz = x.n * x.h * x.w, 2
+        convs = [(x.c, 2 * c_, 1), (c_, c_, 1), (c_, c_, 9), (2 * c_, pc3.cout, 1)]   # cv1 + cv2 (two reference convs reading x), m.cv1, m.cv2, cv3
+        flops = sum(2.0 * npix * ci * co * k for ci, co, k in convs)
+        # algorithmic bytes as SURVEY.md 8d counts them: every reference conv reads its input once and writes its output once
+        nbytes = float(npix * esz * (2 * x.c + 2 * c_ + 2 * c_ + 2 * c_ + 2 * c_ + pc3.cout) + esz * sum(ci * co * k for ci, co, k in convs))
+        self.io[self.num_ops] = {"name": name, "x": x, "y": out, "y2": None, "split": 0, "up2": None, "res": None, "chain_y": None, "chain_x2": None,
+                                 "stride": (1, 1), "pad": (0, 0), "fused_c3": True}
+        self._record(self.lib.ymi_plan_add_c3_fused(self.handle, C.byref(d)), name, kind="conv", flops=flops, bytes=nbytes, ref_convs=5, tile=-1,
+                     shape=f"C3 {x.c}->{pc3.cout} hidden {c_} n1 {x.h}x{x.w}")
+        return out
 
     def spp_pool(self, buf: View, c: int, name: str = "spp_pool") -> None:
         assert buf.c == 4 * c

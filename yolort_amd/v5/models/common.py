@@ -116,8 +116,18 @@ class C3(HipModule):
 
     def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "c3") -> View:
         c_ = self.cv1.conv.out_channels
-        cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
         nb = len(self.m)
+        # opt-in (YOLORT_AMD_FUSE_C3=1, engine.Plan.fuse_c3): the whole block in one launch when it is the instance
+        # csrc/c3_fused32.hip holds -- 64 -> 64, one shortcut Bottleneck of 32 hidden channels (yolov5s backbone.body.2)
+        if (getattr(plan, "fuse_c3", False) and not plan.use_v1 and nb == 1 and c_ == 32 and x.c == 64 and self.cv3.conv.out_channels == 64
+                and isinstance(self.m[0], Bottleneck) and self.m[0].add and self.m[0].cv1.conv.kernel_size == (1, 1) and self.m[0].cv2.conv.kernel_size == (3, 3)
+                and self.m[0].cv2.conv.groups == 1
+                and all(isinstance(c.act, nn.SiLU) for c in (self.cv1, self.cv2, self.cv3, self.m[0].cv1, self.m[0].cv2))
+                and (out is None or out.cs % 8 == 0) and x.cs % 8 == 0):
+            b0 = self.m[0]
+            return plan.c3_fused(x, self.packed_pair(plan.dtype, plan.device, x.c), b0.cv1.packed(plan.dtype, plan.device, c_),
+                                 b0.cv2.packed(plan.dtype, plan.device, c_), self.cv3.packed(plan.dtype, plan.device, 2 * c_), out=out, name=name + ".fused")
+        cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
         fuse = (not plan.use_v1) and c_ % 8 == 0 and nb >= 1 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
         t0 = None
         if fuse:
