@@ -1,6 +1,6 @@
 """First GPU run of the fused one-Bottleneck C3 launch (csrc/c3_fused32.hip, ymi_c3_fused).
 
-The kernel was written at the end of round 2 with no GPU time left: it cross-compiles (122 VGPRs, no scratch, 63.5 KB of LDS)
+The kernel was written at the end of round 2 with no GPU time left: it cross-compiles (122 VGPRs, no scratch, 63.75 KB of LDS)
 and its book-keeping agrees with a lane-level model (tools/c3_fused_index_model.py), but it has NOT run on an MI355X yet.  It is
 opt-in in the product (YOLORT_AMD_FUSE_C3=1) and these tests are opt-in too (YOLORT_AMD_EXPERIMENTAL=1) so that an unverified
 kernel cannot take the GPU suite down; tools/gpu_calls/gpu_r3_c3fused.sh runs them and the A/B bench.

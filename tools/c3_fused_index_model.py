@@ -12,7 +12,7 @@ v_mfma_f32_32x32x16 are the ones every other conv kernel of this repo is tested 
 import numpy as np
 
 TH = TW = 16
-PW, PPIX, HG, SLOT = 18, 324, 11, 80
+PW, PPIX, HG, SLOT, ROW = 18, 324, 11, 80, 1536
 F3_W12, F3_WM1, F3_WM2, F3_W3 = 0, 8 * 1024, 10 * 1024, 28 * 1024
 F3_BIAS = 36 * 1024
 F3_PATCH = F3_BIAS + 6 * 128
@@ -102,7 +102,7 @@ def run_kernel(x, w12, b12, wm1, bm1, wm2, bm2, w3, b3):
     """x: (n, h, w, 64); packed weights [rows][k] (K-major, k = (ky*3 + kx)*32 + c for the 3x3); returns y (n, h, w, 64)"""
     n, h, w, _ = x.shape
     y = np.full((n, h, w, 64), np.nan)
-    lds = Lds(F3_PATCH + PPIX * SLOT)
+    lds = Lds(F3_PATCH + (TH + 2) * ROW)
     # ---- resident weights / biases ----
     def fill(base, wt, nfrag, ks):
         for f in range(nfrag):
@@ -161,18 +161,19 @@ def run_kernel(x, w12, b12, wm1, bm1, wm2, bm2, w3, b3):
                             acc2 = mfma(wfrag(F3_WM1, s), as_frag(p1[s]), acc2)
                         pu = silu_pack_subtile(acc2, None, False)
                         pu[:, ~inside] = 0.0
-                        return q, pu
+                        po = np.where(q < PPIX, pr * ROW + pc * SLOT + HI * 16, -1)
+                        return po, pu
 
                     q0, pu0 = halo(wave)
                     for gq in range(2):
                         for l in range(64):
-                            pend.append((F3_PATCH + q0[l] * SLOT + (2 * gq + HI[l]) * 16, as_frag(pu0[gq])[l]))
+                            pend.append((F3_PATCH + q0[l] + gq * 32, as_frag(pu0[gq])[l]))
                     if wave + 8 < HG:
                         q1, pu1 = halo(wave + 8)
                         for gq in range(2):
                             for l in range(64):
-                                if q1[l] < PPIX:
-                                    pend.append((F3_PATCH + q1[l] * SLOT + (2 * gq + HI[l]) * 16, as_frag(pu1[gq])[l]))
+                                if q1[l] >= 0:
+                                    pend.append((F3_PATCH + q1[l] + gq * 32, as_frag(pu1[gq])[l]))
                     acc0, acc1 = bias_acc(0), bias_acc(1)
                     for s in range(4):
                         acc0 = mfma(wfrag(F3_W12, s), xb[s], acc0)
@@ -183,10 +184,10 @@ def run_kernel(x, w12, b12, wm1, bm1, wm2, bm2, w3, b3):
                     lds.write16(byte, v)
                 for wave in range(8):
                     pr_o, pc_o, oy, ox, okc, pk1, pk2 = waves[wave]
-                    pc_base = F3_PATCH + (pr_o * PW + pc_o) * SLOT + HI * 16
+                    pc_base = F3_PATCH + pr_o * ROW + pc_o * SLOT + HI * 16
                     acc = bias_acc(3)
                     for ts in range(18):
-                        off = (((ts >> 1) // 3) * PW + (ts >> 1) % 3) * SLOT + (ts & 1) * 32
+                        off = ((ts >> 1) // 3) * ROW + ((ts >> 1) % 3) * SLOT + (ts & 1) * 32
                         fa = np.stack([lds.read16(pc_base[l] + off) for l in range(64)])
                         acc = mfma(wfrag(F3_WM2, ts), fa, acc)
                     rv = unswap_packets(pk1)

@@ -40,19 +40,22 @@ struct C3Args {
 constexpr int F3_TH = 16, F3_TW = 16;             // output tile: 256 pixels, one 32-pixel group (2 rows) per wave
 constexpr int F3_PW = F3_TW + 2, F3_PPIX = (F3_TH + 2) * (F3_TW + 2);   // halo patch 18 x 18 = 324 slots
 constexpr int F3_HG = (F3_PPIX + 31) / 32;        // 11 halo pixel groups: waves 0-2 take two
-// LDS map (bytes): weight fragments [frag index][64 lanes] x 16 B, biases [tile][4 groups][2 halves] x 16 B, patch [slot] x 80 B
+// LDS map (bytes): weight fragments [frag index][64 lanes] x 16 B, biases [tile][4 groups][2 halves] x 16 B, patch [18 rows][18 slots x 80 B, padded to 1536 B]
 constexpr int F3_W12 = 0;                         // (tile t in {cv1, cv2}, k16 step s): t*4 + s        8 KiB
 constexpr int F3_WM1 = F3_W12 + 8 * 1024;         // (step s): s                                        2 KiB
 constexpr int F3_WM2 = F3_WM1 + 2 * 1024;         // (tap, k16 half): tap*2 + ks                       18 KiB
 constexpr int F3_W3 = F3_WM2 + 18 * 1024;         // (tile t, step s): t*4 + s                          8 KiB
 constexpr int F3_BIAS = F3_W3 + 8 * 1024;         // tiles: 0, 1 = cv1, cv2; 2 = m.cv1; 3 = m.cv2; 4, 5 = cv3
 constexpr int F3_PATCH = F3_BIAS + 6 * 128;
-// patch slot = 64 B of channels + 16 B pad: with an 80-byte pitch 16 consecutive slots fall on 16 different 16-byte bank slots
-// (5 q mod 16) -- what the XOR swizzle of conv3x3_c32.hip achieves -- and every tap's fragment address is the lane's base plus a
-// CONSTANT (an instruction offset instead of nine address registers); the column-wise ds_write_b128 of phase A is conflict-free
-// (8-lane groups: 5 q mod 8).
-constexpr int F3_SLOT = 80;
-constexpr int F3_LDS = F3_PATCH + F3_PPIX * F3_SLOT;   // 63 552 B: two blocks per CU
+// patch slot = 64 B of channels + 16 B pad, patch row = 18 slots padded to 1536 B: with an 80-byte slot pitch 16 consecutive slots
+// fall on 16 different 16-byte bank slots (5 c mod 16), and with a row pitch that is a multiple of 256 B the two half-rows a
+// ds_read_b128 lane group spans (columns 0-3, 12-15 of one output row and 4-11 of the next) still cover 16 different ones: the
+// fragment reads are conflict-free (4.0 LDS cycles per read in the bank model of MI355X_MICROARCH.md; 8.0 with a dense
+// 18-slot row, which is also what the XOR swizzle of conv3x3_c32.hip gets: its measured 38 % conflict share).  Every tap's
+// fragment address is the lane's base plus a CONSTANT (an instruction offset instead of nine address registers).  The
+// column-wise ds_write_b128 of phase A cost 10.4 instead of 8 LDS cycles at row changes (2-4 writes per wave and tile).
+constexpr int F3_SLOT = 80, F3_ROW = 1536;
+constexpr int F3_LDS = F3_PATCH + (F3_TH + 2) * F3_ROW;   // 65 280 B: two blocks per CU, no opt-in needed (<= 64 KiB)
 
 template <int DT>
 __device__ __forceinline__ typename Mfma<DT>::frag as_frag(const u32x4& p) {
@@ -119,9 +122,9 @@ __global__ __launch_bounds__(512, 4) void c3_fused32_kernel(const C3Args a, int 
     }
 
     // ---- phase C geometry (fixed per lane): output pixel p = wave*32 + frow -> (r, c); tap (dy, dx), k16 half ks reads
-    //      patch + ((r + dy)*18 + c + dx)*80 + ks*32 + hi*16 ----
+    //      patch + (r + dy)*1536 + (c + dx)*80 + ks*32 + hi*16 ----
     const int pr_o = (wave * 32 + frow) / F3_TW, pc_o = (wave * 32 + frow) % F3_TW;
-    const unsigned char* const pc_base = patch + (pr_o * F3_PW + pc_o) * F3_SLOT + hi * 16;
+    const unsigned char* const pc_base = patch + pr_o * F3_ROW + pc_o * F3_SLOT + hi * 16;
     const bool two = wave + 8 < F3_HG;   // wave-uniform: this wave has a second halo group (halo group hg = wave + 8*j covers patch slots hg*32 + frow)
     const u32x2 none[4] = {};
     __syncthreads();   // the resident weights are written
@@ -149,10 +152,11 @@ __global__ __launch_bounds__(512, 4) void c3_fused32_kernel(const C3Args a, int 
         // the 3x3 it costs registers this kernel does not have -- 128 per lane at four waves per SIMD.)
         int fr = frow;
         asm volatile("" : "+v"(fr));
-        auto halo_load = [&](int hg, int& q, bool& inside) {
-            q = hg * 32 + fr;
+        auto halo_load = [&](int hg, int& po, bool& inside) {   // po: byte offset of the lane's patch slot, -1 past the patch
+            const int q = hg * 32 + fr;
             const int qc = q < F3_PPIX ? q : F3_PPIX - 1;
             const int pr = qc / F3_PW, pc = qc - pr * F3_PW;
+            po = q < F3_PPIX ? pr * F3_ROW + pc * F3_SLOT + hi * 16 : -1;
             const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
             inside = q < F3_PPIX && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
             const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = ix < 0 ? 0 : (ix < a.w ? ix : a.w - 1);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(512, 4) void c3_fused32_kernel(const C3Args a, int 
                 pu[1] = z;
             }
         };
-        int q0, q1 = F3_PPIX;
+        int q0, q1 = -1;
         bool in0, in1 = false;
         u32x4 pu0[2], pu1[2];
         halo_load(wave, q0, in0);
@@ -202,10 +206,10 @@ __global__ __launch_bounds__(512, 4) void c3_fused32_kernel(const C3Args a, int 
         if (two) halo_compute(in1, pu1);
         __syncthreads();   // every wave is done reading the previous tile's patch
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq) *reinterpret_cast<u32x4*>(patch + q0 * F3_SLOT + (2 * gq + hi) * 16) = pu0[gq];   // (q0 <= 255: always a patch slot)
-        if (two && q1 < F3_PPIX) {
+        for (int gq = 0; gq < 2; ++gq) *reinterpret_cast<u32x4*>(patch + q0 + gq * 32) = pu0[gq];   // (first group: slots 0 .. 255, always inside the patch)
+        if (two && q1 >= 0) {
 #pragma unroll
-            for (int gq = 0; gq < 2; ++gq) *reinterpret_cast<u32x4*>(patch + q1 * F3_SLOT + (2 * gq + hi) * 16) = pu1[gq];
+            for (int gq = 0; gq < 2; ++gq) *reinterpret_cast<u32x4*>(patch + q1 + gq * 32) = pu1[gq];
         }
         __syncthreads();   // the patch is complete
 
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512, 4) void c3_fused32_kernel(const C3Args a, int 
             f32x16 acc = bias_acc(bl, 3, hi);
 #pragma unroll
             for (int ts = 0; ts < 18; ++ts) {   // (tap, k16 half)
-                const frag fa = *reinterpret_cast<const frag*>(pc_base + (((ts >> 1) / 3) * F3_PW + (ts >> 1) % 3) * F3_SLOT + (ts & 1) * 32);
+                const frag fa = *reinterpret_cast<const frag*>(pc_base + ((ts >> 1) / 3) * F3_ROW + ((ts >> 1) % 3) * F3_SLOT + (ts & 1) * 32);
                 acc = Mfma<DT>::run(wm2l[ts * 64 + lane], fa, acc);
             }
             u32x2 rv[4];
