@@ -1,0 +1,224 @@
+"""Kernel LOGIC on the CPU: selected HIP kernels compiled unchanged for the host on a lane-accurate runtime (tests/hipsim/hipsim.h:
+every lane a fiber, MFMA / permlane32_swap / readfirstlane / barriers / LDS-DMA restated) and driven through ctypes.
+
+Why it exists: round 2 ended with kernels written after the GPU minutes were spent (csrc/c3_fused32.hip, the row-transposed stores
+of csrc/conv1x1_stream.hip had only a partial GPU suite behind them).  This suite executes their real source -- every address,
+lane mapping, barrier and store -- and compares
+  * the fused one-Bottleneck C3 launch with the THREE SEPARATE LAUNCHES it replaces (streaming 1x1 with the chained 1x1, the
+    resident-weights 3x3 with the shortcut, the streaming 1x1 over the concat), bit for bit, and with torch fp32;
+  * the streaming 1x1 kernel (row-transposed stores, channel split, chained 1x1, residual, ragged pixel counts) with torch fp32.
+The simulator is test infrastructure: the product never links it, and nothing here replaces the `-m gpu` parity tests (hardware
+exp2 / rcp, timing, the real MFMA adder tree are not modelled).
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_DIR = os.path.join(ROOT, "tests", "hipsim")
+
+
+def _clangxx():
+    for c in (os.environ.get("HIPSIM_CXX"), "/opt/rocm/lib/llvm/bin/clang++", shutil.which("amdclang++"), shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.fixture(scope="module")
+def sim():
+    cxx = _clangxx()
+    if cxx is None:
+        pytest.skip("no host clang++ (ext_vector_type / _Float16 / __bf16 sources need clang)")
+    out_dir = os.path.join(SIM_DIR, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libhipsim_kernels.so")
+    srcs = [os.path.join(SIM_DIR, f) for f in ("sim_kernels.cpp", "hipsim.h", "hipsim.cpp")] + \
+           [os.path.join(ROOT, "yolort_amd", "csrc", f) for f in ("c3_fused32.hip", "conv1x1_stream.hip", "conv3x3_c32.hip", "conv_common.hpp", "common.hpp")] + \
+           [os.path.join(ROOT, "include", "yolort_amd.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run([cxx, "-std=c++17", "-O1", "-fPIC", "-shared", "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-psabi",
+                        "-o", so, os.path.join(SIM_DIR, "sim_kernels.cpp")], check=True)
+    lib = C.CDLL(so)
+    from yolort_amd._lib import C3Desc, ConvDesc
+    lib.sim_c3_fused.argtypes, lib.sim_c3_fused.restype = [C.POINTER(C3Desc)], C.c_int
+    lib.sim_conv2d.argtypes, lib.sim_conv2d.restype = [C.POINTER(ConvDesc)], C.c_int
+    lib.sim_last_error.restype = C.c_char_p
+    lib.sim_max_lds.restype = C.c_int
+    return lib
+
+
+def _check(lib, rc):
+    assert rc == 0, lib.sim_last_error().decode()
+
+
+class Buf:
+    """NHWC host buffer with the 256-byte zero tail plan buffers carry (source of out-of-image operand chunks)"""
+
+    def __init__(self, n, h, w, c, dtype, fill=None):
+        self.n, self.h, self.w, self.c, self.cs, self.off = n, h, w, c, c, 0
+        numel = (n * h * w * c + 7) // 8 * 8
+        self.t = torch.zeros(numel + 128, dtype=dtype)
+        self.numel = numel
+        if fill is not None:
+            self.t[: n * h * w * c] = fill.reshape(-1).to(dtype)
+
+    def view(self):
+        return torch.as_strided(self.t, (self.n, self.h, self.w, self.c), (self.h * self.w * self.cs, self.w * self.cs, self.cs, 1), self.off)
+
+    def slice_c(self, c0, c):
+        v = Buf.__new__(Buf)
+        v.__dict__.update(self.__dict__)
+        v.off, v.c = self.off + c0, c
+        return v
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 2 * self.off
+
+    @property
+    def zeros(self):
+        return self.t.data_ptr() + 2 * self.numel
+
+
+def _conv_desc(x, pc, y, tile, k=1, pad=0, res=None, y2=None, split=0, chain=None):
+    from yolort_amd._lib import ACT_SILU, ConvDesc, dtype_code
+    d = ConvDesc()
+    d.x, d.w, d.bias, d.y = x.ptr, pc.w.data_ptr(), pc.bias.data_ptr(), y.ptr
+    d.res = None if res is None else res.ptr
+    d.n, d.h, d.w_in, d.cin, d.x_cstride = x.n, x.h, x.w, pc.cin, x.cs
+    d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = x.h, x.w, pc.cout, pc.cout_pad, y.cs
+    d.res_cstride = 0 if res is None else res.cs
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = k, k, 1, 1, pad, pad, pc.k_pad
+    d.act, d.dtype, d.out_dtype, d.tile = ACT_SILU, dtype_code(pc.dtype), dtype_code(pc.dtype), tile
+    if y2 is not None:
+        d.y2, d.y2_cstride, d.cout_split = y2.ptr, y2.cs, split
+    if chain is not None:
+        pc2, tv = chain
+        d.chain_w, d.chain_bias, d.chain_y, d.chain_cout, d.chain_y_cstride = pc2.w.data_ptr(), pc2.bias.data_ptr(), tv.ptr, pc2.cout, tv.cs
+    d.zeros = x.zeros
+    return d
+
+
+def _make_c3(seed):
+    from yolort_amd.v5.models.common import C3
+    torch.manual_seed(seed)
+    m = C3(64, 64, n=1).eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.6, 1.4)
+                mod.bias.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m
+
+
+def _torch_conv(c, t, dtype, res=None):
+    bn = c.bn
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    w = (c.conv.weight * scale.view(-1, 1, 1, 1)).to(dtype).float()
+    y = F.silu(F.conv2d(t, w, bn.bias - bn.running_mean * scale, c.conv.stride, c.conv.padding))
+    if res is not None:
+        y = y + res
+    return y.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+# (5, 112, 128): 280 tiles on a grid of 256 persistent blocks -- the second trip through the tile loop (patch reuse behind the barriers)
+@pytest.mark.parametrize("shape", [(1, 16, 16), (2, 21, 37), (1, 5, 3), (1, 33, 16), (5, 112, 128)])
+def test_fused_c3_equals_the_three_launches_and_torch(sim, dtype, shape):
+    from yolort_amd._lib import C3Desc, dtype_code
+    n, h, w = shape
+    if n * h * w > 20000 and dtype == torch.bfloat16:
+        pytest.skip("the large case runs once (fp16)")
+    m = _make_c3(seed=h * 7 + w)
+    cpu = torch.device("cpu")
+    x = torch.randn(n, 64, h, w, generator=torch.Generator().manual_seed(n + h)).to(dtype).float()
+    xb = Buf(n, h, w, 64, dtype, fill=x.permute(0, 2, 3, 1))
+    pc12 = m.packed_pair(dtype, cpu, 64)
+    b0 = m.m[0]
+    pcm1, pcm2, pc3 = b0.cv1.packed(dtype, cpu, 32), b0.cv2.packed(dtype, cpu, 32), m.cv3.packed(dtype, cpu, 64)
+
+    # ---- the three launches C3.emit records by default (tiles of the pinned table for this layer) ----
+    y1, t0, cat, out_sep = Buf(n, h, w, 32, dtype), Buf(n, h, w, 32, dtype), Buf(n, h, w, 64, dtype), Buf(n, h, w, 64, dtype)
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc12, y1, 121, y2=cat.slice_c(32, 32), split=32, chain=(pcm1, t0)))))
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(t0, pcm2, cat.slice_c(0, 32), 131, k=3, pad=1, res=y1))))
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(cat, pc3, out_sep, 122))))
+
+    # ---- the fused launch ----
+    out_f = Buf(n, h, w, 64, dtype)
+    d = C3Desc()
+    d.x, d.y = xb.ptr, out_f.ptr
+    d.w12, d.b12, d.wm1, d.bm1 = pc12.w.data_ptr(), pc12.bias.data_ptr(), pcm1.w.data_ptr(), pcm1.bias.data_ptr()
+    d.wm2, d.bm2, d.w3, d.b3 = pcm2.w.data_ptr(), pcm2.bias.data_ptr(), pc3.w.data_ptr(), pc3.bias.data_ptr()
+    d.n, d.h, d.w, d.x_cstride, d.y_cstride, d.dtype = n, h, w, 64, 64, dtype_code(dtype)
+    d.c_in, d.c_hidden, d.c_out, d.n_bottlenecks, d.shortcut = 64, 32, 64, 1, 1
+    d.k12_pad, d.km1_pad, d.km2_pad, d.k3_pad = pc12.k_pad, pcm1.k_pad, pcm2.k_pad, pc3.k_pad
+    _check(sim, sim.sim_c3_fused(C.byref(d)))
+    assert sim.sim_max_lds() <= 64 * 1024   # no launch of this test may need the > 64 KiB opt-in
+
+    a, b = out_sep.view(), out_f.view()
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"fused vs separate launches: max difference {(a.float() - b.float()).abs().max().item()}"
+    with torch.no_grad():
+        x1, x2 = _torch_conv(m.cv1, x, dtype), _torch_conv(m.cv2, x, dtype)
+        v = _torch_conv(b0.cv2, _torch_conv(b0.cv1, x1, dtype), dtype, res=x1)
+        ref = _torch_conv(m.cv3, torch.cat([v, x2], 1), dtype).permute(0, 2, 3, 1)
+    tol = 4e-3 if dtype == torch.float16 else 3.2e-2
+    err = (b.float() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("tile", [121, 122, 124])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_streaming_1x1_kernel_logic(sim, dtype, tile):
+    """conv1x1_stream.hip as the plan uses it: whole cout blocks (row-transposed stores), a ragged last pixel group, channel-slice
+    output views, residual, and -- tile 121 / 122 -- the channel split with the chained 1x1"""
+    from yolort_amd import engine
+    cpu = torch.device("cpu")
+    tnw = tile - 120
+    g = torch.Generator().manual_seed(tile)
+    for cin, cout, n, h, w, residual in [(64, 32 * tnw, 2, 9, 7, True), (32, 64 * tnw, 1, 13, 5, False), (128, 32 * tnw, 1, 6, 11, False)]:
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        ref = F.silu(F.conv2d(x, wt, bias))
+        pc = engine.PackedConv(wt, bias, None, dtype, cpu)
+        xb = Buf(n, h, w, cin, dtype, fill=x.permute(0, 2, 3, 1))
+        wide = Buf(n, h, w, cout + 64, dtype)           # the output is a channel slice of a wider buffer
+        yv = wide.slice_c(32, cout)
+        rb = None
+        if residual:
+            r = torch.randn(n, cout, h, w, generator=g).to(dtype).float()
+            ref = ref + r
+            rb = Buf(n, h, w, cout, dtype, fill=r.permute(0, 2, 3, 1))
+        _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc, yv, tile, res=rb))))
+        got = yv.view().float().permute(0, 3, 1, 2)
+        tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        w_all = wide.view().float()
+        assert w_all[..., :32].abs().max().item() == 0 and w_all[..., 32 + cout:].abs().max().item() == 0   # nothing outside the slice
+    if tnw <= 2:   # channel split + chained 1x1 (cv1 | cv2 of a C3 with the first Bottleneck's 1x1 riding along)
+        k1 = 32 * tnw
+        x = torch.randn(2, 64, 7, 9, generator=g).to(dtype).float()
+        wt = (torch.randn(2 * k1, 64, 1, 1, generator=g) / 8).to(dtype).float()
+        bias = torch.randn(2 * k1, generator=g) * 0.1
+        w2 = (torch.randn(k1, k1, 1, 1, generator=g) / np.sqrt(k1)).to(dtype).float()
+        b2 = torch.randn(k1, generator=g) * 0.1
+        full = F.silu(F.conv2d(x, wt, bias)).to(dtype).float()
+        chained = F.silu(F.conv2d(full[:, :k1], w2, b2))
+        pc, pc2 = engine.PackedConv(wt, bias, None, dtype, cpu), engine.PackedConv(w2, b2, None, dtype, cpu)
+        xb = Buf(2, 7, 9, 64, dtype, fill=x.permute(0, 2, 3, 1))
+        y1, cat, tb = Buf(2, 7, 9, k1, dtype), Buf(2, 7, 9, 2 * k1, dtype), Buf(2, 7, 9, k1, dtype)
+        _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc, y1, tile, y2=cat.slice_c(k1, k1), split=k1, chain=(pc2, tb)))))
+        tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+        assert torch.equal(y1.view().float(), full[:, :k1].permute(0, 2, 3, 1)) or (y1.view().float() - full[:, :k1].permute(0, 2, 3, 1)).abs().max().item() <= tol * full.abs().max().item()
+        assert (cat.view().float()[..., k1:] - full[:, k1:].permute(0, 2, 3, 1)).abs().max().item() <= tol * max(1.0, full.abs().max().item())
+        assert cat.view().float()[..., :k1].abs().max().item() == 0   # the first half of the concat belongs to the Bottleneck
+        assert (tb.view().float() - chained.permute(0, 2, 3, 1)).abs().max().item() <= 2 * tol * max(1.0, chained.abs().max().item())

@@ -22,8 +22,9 @@
 // intermediate is rounded to the storage dtype exactly where the unfused launches round it and every accumulation runs in
 // the same k order on top of the bias, so the result is BIT-IDENTICAL to the three-launch form (tests/test_c3_fused_gpu.py).
 //
-// Status (end of round 2): written and cross-compiled without a GPU at hand -- opt-in only (YOLORT_AMD_FUSE_C3=1), never
-// taken by default; the A/B script is tools/gpu_calls/gpu_r3_c3fused.sh.
+// Status (end of round 2): written without a GPU at hand -- cross-compiled for gfx950 and EXECUTED on the CPU simulator
+// (tests/hipsim, tests/test_hipsim_kernels.py: bit-identical to the three launches), not yet timed.  Opt-in only
+// (YOLORT_AMD_FUSE_C3=1), never taken by default; the A/B script is tools/gpu_calls/gpu_r3_c3fused.sh.
 #include "conv_common.hpp"
 
 namespace ymi {
