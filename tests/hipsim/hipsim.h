@@ -116,6 +116,30 @@ inline f32x16_t mfma_32x32x16(Frag a, Frag b, f32x16_t c) {
     return c;
 }
 
+// every lane's value of v (all 64 lanes of the wave must take part: wave-uniform control flow around the call)
+template <class T>
+inline void wave_gather(T v, T* out64) {
+    static_assert(sizeof(T) <= 64, "deposit slot");
+    unsigned char* d = wave_deposit();
+    memcpy(d + lane_id() * 64, &v, sizeof(T));
+    wave_sync();
+    for (int l = 0; l < 64; ++l) memcpy(&out64[l], d + l * 64, sizeof(T));
+    wave_sync();
+}
+template <class T>
+inline T shfl(T v, int src) {
+    T all[64];
+    wave_gather(v, all);
+    return all[src & 63];
+}
+inline unsigned long long ballot(bool p) {
+    int all[64];
+    wave_gather((int)p, all);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) m |= (unsigned long long)(all[l] != 0) << l;
+    return m;
+}
+
 inline void global_load_lds16(const void* g, void* lds_wave_uniform) { memcpy((unsigned char*)lds_wave_uniform + lane_id() * 16, g, 16); }
 
 template <class K, class... A>
@@ -144,6 +168,8 @@ inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, s
     return hipSuccess;
 }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+struct hipFuncAttributes { int numRegs; size_t sharedSizeBytes; int maxDynamicSharedSizeBytes; };
+inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { memset(a, 0, sizeof(*a)); return hipSuccess; }
 
 // ---- device builtins ----
 #define __syncthreads() hipsim::block_sync()
@@ -156,7 +182,23 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 // lanes of a wave do NOT run in lockstep here (each runs to its next collective): an exchange through LDS inside one wave needs a
 // sync between its writes and its reads -- the kernels carry __builtin_amdgcn_wave_barrier() (a scheduling fence on the GPU) there
 #define __builtin_amdgcn_wave_barrier() hipsim::wave_sync()
+#define __builtin_amdgcn_s_barrier() hipsim::block_sync()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipsim::global_load_lds16((const void*)(g), (void*)(l))
+#define __shfl(v, src, ...) hipsim::shfl(v, (int)(src))
+#define __shfl_xor(v, mask, ...) hipsim::shfl(v, hipsim::lane_id() ^ (int)(mask))
+#define __ballot(p) hipsim::ballot((bool)(p))
+#define __builtin_amdgcn_readlane(v, l) hipsim::shfl(v, (int)(l))
+#define __popcll(x) __builtin_popcountll(x)
+#define __popc(x) __builtin_popcount(x)
+#define __fmul_rn(a, b) ((float)(a) * (float)(b))   /* the simulator build uses -ffp-contract=off: no fused multiply-add */
+#define __fadd_rn(a, b) ((float)(a) + (float)(b))
+#define __fsub_rn(a, b) ((float)(a) - (float)(b))
+#define __fdiv_rn(a, b) ((float)(a) / (float)(b))
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }   // one thread runs at a time
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+#define __builtin_amdgcn_kernarg_segment_ptr() ((const void*)nullptr)
 #define __umulhi(a, b) ((unsigned)(((uint64_t)(unsigned)(a) * (uint64_t)(unsigned)(b)) >> 32))
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

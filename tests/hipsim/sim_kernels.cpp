@@ -2,6 +2,8 @@
 // this file with the host clang++ and drives it through ctypes; nothing here is part of libyolort_amd.so).
 //   sim_c3_fused   -> ymi_c3_fused                        (csrc/c3_fused32.hip)
 //   sim_conv2d     -> conv1x1_stream_launch (tiles 121-124) / conv3x3_c32_launch (tile 131), the launches the fused C3 replaces
+//                   (+ sim_kernels_gemm.cpp, a second translation unit so that the two compile in parallel: the 8-wave and 4-wave
+//                   LDS-halo 3x3 kernels, the 8-wave implicit GEMM and a few LDS-DMA implicit-GEMM tiles)
 // All pointers are host memory.
 #include "hipsim.h"
 #include "hipsim.cpp"
@@ -24,11 +26,14 @@ constexpr int SIM_LDS = 160 * 1024;
 alignas(16) unsigned char f3_sm[SIM_LDS];
 alignas(16) unsigned char st_sm[SIM_LDS];
 alignas(16) unsigned char c32_sm[SIM_LDS];
+alignas(16) uint16_t smem[SIM_LDS / 2];
 }  // namespace ymi
 
 #include "../../yolort_amd/csrc/c3_fused32.hip"
 #include "../../yolort_amd/csrc/conv1x1_stream.hip"
 #include "../../yolort_amd/csrc/conv3x3_c32.hip"
+
+int sim_conv2d_gemm(const ymi::ConvArgs& a, const ymi_conv_desc* d);
 
 namespace {
 // descriptor -> kernel arguments: the fields conv_igemm.hip's fill_conv_args sets (that file is not part of this build)
@@ -59,6 +64,7 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     sim_fill(d, a);
     if (d->tile >= 121 && d->tile <= 124) return ymi::conv1x1_stream_launch(a, d->dtype, d->out_dtype, d->tile - 120, nullptr);
     if (d->tile == 131) return ymi::conv3x3_c32_launch(a, d->dtype, d->out_dtype, 1, nullptr);
+    if ((d->tile >= 11 && d->tile <= 119)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
     ymi::set_error("sim_conv2d: tile %d is not part of the simulator build", d->tile);
     return YMI_EINVAL;
 }

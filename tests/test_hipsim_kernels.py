@@ -39,12 +39,16 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    srcs = [os.path.join(SIM_DIR, f) for f in ("sim_kernels.cpp", "hipsim.h", "hipsim.cpp")] + \
-           [os.path.join(ROOT, "yolort_amd", "csrc", f) for f in ("c3_fused32.hip", "conv1x1_stream.hip", "conv3x3_c32.hip", "conv_common.hpp", "common.hpp")] + \
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2"]   # three translation units, compiled in parallel (~70 s on 8 cores)
+    csrc = os.path.join(ROOT, "yolort_amd", "csrc")
+    srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
+           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
            [os.path.join(ROOT, "include", "yolort_amd.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run([cxx, "-std=c++17", "-O1", "-fPIC", "-shared", "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-psabi",
-                        "-o", so, os.path.join(SIM_DIR, "sim_kernels.cpp")], check=True)
+        flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-psabi"]
+        procs = [subprocess.Popen([cxx, *flags, "-c", os.path.join(SIM_DIR, u + ".cpp"), "-o", os.path.join(out_dir, u + ".o")]) for u in units]
+        assert all(p.wait() == 0 for p in procs), "the simulator build failed"
+        subprocess.run([cxx, "-shared", "-o", so] + [os.path.join(out_dir, u + ".o") for u in units], check=True)
     lib = C.CDLL(so)
     from yolort_amd._lib import C3Desc, ConvDesc
     lib.sim_c3_fused.argtypes, lib.sim_c3_fused.restype = [C.POINTER(C3Desc)], C.c_int
@@ -87,15 +91,15 @@ class Buf:
         return self.t.data_ptr() + 2 * self.numel
 
 
-def _conv_desc(x, pc, y, tile, k=1, pad=0, res=None, y2=None, split=0, chain=None):
+def _conv_desc(x, pc, y, tile, k=1, pad=0, res=None, y2=None, split=0, chain=None, stride=1):
     from yolort_amd._lib import ACT_SILU, ConvDesc, dtype_code
     d = ConvDesc()
     d.x, d.w, d.bias, d.y = x.ptr, pc.w.data_ptr(), pc.bias.data_ptr(), y.ptr
     d.res = None if res is None else res.ptr
     d.n, d.h, d.w_in, d.cin, d.x_cstride = x.n, x.h, x.w, pc.cin, x.cs
-    d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = x.h, x.w, pc.cout, pc.cout_pad, y.cs
+    d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = y.h, y.w, pc.cout, pc.cout_pad, y.cs
     d.res_cstride = 0 if res is None else res.cs
-    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = k, k, 1, 1, pad, pad, pc.k_pad
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = k, k, stride, stride, pad, pad, pc.k_pad
     d.act, d.dtype, d.out_dtype, d.tile = ACT_SILU, dtype_code(pc.dtype), dtype_code(pc.dtype), tile
     if y2 is not None:
         d.y2, d.y2_cstride, d.cout_split = y2.ptr, y2.cs, split
@@ -222,3 +226,66 @@ def test_streaming_1x1_kernel_logic(sim, dtype, tile):
         assert (cat.view().float()[..., k1:] - full[:, k1:].permute(0, 2, 3, 1)).abs().max().item() <= tol * max(1.0, full.abs().max().item())
         assert cat.view().float()[..., :k1].abs().max().item() == 0   # the first half of the concat belongs to the Bottleneck
         assert (tb.view().float() - chained.permute(0, 2, 3, 1)).abs().max().item() <= 2 * tol * max(1.0, chained.abs().max().item())
+
+
+def _run_conv(sim, dtype, tile, n, cin, cout, h, w, k, s, residual=False, seed=0):
+    """one convolution through the simulator against torch fp32 on the same rounded operands (bound of tests/test_ops_gpu.py)"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(seed)
+    p = k // 2
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).to(dtype).float()
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x, wt, bias, s, p))
+    ho, wo = ref.shape[2], ref.shape[3]
+    pc = engine.PackedConv(wt, bias, None, dtype, torch.device("cpu"))
+    xb = Buf(n, h, w, cin, dtype, fill=x.permute(0, 2, 3, 1))
+    wide = Buf(n, ho, wo, cout + 32, dtype)
+    yv = wide.slice_c(16, cout)
+    rb = None
+    if residual:
+        r = torch.randn(n, cout, ho, wo, generator=g).to(dtype).float()
+        ref = ref + r
+        rb = Buf(n, ho, wo, cout, dtype, fill=r.permute(0, 2, 3, 1))
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc, yv, tile, k=k, pad=p, res=rb, stride=s))))
+    got = yv.view().float().permute(0, 3, 1, 2)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (tile, cin, cout, k, s)
+    w_all = wide.view().float()
+    assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + cout:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("cout", [32, 64])
+def test_resident_weights_3x3_kernel_logic(sim, stride, cout):
+    """conv3x3_c32.hip (tile 131): both strides (parity-split patch columns), ragged maps, the shortcut"""
+    for dtype, (n, h, w) in [(torch.float16, (2, 13, 21)), (torch.bfloat16, (1, 8, 16)), (torch.float16, (1, 5, 7))]:
+        _run_conv(sim, dtype, 131, n, 32, cout, h, w, 3, stride, residual=(stride == 1 and cout == 32), seed=cout + stride)
+
+
+@pytest.mark.parametrize("tile,cout", [(91, 128), (92, 64), (93, 64), (94, 32), (95, 128)])
+def test_halo8_3x3_kernel_logic(sim, tile, cout):
+    """conv_halo8.hip: every wave layout; one and two 32-channel chunks (single / double patch buffer), ragged maps, the shortcut"""
+    _run_conv(sim, torch.float16, tile, 2, 64, cout, 9, 12, 3, 1, residual=True, seed=tile)
+    _run_conv(sim, torch.bfloat16, tile, 1, 32, cout, 20, 20, 3, 1, seed=tile + 1)
+
+
+@pytest.mark.parametrize("tile,cout", [(31, 128), (32, 64), (33, 32), (35, 64), (37, 128)])
+def test_halo4_3x3_kernel_logic(sim, tile, cout):
+    """conv3x3_halo.hip (4-wave LDS-halo kernel)"""
+    _run_conv(sim, torch.float16, tile, 2, 64, cout, 11, 9, 3, 1, residual=True, seed=tile)
+
+
+@pytest.mark.parametrize("tile,cout", [(111, 128), (112, 64), (114, 32), (116, 128), (115, 256)])
+def test_igemm8_kernel_logic(sim, tile, cout):
+    """conv_igemm8.hip (8 waves, 64-deep steps): pointwise and strided 3x3 forms"""
+    _run_conv(sim, torch.float16, tile, 2, 64, cout, 10, 13, 1, 1, seed=tile)
+    _run_conv(sim, torch.bfloat16, tile, 1, 64, cout, 12, 10, 3, 2, seed=tile + 1)
+
+
+@pytest.mark.parametrize("tile,cout", [(12, 64), (21, 128), (24, 128), (27, 64), (61, 128), (64, 128), (66, 128)])
+def test_igemm_v2_kernel_logic(sim, tile, cout):
+    """conv_igemm_impl.hpp (4-wave LDS-DMA implicit GEMM): the tiles the yolov5s table uses, 1x1 / 3x3 / strided 3x3"""
+    _run_conv(sim, torch.float16, tile, 2, 64, cout, 10, 13, 1, 1, residual=True, seed=tile)
+    _run_conv(sim, torch.float16, tile, 1, 32, cout, 12, 10, 3, 2, seed=tile + 1)
+    _run_conv(sim, torch.bfloat16, tile, 1, 64, cout, 9, 9, 3, 1, seed=tile + 2)
