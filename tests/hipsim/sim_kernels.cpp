@@ -64,7 +64,7 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     sim_fill(d, a);
     if (d->tile >= 121 && d->tile <= 124) return ymi::conv1x1_stream_launch(a, d->dtype, d->out_dtype, d->tile - 120, nullptr);
     if (d->tile == 131) return ymi::conv3x3_c32_launch(a, d->dtype, d->out_dtype, 1, nullptr);
-    if ((d->tile >= 11 && d->tile <= 119)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
+    if ((d->tile >= 11 && d->tile <= 119) || (d->tile >= 141 && d->tile <= 159)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
     ymi::set_error("sim_conv2d: tile %d is not part of the simulator build", d->tile);
     return YMI_EINVAL;
 }

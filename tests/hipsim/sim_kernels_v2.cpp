@@ -24,6 +24,11 @@ int sim_v2(const ymi::ConvArgs& a, bool is1x1, int tile) {
         case 61: return launch_v2<DT, DT, 128, 128, 64, 64, 4, true>(a, is1x1, nullptr);
         case 64: return launch_v2<DT, DT, 64, 128, 32, 64, 4, true>(a, is1x1, nullptr);
         case 66: return launch_v2<DT, DT, 256, 128, 128, 64, 3, true>(a, is1x1, nullptr);
+        // the same tiles with row-transposed stores (StoreEpilogueTP)
+        case 141: return launch_v2<DT, DT, 256, 64, 64, 64, 3, false, true>(a, is1x1, nullptr);
+        case 142: return launch_v2<DT, DT, 128, 128, 64, 64, 2, false, true>(a, is1x1, nullptr);
+        case 143: return launch_v2<DT, DT, 256, 128, 128, 64, 3, true, true>(a, is1x1, nullptr);
+        case 144: return launch_v2<DT, DT, 128, 128, 64, 64, 4, true, true>(a, is1x1, nullptr);
         default: break;
     }
     set_error("sim_conv2d: implicit-GEMM tile %d is not instantiated in the simulator build", tile);

@@ -116,3 +116,35 @@ def test_yolov5s_detections_unchanged_by_the_fused_c3(dev, monkeypatch):
     for a, b in zip(*outs):
         for k in ("scores", "labels", "boxes"):
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("tile,base,cout", [(141, 12, 64), (142, 21, 128), (143, 66, 128), (144, 61, 128), (145, 71, 128), (151, 111, 128), (152, 112, 64), (155, 115, 256)])
+def test_row_transposed_store_tiles_equal_their_base_tiles(dev, tile, base, cout):
+    """tiles 141-145 / 151-155 (StoreEpilogueTP: the lean epilogue's packets leave as whole rows through a wave-private LDS tile): the same
+    bits as the tile they derive from.  On the CPU simulator they already are (tests/test_hipsim_kernels.py); this is their first GPU run."""
+    from yolort_amd import engine
+
+    def run(t, dtype, n, cin, h, w, k, s, residual):
+        g = torch.Generator().manual_seed(tile)
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        plan = engine.Plan(dev, dtype)
+        xv = plan.alloc(n, h, w, cin)
+        xv.as_tensor().copy_(x.permute(0, 2, 3, 1).to(dev, dtype))
+        pc = engine.PackedConv(wt, bias, None, dtype, dev)
+        ho, wo = engine.conv_out_hw(h, w, (k, k), (s, s), (k // 2, k // 2))
+        wide = plan.alloc(n, ho, wo, cout + 64, zero=True)
+        rv = None
+        if residual:
+            rv = plan.alloc(n, ho, wo, cout)
+            rv.as_tensor().copy_(torch.randn(n, ho, wo, cout, generator=g).to(dev, dtype))
+        plan.conv(xv, pc, s, k // 2, out=wide.slice_c(32, cout), res=rv, tile=t)
+        plan.run()
+        torch.cuda.synchronize()
+        return wide.as_tensor().cpu()
+
+    for dtype, cfg in [(torch.float16, (2, 64, 37, 29, 1, 1, True)), (torch.bfloat16, (3, 64, 40, 40, 3, 1, False)), (torch.float16, (2, 32, 33, 21, 3, 2, False)),
+                       (torch.float16, (8, 128, 80, 80, 1, 1, False))]:
+        a, b = run(base, dtype, *cfg), run(tile, dtype, *cfg)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), cfg

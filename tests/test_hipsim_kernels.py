@@ -253,6 +253,7 @@ def _run_conv(sim, dtype, tile, n, cin, cout, h, w, k, s, residual=False, seed=0
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (tile, cin, cout, k, s)
     w_all = wide.view().float()
     assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + cout:].abs().max().item() == 0
+    return yv.view().clone()
 
 
 @pytest.mark.parametrize("stride", [1, 2])
@@ -289,3 +290,35 @@ def test_igemm_v2_kernel_logic(sim, tile, cout):
     _run_conv(sim, torch.float16, tile, 2, 64, cout, 10, 13, 1, 1, residual=True, seed=tile)
     _run_conv(sim, torch.float16, tile, 1, 32, cout, 12, 10, 3, 2, seed=tile + 1)
     _run_conv(sim, torch.bfloat16, tile, 1, 64, cout, 9, 9, 3, 1, seed=tile + 2)
+
+
+@pytest.mark.parametrize("tile,base,cout", [(141, 12, 64), (142, 21, 128), (143, 66, 128), (144, 61, 128), (151, 111, 128), (152, 112, 64), (155, 115, 256)])
+def test_row_transposed_store_tiles_equal_their_base_tiles(sim, tile, base, cout):
+    """StoreEpilogueTP (tiles 141-145 / 151-155: opt-in, written at the end of round 2): the same bits as the tile they derive from, through
+    ragged pixel counts (partial last rows), a residual, pointwise and 3x3 forms, both 16-bit types"""
+    for dtype, (n, cin, h, w, k, s_, res) in [(torch.float16, (2, 64, 10, 13, 1, 1, True)), (torch.bfloat16, (1, 64, 9, 9, 3, 1, False)),
+                                             (torch.float16, (1, 32, 12, 10, 3, 2, False))]:
+        a = _run_conv(sim, dtype, base, n, cin, cout, h, w, k, s_, residual=res, seed=tile)
+        b = _run_conv(sim, dtype, tile, n, cin, cout, h, w, k, s_, residual=res, seed=tile)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_row_transposed_store_tile_with_channel_split(sim):
+    """a fused cv1 + cv2 launch through a row-transposed tile: the wave tiles on either side of the split go to their own views"""
+    from yolort_amd import engine
+    dtype, cpu = torch.float16, torch.device("cpu")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 128, 9, 11, generator=g).to(dtype).float()
+    wt = (torch.randn(128, 128, 1, 1, generator=g) / 11).to(dtype).float()
+    bias = torch.randn(128, generator=g) * 0.1
+    pc = engine.PackedConv(wt, bias, None, dtype, cpu)
+    xb = Buf(2, 9, 11, 128, dtype, fill=x.permute(0, 2, 3, 1))
+    outs = []
+    for tile in (21, 142):
+        y1, cat = Buf(2, 9, 11, 64, dtype), Buf(2, 9, 11, 128, dtype)
+        _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc, y1, tile, y2=cat.slice_c(64, 64), split=64))))
+        outs.append((y1.view().clone(), cat.view().clone()))
+    ref = F.silu(F.conv2d(x, wt, bias)).permute(0, 2, 3, 1)
+    assert (outs[1][0].float() - ref[..., :64]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    assert outs[1][1].float()[..., :64].abs().max().item() == 0

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03a
 mkdir -p $O
-YOLORT_AMD_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_c3_fused_gpu.py -m gpu -x -q --timeout 500 -p no:cacheprovider > $O/pytest_c3fused.log 2>&1
+YOLORT_AMD_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_c3_fused_gpu.py -m gpu -q --timeout 500 -p no:cacheprovider > $O/pytest_c3fused.log 2>&1
 rc=$?
 tail -15 $O/pytest_c3fused.log
 [ $rc -ne 0 ] && { echo "fused C3: tests FAILED (rc $rc) -- no A/B"; exit 0; }
@@ -24,4 +24,17 @@ python - <<'P'
 import json
 for r in json.load(open('gpurun_out/r03a/perop_c3fused.json'))[:8]:
     print(r)
+P
+# 3. row-transposed-store tiles (141-145, 151-155): offered to the tuner only under YOLORT_AMD_TUNE_TP=1; re-tune C2 with them (and with the
+#    streaming kernel's row stores, which the committed table predates), then A/B the new table against the committed one
+YOLORT_AMD_TUNE_TP=1 timeout 1200 python tools/tune_tiles.py --out $O/tiles_tp.json yolov5_darknet_pan_s_r60:fp16:32:640 > $O/tune_tp.log 2>&1; tail -2 $O/tune_tp.log | cut -c1-200
+for rep in 1 2 3; do
+run "committed table" A=1
+run "re-tuned with TP tiles" YOLORT_AMD_TILE_TABLE_PATH=$PWD/$O/tiles_tp.json
+done
+python - <<'P'
+import json
+old=json.load(open('yolort_amd/data/tiles_gfx950.json'))['tiles']; new=json.load(open('gpurun_out/r03a/tiles_tp.json'))['tiles']
+for k,v in new.items():
+    if old.get(k)!=v: print(k, old.get(k), '->', v)
 P

@@ -361,6 +361,60 @@ __device__ __forceinline__ bool lean_ok(const ConvArgs& a, int cbase0, int tn) {
     return a.act == YMI_ACT_SILU && cbase0 + 32 * tn <= a.cout && (a.split & 15) == 0 && ((int64_t)a.M + 1) * cs_max * (a.up2 ? 4 : 1) < ((int64_t)1 << 31);
 }
 
+// ROW-TRANSPOSED form of the lean epilogue for wave tiles whose pixel groups are 32 CONSECUTIVE output pixels (the implicit-GEMM
+// kernels: lane l of group j holds pixel mbase + 32 j + (l & 31)).  The lean stores write, per instruction, 32 bytes into each of 32
+// pixels -- measured 11 % below full-line stores on HBM-streaming layers (tools/partial_line_bench.hip).  Here the packets of a
+// pixel group go through a wave-private LDS tile [32 pixels][64 TN + 16 bytes] (the pad keeps the column-wise ds_write_b128
+// conflict-free) and leave as whole rows: 64 lanes x 16 bytes = 16 / TN pixels' complete 64 TN-byte channel ranges per instruction.
+// Same arithmetic as finish_wave_tile_lean (bit-identical results); `tw` is this wave's 32 * (64 TN + 16) bytes of LDS that nobody
+// else touches (the callers put it into the operand ring behind a block barrier).  Opt-in tiles only (141-145, 151-155): written
+// at the end of round 2, executed on the CPU simulator (tests/test_hipsim_kernels.py), not yet timed.
+template <int TN> constexpr int LEAN_TP_PITCH = 64 * TN + 16;
+template <int TN> constexpr int LEAN_TP_BYTES = 32 * LEAN_TP_PITCH<TN>;
+// the wave's 32 TN couts go to ONE destination: no upsampled copy, the channel split not inside the wave's range
+template <int TN>
+__device__ __forceinline__ bool lean_tp_ok(const ConvArgs& a, int cbase0) {
+    return lean_ok(a, cbase0, TN) && !a.up2 && !(a.split > 0 && cbase0 < a.split && cbase0 + 32 * TN > a.split);
+}
+template <int DT, int TN, int TM, bool RES>
+__device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int mbase, int lane, unsigned char* tw) {
+    static_assert(TN == 1 || TN == 2 || TN == 4, "whole rows per store instruction");
+    constexpr int PITCH = LEAN_TP_PITCH<TN>, LPR = 4 * TN, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+    const int hi = lane >> 5, frow = lane & 31;
+    const bool second = a.split > 0 && cbase0 >= a.split;   // wave-uniform
+    char* const yb = second ? reinterpret_cast<char*>(a.y2) + (size_t)(cbase0 - a.split) * 2 : reinterpret_cast<char*>(a.y) + (size_t)cbase0 * 2;
+    const size_t ycs = (size_t)(second ? a.y2_cs : a.y_cs) * 2;
+    const int row_l = lane / LPR, chunk = lane - row_l * LPR;
+    auto pix = [&](int j, int64_t& m, bool& ok) {
+        m = mbase + j * 32 + frow;
+        ok = m < a.M;
+    };
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        u32x2 rv[TN][4] = {};
+        if constexpr (RES) {
+            const LeanPix p = lean_pix(a, j, hi, pix);
+            lean_load_residual<TN>(a, cbase0, p, rv);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            u32x4 o[2];
+            silu_pack_subtile<DT, RES>(acc[i][j], rv[i], o);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(tw + frow * PITCH + (i * 4 + 2 * q + hi) * 16) = o[q];
+        }
+        __builtin_amdgcn_wave_barrier();   // (scheduling fence: the LDS executes one wave's operations in order)
+#pragma unroll
+        for (int jj = 0; jj < 2 * TN; ++jj) {
+            const int row = jj * RPI + row_l;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tw + row * PITCH + chunk * 16);
+            const int64_t mr = (int64_t)mbase + j * 32 + row;
+            if (mr < a.M) *reinterpret_cast<u32x4*>(yb + (size_t)mr * ycs + chunk * 16) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // whole wave tile: TM pixel groups x TN cout groups.  pix(j, m, m_ok) yields the output pixel index of this lane in group j.
 template <int DT, int ODT, int TN, int TM, class PixFn>
 __device__ __forceinline__ void finish_wave_tile(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int hi, PixFn&& pix) {

@@ -28,18 +28,22 @@ extern template int launch_tile_group<0, YMI_F16, YMI_F16>(const ConvArgs&, bool
 extern template int launch_tile_group<1, YMI_F16, YMI_F16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<2, YMI_F16, YMI_F16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<3, YMI_F16, YMI_F16>(const ConvArgs&, bool, int, hipStream_t);
+extern template int launch_tile_group<4, YMI_F16, YMI_F16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<0, YMI_F16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<1, YMI_F16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<2, YMI_F16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<3, YMI_F16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
+extern template int launch_tile_group<4, YMI_F16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<0, YMI_BF16, YMI_BF16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<1, YMI_BF16, YMI_BF16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<2, YMI_BF16, YMI_BF16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<3, YMI_BF16, YMI_BF16>(const ConvArgs&, bool, int, hipStream_t);
+extern template int launch_tile_group<4, YMI_BF16, YMI_BF16>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<0, YMI_BF16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<1, YMI_BF16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<2, YMI_BF16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_tile_group<3, YMI_BF16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
+extern template int launch_tile_group<4, YMI_BF16, YMI_F32>(const ConvArgs&, bool, int, hipStream_t);
 extern template int launch_head_decode<YMI_F16, 1>(const ConvArgs&, const HeadDecodeArgs&, hipStream_t);
 extern template int launch_head_group<YMI_F16, 1>(const HeadGroupArgs&, hipStream_t);
 extern template int launch_head_decode<YMI_F16, 2>(const ConvArgs&, const HeadDecodeArgs&, hipStream_t);
@@ -90,12 +94,14 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile == 41) return conv_stem_launch(a, DT, ODT, s);
     if (tile >= 91 && tile <= 99) return conv_halo8_launch(a, DT, ODT, tile - 90, s);     // 8-wave LDS-halo 3x3 s1 kernel
     if (tile >= 111 && tile <= 119) return conv_igemm8_launch(a, DT, ODT, tile - 110, s);  // 8-wave implicit GEMM, 64-deep steps
+    if (tile >= 151 && tile <= 159) return conv_igemm8_launch(a, DT, ODT, tile - 140, s);  // ... with row-transposed stores (variants 11 .. 19)
     if (tile >= 121 && tile <= 124) return conv1x1_stream_launch(a, DT, ODT, tile - 120, s);   // streaming 1x1 (cin <= 128), no LDS
     if (tile == 131) return conv3x3_c32_launch(a, DT, ODT, 1, s);                              // resident-weights persistent 3x3, cin = 32
     switch (tile_group_of(tile)) {
         case 0: return launch_tile_group<0, DT, ODT>(a, is1x1, tile, s);
         case 1: return launch_tile_group<1, DT, ODT>(a, is1x1, tile, s);
         case 2: return launch_tile_group<2, DT, ODT>(a, is1x1, tile, s);
+        case 4: return launch_tile_group<4, DT, ODT>(a, is1x1, tile, s);
         default: return launch_tile_group<3, DT, ODT>(a, is1x1, tile, s);
     }
 }

@@ -17,7 +17,8 @@
 
 namespace ymi {
 
-template <int DT, int ODT, int BN, int WAVES_M, int RING>
+// TP: row-transposed stores (StoreEpilogueTP, conv_igemm_impl.hpp) -- variants 11 .. 19 = tiles 151 .. 159, opt-in
+template <int DT, int ODT, int BN, int WAVES_M, int RING, bool TP = false>
 __global__ __launch_bounds__(512, RING == 2 ? 2 : 1) void conv_igemm8_kernel(const ConvArgs a) {
     static_assert(RING == 2 || RING == 3, "two- or three-deep stage ring");
     constexpr int WAVES_N = 8 / WAVES_M;
@@ -205,10 +206,15 @@ __global__ __launch_bounds__(512, RING == 2 ? 2 : 1) void conv_igemm8_kernel(con
         slot = slot + 1 == RING ? 0 : slot + 1;
     }
 
-    StoreEpilogue<DT, ODT>{a}(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem);
+    if constexpr (TP) {
+        static_assert(RING * 2 * (256 + BN) * 64 >= 8 * LEAN_TP_BYTES<(BN / (8 / WAVES_M)) / 32>, "the operand ring holds the eight waves' store tiles");
+        StoreEpilogueTP<DT, ODT>{a}(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem);
+    } else {
+        StoreEpilogue<DT, ODT>{a}(acc, m0 + wave_m, n0 + wave_n, lane, wave, smem);
+    }
 }
 
-template <int DT, int ODT, int BN, int WAVES_M, int RING = 2>
+template <int DT, int ODT, int BN, int WAVES_M, int RING = 2, bool TP = false>
 static int launch_igemm8(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, 256);
@@ -218,7 +224,7 @@ static int launch_igemm8(const ConvArgs& a0, hipStream_t s) {
         return YMI_EINVAL;
     }
     size_t lds = (size_t)RING * 2 * (256 + BN) * 64;
-    auto kfn = conv_igemm8_kernel<DT, ODT, BN, WAVES_M, RING>;
+    auto kfn = conv_igemm8_kernel<DT, ODT, BN, WAVES_M, RING, TP>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
     hipLaunchKernelGGL(kfn, dim3(a.nblk_m * a.nblk_n), dim3(512), lds, s, a);
@@ -239,7 +245,19 @@ static int igemm8_variant(const ConvArgs& a, int variant, hipStream_t s) {
         case 7: return launch_igemm8<DT, ODT, 128, 4, 3>(a, s);
         case 8: return launch_igemm8<DT, ODT, 128, 8, 3>(a, s);
         case 9: return launch_igemm8<DT, ODT, 64, 4, 3>(a, s);
-        default: set_error("ymi_conv2d: unknown igemm8 variant %d", variant); return YMI_EINVAL;
+        default: break;
+    }
+    if constexpr (ODT == DT) {   // variants 1 / 2 / 5 with row-transposed stores
+        switch (variant) {
+            case 11: return launch_igemm8<DT, ODT, 128, 4, 2, true>(a, s);
+            case 12: return launch_igemm8<DT, ODT, 64, 4, 2, true>(a, s);
+            case 15: return launch_igemm8<DT, ODT, 256, 4, 2, true>(a, s);
+            default: break;
+        }
+    }
+    {
+        set_error("ymi_conv2d: unknown igemm8 variant %d", variant);
+        return YMI_EINVAL;
     }
 }
 

@@ -528,9 +528,35 @@ struct StoreEpilogue {
     }
 };
 
+// StoreEpilogue with ROW-TRANSPOSED stores (finish_wave_tile_lean_tp, conv_common.hpp): the operand ring is dead once every wave has
+// left the main loop -- one block barrier -- and each wave takes 32 * (64 TN + 16) bytes of it.  Waves outside the lean case (ragged
+// cout, fp32 output, upsampled copy, a chained 1x1, a split inside the wave's range) store as StoreEpilogue does.
+template <int DT, int ODT>
+struct StoreEpilogueTP {
+    const ConvArgs& a;
+    template <int TN, int TM>
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[TN][TM], int mbase, int cbase0, int lane, int wave, uint16_t* smem) const {
+        if constexpr (ODT == DT && (TN == 1 || TN == 2 || TN == 4)) {
+            __syncthreads();   // every wave of the block is done reading the ring (all of them call the epilogue)
+            if (!(a.chain_w != nullptr && cbase0 == 0) && lean_tp_ok<TN>(a, cbase0)) {
+                unsigned char* tw = reinterpret_cast<unsigned char*>(smem) + wave * LEAN_TP_BYTES<TN>;
+                if (a.res != nullptr) finish_wave_tile_lean_tp<DT, TN, TM, true>(a, acc, cbase0, mbase, lane, tw);
+                else finish_wave_tile_lean_tp<DT, TN, TM, false>(a, acc, cbase0, mbase, lane, tw);
+                return;
+            }
+        }
+        StoreEpilogue<DT, ODT>{a}(acc, mbase, cbase0, lane, wave, smem);
+    }
+};
+
 template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs a) {   // >= 2 waves per SIMD: <= 256 VGPR + AGPR
     conv_igemm_v2_body<DT, ODT, BM, BN, WM, WN, STAGES, IS1X1, UTAP, PIPE>(a, StoreEpilogue<DT, ODT>{a}, blockIdx.x);
+}
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool IS1X1, bool UTAP, bool PIPE = false>
+__global__ __launch_bounds__(256, 2) void conv_igemm_v2_tp_kernel(const ConvArgs a) {   // the same tile with row-transposed stores (tiles 141-145)
+    static_assert(STAGES * (BM + BN) * 64 >= 4 * LEAN_TP_BYTES<WN / 32>, "the operand ring holds the four waves' store tiles");
+    conv_igemm_v2_body<DT, ODT, BM, BN, WM, WN, STAGES, IS1X1, UTAP, PIPE>(a, StoreEpilogueTP<DT, ODT>{a}, blockIdx.x);
 }
 
 // ---- detection head with the decode fused into the epilogue (head_decode.hpp): 128 pixels x (3 anchors x 32*TNA rows) ----
@@ -594,7 +620,7 @@ int launch_v2_kernel(K kfn, const ConvArgs& a, size_t lds, dim3 grid, hipStream_
     return check_launch("conv_igemm_v2_kernel");
 }
 
-template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE = false>
+template <int DT, int ODT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE = false, bool TP = false>
 int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, BM);
@@ -606,6 +632,14 @@ int launch_v2(const ConvArgs& a0, bool is1x1, hipStream_t s) {
     const bool utap = (a.cin % 32 == 0) && (a.kh * a.kw <= 32);
     const size_t lds = (size_t)STAGES * (BM + BN) * 64 + ((is1x1 || utap) ? 0 : (size_t)a.k_pad) + 16;
     dim3 grid(a.nblk_m * a.nblk_n);
+    if constexpr (TP) {   // row-transposed stores: the unit-tap and pointwise forms only (what the big-map layers are)
+        if (utap) return launch_v2_kernel(conv_igemm_v2_tp_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, true, PIPE>, a, lds, grid, s);
+        if constexpr (!PIPE) {
+            if (is1x1) return launch_v2_kernel(conv_igemm_v2_tp_kernel<DT, ODT, BM, BN, WM, WN, STAGES, true, false>, a, lds, grid, s);
+        }
+        set_error("ymi_conv2d: the row-transposed-store tiles need cin %% 32 == 0 (or a pointwise convolution)");
+        return YMI_EINVAL;
+    }
     if (utap) return launch_v2_kernel(conv_igemm_v2_kernel<DT, ODT, BM, BN, WM, WN, STAGES, false, true, PIPE>, a, lds, grid, s);
     if constexpr (PIPE) {
         set_error("ymi_conv2d: the software-pipelined tiles need cin %% 32 == 0");
@@ -634,6 +668,7 @@ int launch_cfg(const ConvArgs& a0, bool is1x1, hipStream_t s) {
 // so that the library builds in parallel; conv_igemm.hip only dispatches.
 //   group 0: register-staged kernel (1..5) + 3/4-stage LDS-DMA tiles (11..15)      group 1: 2-stage tiles (21..27)
 //   group 2: software-pipelined 61..70                                              group 3: software-pipelined 71..81
+//   group 4: 141..145 = tiles 12 / 21 / 66 / 61 / 71 with row-transposed stores (opt-in, not in the pinned table yet)
 template <int G, int DT, int ODT>
 int launch_tile_group(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) {
     if constexpr (G == 0) {
@@ -693,11 +728,26 @@ int launch_tile_group(const ConvArgs& a, bool is1x1, int tile, hipStream_t s) {
             default: break;
         }
     }
+    if constexpr (G == 4) {   // tiles 12 / 21 / 66 / 61 / 71 with row-transposed stores (StoreEpilogueTP); 16-bit outputs
+        if constexpr (ODT == DT) {
+            switch (tile) {
+                case 141: return launch_v2<DT, ODT, 256, 64, 64, 64, 3, false, true>(a, is1x1, s);
+                case 142: return launch_v2<DT, ODT, 128, 128, 64, 64, 2, false, true>(a, is1x1, s);
+                case 143: return launch_v2<DT, ODT, 256, 128, 128, 64, 3, true, true>(a, is1x1, s);
+                case 144: return launch_v2<DT, ODT, 128, 128, 64, 64, 4, true, true>(a, is1x1, s);
+                case 145: return launch_v2<DT, ODT, 128, 128, 64, 64, 2, true, true>(a, is1x1, s);
+                default: break;
+            }
+        } else {
+            set_error("ymi_conv2d: the row-transposed-store tiles write the compute dtype");
+            return YMI_EINVAL;
+        }
+    }
     set_error("ymi_conv2d: unknown tile id %d", tile);
     return YMI_EINVAL;
 }
 
-inline int tile_group_of(int tile) { return (tile <= 5 || (tile >= 11 && tile <= 15)) ? 0 : (tile >= 21 && tile <= 27) ? 1 : (tile >= 61 && tile <= 70) ? 2 : 3; }
+inline int tile_group_of(int tile) { return (tile >= 141 && tile <= 149) ? 4 : (tile <= 5 || (tile >= 11 && tile <= 15)) ? 0 : (tile >= 21 && tile <= 27) ? 1 : (tile >= 61 && tile <= 70) ? 2 : 3; }
 
 template <int NA>
 inline size_t head_decode_lds(int tna) {

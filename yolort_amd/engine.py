@@ -341,6 +341,12 @@ class Plan:
         if d.cin % 32 == 0 and d.kh * d.kw <= 32:
             cands = cands + [t + 50 for t in cands]   # the same tiles with the software-pipelined main loop (61..65, 71..77)
             cands = cands + ([69, 70] if d.cout_pad > 32 else []) + ([66, 68] if d.cout_pad >= 128 else [])   # 3-stage / 256-pixel tiles
+        if os.environ.get("YOLORT_AMD_TUNE_TP", "0") == "1" and d.out_dtype == d.dtype and d.y2_mode == 0 and chain is None and d.cin % 32 == 0 and d.kh * d.kw <= 32 and \
+                d.k_pad == d.kh * d.kw * d.cin:
+            # row-transposed-store forms of tiles 12 / 21 / 66 / 61 / 71 and of the 8-wave implicit GEMM (141-145, 151-155): opt-in
+            # candidates (written at the end of round 2, executed on the CPU simulator only: tests/test_hipsim_kernels.py)
+            cands = cands + [t for t, base in ((141, 12), (142, 21), (143, 66), (144, 61), (145, 71)) if base in cands]
+            cands = cands + ([155] if d.cout_pad > 128 else []) + ([151] if d.cout_pad > 64 else []) + ([152] if 32 < d.cout_pad <= 128 else [])
         if d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1 and d.cin % 32 == 0 and d.cin <= 128 and d.k_pad == d.cin and d.out_dtype == d.dtype and d.y2_mode == 0 and d.cout % 32 == 0:
             # streaming 1x1 kernel (conv1x1_stream.hip): variant = cout tiles of 32 per wave; a split / chained conv fixes the block width
             k1 = d.cout_split if d.cout_split > 0 else 0
