@@ -61,10 +61,10 @@ void wave_sync() { bar_wait(g_blk->wave_bar[g_blk->cur >> 6]); }
 void block_sync() { bar_wait(g_blk->block_bar); }
 unsigned char* wave_deposit() { return g_blk->dep[g_blk->cur >> 6].data(); }
 
-void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigned bidx) {
+void run_block(const std::function<void()>& body, dim3 grid, dim3 block, dim3 bidx) {
     const int n = (int)block.x;
-    if (n % 64 != 0 || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) {
-        fprintf(stderr, "hipsim: 1-D launches of whole waves only\n");
+    if (n % 64 != 0 || block.y != 1 || block.z != 1) {
+        fprintf(stderr, "hipsim: 1-D blocks of whole waves only\n");
         abort();
     }
     Block b;
@@ -75,7 +75,7 @@ void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigne
     b.block_bar.n = n;
     b.body = &body;
     g_blk = &b;
-    g_blockIdx = dim3(bidx);
+    g_blockIdx = bidx;
     g_blockDim = block;
     g_gridDim = grid;
     for (int i = 0; i < n; ++i) {
@@ -102,7 +102,7 @@ void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigne
             if (b.lanes[i].done) ++ndone;
         }
         if (!b.progress && ndone < n) {
-            fprintf(stderr, "hipsim: DEADLOCK in block %u -- lanes wait at barriers not every lane reaches (divergent __syncthreads or wave collective)\n", bidx);
+            fprintf(stderr, "hipsim: DEADLOCK in block (%u, %u, %u) -- lanes wait at barriers not every lane reaches (divergent __syncthreads or wave collective)\n", bidx.x, bidx.y, bidx.z);
             abort();
         }
     }

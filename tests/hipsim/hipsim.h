@@ -57,7 +57,7 @@ void yield();
 void wave_sync();                  // every lane of the calling lane's wave
 void block_sync();                 // __syncthreads
 unsigned char* wave_deposit();     // 64 lanes x 64 bytes of exchange space of the calling lane's wave
-void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigned bidx);
+void run_block(const std::function<void()>& body, dim3 grid, dim3 block, dim3 bidx);
 
 inline int lane_id() { return (int)(g_threadIdx.x & 63); }
 
@@ -146,7 +146,9 @@ template <class K, class... A>
 inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
     if ((int)lds > g_max_lds) g_max_lds = (int)lds;
     ++g_launches;
-    for (unsigned b = 0; b < grid.x; ++b) run_block([&]() { kernel(args...); }, grid, block, b);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) run_block([&]() { kernel(args...); }, grid, block, dim3(bx, by, bz));
 }
 
 }  // namespace hipsim
@@ -200,6 +202,9 @@ template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; 
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 #define __builtin_amdgcn_kernarg_segment_ptr() ((const void*)nullptr)
 #define __umulhi(a, b) ((unsigned)(((uint64_t)(unsigned)(a) * (uint64_t)(unsigned)(b)) >> 32))
+// HIP's device-side integer min / max overloads
+template <class T> inline T min(T a, T b) { return b < a ? b : a; }
+template <class T> inline T max(T a, T b) { return a < b ? b : a; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 

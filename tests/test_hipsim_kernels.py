@@ -39,7 +39,7 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2"]   # three translation units, compiled in parallel (~70 s on 8 cores)
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre"]   # translation units, compiled in parallel (~70 s on 8 cores)
     csrc = os.path.join(ROOT, "yolort_amd", "csrc")
     srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
@@ -55,6 +55,9 @@ def sim():
     lib.sim_conv2d.argtypes, lib.sim_conv2d.restype = [C.POINTER(ConvDesc)], C.c_int
     lib.sim_last_error.restype = C.c_char_p
     lib.sim_max_lds.restype = C.c_int
+    lib.ymi_letterbox.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    lib.ymi_spp_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.ymi_upsample2x.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return lib
 
 
@@ -322,3 +325,76 @@ def test_row_transposed_store_tile_with_channel_split(sim):
     assert (outs[1][0].float() - ref[..., :64]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
     assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
     assert outs[1][1].float()[..., :64].abs().max().item() == 0
+
+
+def _sim_letterbox(sim, imgs, size, out_dtype, c_out=4):
+    """the product's host recipe (YOLOTransform.geometry: reference transform.py:53-97, 297-330) + ymi_letterbox on the simulator"""
+    from yolort_amd._lib import YMI_U8_HWC, dtype_code
+    from yolort_amd.models.transform import YOLOTransform
+    tr = YOLOTransform(size, size)
+    (hb, wb), sizes, pads = tr.geometry([tr.image_hw(im) for im in imgs])
+    n = len(imgs)
+    imgs = [im.contiguous() for im in imgs]
+    ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in imgs])
+    geom = (C.c_int32 * (6 * n))()
+    for i, im in enumerate(imgs):
+        h_in, w_in = tr.image_hw(im)
+        geom[6 * i: 6 * i + 6] = [h_in, w_in, sizes[i][0], sizes[i][1], pads[i][0], pads[i][1]]
+    out = torch.full((n, hb, wb, c_out), 7.0, dtype=out_dtype)
+    in_code = YMI_U8_HWC if tr.is_hwc(imgs[0]) else dtype_code(imgs[0].dtype)
+    _check(sim, sim.ymi_letterbox(ptrs, geom, n, in_code, out.data_ptr(), hb, wb, c_out, dtype_code(out_dtype), C.c_float(tr.fill_color), None))
+    return out, sizes
+
+
+@pytest.mark.parametrize("kernel", ["default", "pixel", "tile1", "1", "4"])
+def test_letterbox_kernels_vs_oracle(sim, kernel, monkeypatch):
+    """csrc/preproc_pool.hip on the simulator against the oracle's letterbox (reference transform.py:53-97, 297-330): every kernel variant,
+    the rounding-trap shapes, fp32 / fp16 output, uint8 planar and interleaved input"""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("YOLORT_AMD_LETTERBOX", kernel)
+    shapes = [(135, 101), (60, 80), (90, 160), (47, 63), (100, 37), (81, 60)]
+    imgs = [synth_images(1, h, w, seed=h + w)[0] for h, w in shapes]
+    ref, sizes = O.letterbox(imgs, 96, 96, 32)
+    got, got_sizes = _sim_letterbox(sim, imgs, 96, torch.float32)
+    assert got_sizes == sizes and tuple(got.shape[1:3]) == tuple(ref.shape[2:])
+    assert (got[..., :3].permute(0, 3, 1, 2) - ref).abs().max().item() <= 5e-5 and got[..., 3].abs().max().item() == 0
+    got16, _ = _sim_letterbox(sim, imgs, 96, torch.float16)
+    assert (got16[..., :3].float().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-3
+    u8 = [(im * 255).round().to(torch.uint8) for im in imgs]
+    ref8, _ = O.letterbox([u.float() / 255.0 for u in u8], 96, 96, 32)
+    got8, _ = _sim_letterbox(sim, u8, 96, torch.float32)
+    assert (got8[..., :3].permute(0, 3, 1, 2) - ref8).abs().max().item() <= 5e-5
+    hwc8, _ = _sim_letterbox(sim, [u.permute(1, 2, 0).contiguous() for u in u8], 96, torch.float32)
+    assert torch.equal(hwc8, got8)   # the interleaved ingest equals the planar one bit for bit
+
+
+def test_letterbox_identity_sizes_are_exact(sim):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import synth_images
+    imgs = [synth_images(1, 64, 96, seed=70 + i)[0] for i in range(3)]
+    ref, _ = O.letterbox(imgs, 96, 96, 32)
+    got, _ = _sim_letterbox(sim, imgs, 96, torch.float32)
+    assert torch.equal(got[..., :3].permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("spp_g", ["default", "1"])
+def test_spp_pool_and_upsample_exact(sim, spp_g, monkeypatch):
+    """the SPP max-pool cascade (reference common.py:183-187) and the nearest x2 upsample (path_aggregation_network.py:123) are exact"""
+    monkeypatch.delenv("YOLORT_AMD_SPP_G", raising=False)
+    if spp_g != "default":
+        monkeypatch.setenv("YOLORT_AMD_SPP_G", spp_g)
+    from yolort_amd._lib import YMI_F16
+    x = torch.randn(2, 64, 20, 17, generator=torch.Generator().manual_seed(7)).half()
+    buf = Buf(2, 20, 17, 256, torch.float16)
+    buf.view()[..., :64] = x.permute(0, 2, 3, 1)
+    _check(sim, sim.ymi_spp_pool(buf.ptr, 2, 20, 17, 64, 256, YMI_F16, None))
+    got = buf.view().float().permute(0, 3, 1, 2)
+    for i, k in enumerate((5, 9, 13)):
+        assert torch.equal(got[:, 64 * (i + 1): 64 * (i + 2)], F.max_pool2d(x.float(), k, 1, k // 2)), f"maxpool{k} not exact"
+    up = Buf(2, 40, 34, 96, torch.float16)
+    _check(sim, sim.ymi_upsample2x(buf.ptr, 256, 2, 20, 17, 64, up.slice_c(32, 64).ptr, 96, YMI_F16, None))
+    gu = up.view().float().permute(0, 3, 1, 2)
+    assert torch.equal(gu[:, 32:96], F.interpolate(x.float(), scale_factor=2.0, mode="nearest")) and gu[:, :32].abs().max().item() == 0
