@@ -33,7 +33,9 @@
 #define __global__
 #define __device__
 #define __host__
-#define __shared__
+#ifndef __shared__
+#define __shared__   /* kernels with STATIC __shared__ arrays are built with -D__shared__=static from a copy whose `extern __shared__` lost the keyword (test_hipsim_kernels.py) */
+#endif
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 
@@ -132,6 +134,13 @@ inline T shfl(T v, int src) {
     wave_gather(v, all);
     return all[src & 63];
 }
+template <class T>
+inline T shfl_up(T v, int d) {   // lanes below d keep their own value
+    T all[64];
+    wave_gather(v, all);
+    const int l = lane_id();
+    return l >= d ? all[l - d] : v;
+}
 inline unsigned long long ballot(bool p) {
     int all[64];
     wave_gather((int)p, all);
@@ -169,6 +178,9 @@ inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, s
     *n = e ? atoi(e) : 1;
     return hipSuccess;
 }
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s_, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 struct hipFuncAttributes { int numRegs; size_t sharedSizeBytes; int maxDynamicSharedSizeBytes; };
 inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { memset(a, 0, sizeof(*a)); return hipSuccess; }
@@ -191,6 +203,9 @@ inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { mems
 #define __shfl_xor(v, mask, ...) hipsim::shfl(v, hipsim::lane_id() ^ (int)(mask))
 #define __ballot(p) hipsim::ballot((bool)(p))
 #define __builtin_amdgcn_readlane(v, l) hipsim::shfl(v, (int)(l))
+#define __shfl_up(v, d, ...) hipsim::shfl_up(v, (int)(d))
+#define __ffsll(x) __builtin_ffsll(x)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
 #define __fmul_rn(a, b) ((float)(a) * (float)(b))   /* the simulator build uses -ffp-contract=off: no fused multiply-add */
