@@ -39,9 +39,9 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post"]   # translation units, compiled in parallel (~70 s on 8 cores)
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem"]   # translation units, compiled in parallel (~70 s on 8 cores)
     csrc = os.path.join(ROOT, "yolort_amd", "csrc")
-    srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
+    srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp", "sim_fill.h")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
            [os.path.join(ROOT, "include", "yolort_amd.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
@@ -52,7 +52,7 @@ def sim():
             text = f.read()
         with open(os.path.join(out_dir, "postprocess.sim.hip"), "w") as f:
             f.write(text.replace("extern __shared__", "extern"))
-        extra = {"sim_kernels_post": ["-D__shared__=static", "-I", out_dir, "-I", csrc]}
+        extra = {"sim_kernels_post": ["-D__shared__=static", "-I", out_dir, "-I", csrc], "sim_kernels_stem": ["-D__shared__=static"]}
         procs = [subprocess.Popen([cxx, *flags, *extra.get(u, []), "-c", os.path.join(SIM_DIR, u + ".cpp"), "-o", os.path.join(out_dir, u + ".o")]) for u in units]
         assert all(p.wait() == 0 for p in procs), "the simulator build failed"
         subprocess.run([cxx, "-shared", "-o", so] + [os.path.join(out_dir, u + ".o") for u in units], check=True)
@@ -64,6 +64,7 @@ def sim():
     lib.sim_max_lds.restype = C.c_int
     lib.ymi_letterbox.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     lib.ymi_nms_ws_bytes.argtypes, lib.ymi_nms_ws_bytes.restype = [C.c_int], C.c_int64
+    lib.sim_conv_stem_planar.argtypes, lib.sim_conv_stem_planar.restype = [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int], C.c_int
     from yolort_amd._lib import PostDesc
     lib.ymi_postprocess_ws_bytes.argtypes, lib.ymi_postprocess_ws_bytes.restype = [C.c_int, C.c_int, C.c_int], C.c_int64
     lib.ymi_postprocess.argtypes, lib.ymi_postprocess.restype = [C.POINTER(PostDesc), C.c_void_p], C.c_int
@@ -495,3 +496,40 @@ def test_postprocess_vs_oracle(sim, thr, k):
         gain, px, py = rescale[i].tolist()
         want = (r["boxes"] - torch.tensor([px, py, px, py])) / gain
         np.testing.assert_allclose(boxes[i, :c].numpy(), want.numpy(), rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("cout,hw", [(32, (64, 96)), (48, (40, 64)), (16, (32, 64))])
+def test_stem_kernels_logic(sim, cout, hw):
+    """csrc/conv_stem.hip: Conv(3, c, k=6, s=2, p=2) (darknetv6.py:81) in its super-pixel form from the NHWC4 batch (tile 41) and straight
+    from the planar images (the benchmark's op 0): both against torch, and equal to each other bit for bit"""
+    from yolort_amd import engine
+    from yolort_amd._lib import ACT_SILU, ConvDesc, dtype_code
+    dtype, cpu = torch.float16, torch.device("cpu")
+    g = torch.Generator().manual_seed(5 + cout)
+    n, (h, w) = 2, hw
+    x = torch.rand(n, 3, h, w, generator=g).to(dtype)
+    wt = (torch.randn(cout, 3, 6, 6, generator=g) / 10).to(dtype).float()
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x.float(), wt, b, 2, 2)).permute(0, 2, 3, 1)
+    pc = engine.PackedConv(wt, b, None, dtype, cpu, stem_superpixel=True)
+    xb = Buf(n, h, w, 4, dtype)
+    xb.view()[..., :3] = x.permute(0, 2, 3, 1)
+    outs = []
+    for planar in (False, True):
+        yb = Buf(n, h // 2, w // 2, (cout + 7) // 8 * 8, dtype)
+        d = ConvDesc()
+        d.x, d.w, d.bias, d.y = xb.ptr, pc.w.data_ptr(), pc.bias.data_ptr(), yb.ptr
+        d.n, d.h, d.w_in, d.cin, d.x_cstride = n, h, w // 2, 8, 8
+        d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = h // 2, w // 2, cout, pc.cout_pad, yb.cs
+        d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = 6, 3, 2, 1, 2, 1, pc.k_pad
+        d.act, d.dtype, d.out_dtype, d.tile = ACT_SILU, dtype_code(dtype), dtype_code(dtype), 41
+        d.zeros = xb.zeros
+        if planar:
+            imgs = [x[i].contiguous() for i in range(n)]
+            ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in imgs])
+            _check(sim, sim.sim_conv_stem_planar(C.byref(d), ptrs, n))
+        else:
+            _check(sim, sim.sim_conv2d(C.byref(d)))
+        outs.append(yb.view()[..., :cout].clone())
+        assert (outs[-1].float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
