@@ -1,4 +1,4 @@
-// third translation unit of the simulator build (see sim_kernels.cpp): LDS-DMA implicit-GEMM tiles 12/21/24/27/61/64/66
+// third translation unit of the simulator build (see sim_kernels.cpp): LDS-DMA implicit-GEMM tiles 12/13/21/24/26/27/61/64/66 (+ 141-144)
 #include "hipsim.h"
 
 #include "../../yolort_amd/csrc/common.hpp"
@@ -18,7 +18,9 @@ int sim_v2(const ymi::ConvArgs& a, bool is1x1, int tile) {
     using namespace ymi;
     switch (tile) {
         case 12: return launch_v2<DT, DT, 256, 64, 64, 64, 3>(a, is1x1, nullptr);
+        case 13: return launch_v2<DT, DT, 256, 32, 64, 32, 3>(a, is1x1, nullptr);
         case 21: return launch_v2<DT, DT, 128, 128, 64, 64, 2>(a, is1x1, nullptr);
+        case 26: return launch_v2<DT, DT, 128, 32, 32, 32, 2>(a, is1x1, nullptr);
         case 24: return launch_v2<DT, DT, 64, 128, 32, 64, 2>(a, is1x1, nullptr);
         case 27: return launch_v2<DT, DT, 64, 64, 32, 32, 2>(a, is1x1, nullptr);
         case 61: return launch_v2<DT, DT, 128, 128, 64, 64, 4, true>(a, is1x1, nullptr);

@@ -1,0 +1,130 @@
+"""The yolov5s conv stack (backbone + PAN: 47 launches) on the CPU simulator, THROUGH THE PRODUCT'S OWN EMITTERS.
+
+`engine.Plan` is given a stand-in for libyolort_amd.so whose `ymi_plan_add_*` entry points EXECUTE each op at once on the hipsim build
+of the kernel sources (tests/hipsim) with host buffers, so `backbone.emit(plan, x)` -- concat elimination, cv1 + cv2 in one launch, the
+chained Bottleneck 1x1, the folded upsample, channel-slice views, the SPP cascade -- runs exactly as it is recorded for the GPU, only
+eagerly and on the CPU.  It is test infrastructure (the product has no CPU path: `Plan(...)` itself refuses non-CUDA devices; the plan
+object here is assembled by hand), and it is what lets an opt-in kernel be tried inside the real graph without a GPU:
+  * the fused one-Bottleneck C3 launch (YOLORT_AMD_FUSE_C3) leaves every pyramid feature of yolov5s BIT-IDENTICAL;
+  * the features agree with the oracle's fp16-storage emulation of the reference forward.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_hipsim_kernels import sim  # noqa: F401  (the module-scoped fixture that builds and loads the simulator library)
+
+
+class _SimLib:
+    """libyolort_amd.so's plan interface, executing instead of recording"""
+
+    def __init__(self, sim_lib, real_lib):
+        self.sim, self.real, self.n_ops, self.tiles = sim_lib, real_lib, 0, []
+
+    def _done(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.sim.sim_last_error().decode()}")
+        self.n_ops += 1
+        return self.n_ops - 1
+
+    # tile choice among the instantiations of the simulator build (the GPU build takes them from its pinned table)
+    @staticmethod
+    def _tile(d):
+        if d.cin == 8 and d.kh == 6:
+            return 41
+        pointwise = d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1
+        if d.chain_w:
+            k1 = d.cout_split if d.cout_split > 0 else d.cout
+            if pointwise and d.cin <= 128:
+                return 120 + k1 // 32
+            return {32: 13, 64: 12}[k1]
+        return 26 if d.cout_pad <= 32 else (27 if d.cout_pad <= 64 else 21)
+
+    def ymi_plan_create(self):
+        return 1
+
+    def ymi_plan_destroy(self, h):
+        pass
+
+    def ymi_plan_num_ops(self, h):
+        return self.n_ops
+
+    def ymi_plan_add_conv(self, h, dref):
+        d = dref._obj
+        if d.tile == 0:
+            d.tile = self._tile(d)
+        self.tiles.append(int(d.tile))
+        return self._done(self.sim.sim_conv2d(C.byref(d)), "sim_conv2d")
+
+    def ymi_plan_add_c3_fused(self, h, dref):
+        self.tiles.append(-1)
+        return self._done(self.sim.sim_c3_fused(dref), "sim_c3_fused")
+
+    def ymi_plan_add_spp_pool(self, h, buf, n, hh, w, c, cs, dt):
+        return self._done(self.sim.ymi_spp_pool(buf, n, hh, w, c, cs, dt, None), "ymi_spp_pool")
+
+    def ymi_plan_add_upsample2x(self, h, x, xcs, n, hh, w, c, y, ycs, dt):
+        return self._done(self.sim.ymi_upsample2x(x, xcs, n, hh, w, c, y, ycs, dt, None), "ymi_upsample2x")
+
+    def ymi_conv_build_ktab(self, *a):
+        return self.real.ymi_conv_build_ktab(*a)
+
+
+def _sim_plan(sim_lib, dtype, fuse_c3):
+    from yolort_amd import _lib, engine
+    p = engine.Plan.__new__(engine.Plan)   # Plan.__init__ insists on an MI355X; the attributes it would set:
+    p.lib = _SimLib(sim_lib, _lib.load(require_gpu=False))
+    p.device, p.dtype, p.handle = torch.device("cpu"), dtype, C.c_void_p(1)
+    p.keep, p.names, p.meta, p.bytes_allocated, p.stream = [], [], [], 0, None
+    p.zeros = torch.zeros(1024, dtype=torch.uint8)
+    p.conv_descs, p.io = {}, {}
+    p.chain_1x1, p.chain_cv3, p.use_v1, p.fuse_c3 = True, False, False, fuse_c3
+    p.autotune, p.use_tile_table, p.fp32 = False, False, False
+    return p
+
+
+def _run_backbone(sim_lib, model, img, dtype, fuse_c3):
+    plan = _sim_plan(sim_lib, dtype, fuse_c3)
+    n, _, h, w = img.shape
+    x = plan.alloc(n, h, w, 4, zero=True)
+    x.as_tensor()[..., :3] = img.permute(0, 2, 3, 1).to(dtype)
+    feats = model.model.backbone.emit(plan, x)
+    out = [f.as_tensor().clone() for f in feats]
+    plan.handle = None   # nothing to destroy
+    return out, plan
+
+
+def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch, dtype, S = "yolov5_darknet_pan_s_r60", torch.float16, 64
+    model = YOLOv5(arch=arch, size=(S, S), score_thresh=0.25)
+    model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.4))
+    model = model.to(dtype).eval()
+    img = synth_images(1, S, S, seed=5)[0][None].to(dtype).float()
+
+    sep, plan_sep = _run_backbone(sim, model, img, dtype, fuse_c3=False)
+    fused, plan_fused = _run_backbone(sim, model, img, dtype, fuse_c3=True)
+    assert plan_sep.num_ops == 47 and plan_fused.num_ops == 45, (plan_sep.num_ops, plan_fused.num_ops)   # the C3 at 160^2-equivalent: three launches -> one
+    assert plan_fused.names[2].endswith(".fused") and plan_fused.lib.tiles[2] == -1
+    for a, b in zip(sep, fused):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+    sd = {k: v.float() for k, v in model.state_dict().items()}
+    O.EMULATE.dtype = dtype
+    try:
+        with torch.no_grad():
+            ref = O.backbone(img, sd, p="model.backbone")
+    finally:
+        O.EMULATE.dtype = None
+    assert len(ref) == len(sep) == 3
+    for i, (r, g) in enumerate(zip(ref, sep)):
+        got = g.float().permute(0, 3, 1, 2)
+        assert got.shape == r.shape
+        err, scale = (got - r).abs().max().item(), r.abs().max().item()
+        print(f"feature {i}: {tuple(r.shape)} max |sim - emulation| = {err:.4g} (range {scale:.4g})")
+        assert err <= 2e-2 * max(1.0, scale)
