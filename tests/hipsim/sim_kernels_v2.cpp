@@ -41,6 +41,9 @@ int sim_v2(const ymi::ConvArgs& a, bool is1x1, int tile) {
 
 int sim_conv2d_v2(const ymi::ConvArgs& a, const ymi_conv_desc* d) {
     const bool is1x1 = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0;
-    if (d->out_dtype != d->dtype) { ymi::set_error("sim_conv2d: 16-bit outputs only"); return YMI_EINVAL; }
+    if (d->out_dtype == YMI_F32 && d->tile == 21) {   // the unfused head: fp32 logits (box_head.py:74)
+        return d->dtype == YMI_F16 ? ymi::launch_v2<YMI_F16, YMI_F32, 128, 128, 64, 64, 2>(a, is1x1, nullptr) : ymi::launch_v2<YMI_BF16, YMI_F32, 128, 128, 64, 64, 2>(a, is1x1, nullptr);
+    }
+    if (d->out_dtype != d->dtype) { ymi::set_error("sim_conv2d: fp32 outputs through tile 21 only"); return YMI_EINVAL; }
     return d->dtype == YMI_F16 ? sim_v2<YMI_F16>(a, is1x1, d->tile) : sim_v2<YMI_BF16>(a, is1x1, d->tile);
 }

@@ -36,6 +36,8 @@ class _SimLib:
         if d.cin == 8 and d.kh == 6:
             return 41
         pointwise = d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1
+        if d.out_dtype == 2:   # fp32 logits of the unfused head
+            return 21
         if d.chain_w:
             k1 = d.cout_split if d.cout_split > 0 else d.cout
             if pointwise and d.cin <= 128:
@@ -68,6 +70,13 @@ class _SimLib:
 
     def ymi_plan_add_upsample2x(self, h, x, xcs, n, hh, w, c, y, ycs, dt):
         return self._done(self.sim.ymi_upsample2x(x, xcs, n, hh, w, c, y, ycs, dt, None), "ymi_upsample2x")
+
+    def ymi_plan_add_postprocess(self, h, dref):
+        rc = self.sim.ymi_postprocess(dref, None)
+        return self._done(rc, "ymi_postprocess")
+
+    def ymi_postprocess_ws_bytes(self, *a):
+        return self.sim.ymi_postprocess_ws_bytes(*a)
 
     def ymi_conv_build_ktab(self, *a):
         return self.real.ymi_conv_build_ktab(*a)
@@ -128,3 +137,55 @@ def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
         err, scale = (got - r).abs().max().item(), r.abs().max().item()
         print(f"feature {i}: {tuple(r.shape)} max |sim - emulation| = {err:.4g} (range {scale:.4g})")
         assert err <= 2e-2 * max(1.0, scale)
+
+
+def test_yolov5n_detections_on_the_simulator_vs_oracle(sim):
+    """letterbox -> backbone + PAN -> (unfused) head -> decode / sort / NMS / top-k, every kernel on the simulator, driven by the product's
+    emitters and its host recipe; against the oracle's fp32 forward with the matching criterion of __graft_entry__.smoke()"""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    from test_hipsim_kernels import _sim_letterbox
+    arch, dtype, S, thr = "yolov5_darknet_pan_n_r60", torch.float16, 96, 0.1
+    model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr)
+    model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.5))
+    model = model.to(dtype).eval()
+    imgs = [synth_images(1, 72, 96, seed=21)[0], synth_images(1, 96, 60, seed=22)[0]]
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs, {k: v.float() for k, v in model.state_dict().items()}, size=(S, S), score_thresh=thr)
+
+    canvas, sizes = _sim_letterbox(sim, [im.to(dtype) for im in imgs], S, dtype)       # (n, hb, wb, 4) NHWC4, as the plan's input view
+    n, hb, wb, _ = canvas.shape
+    plan = _sim_plan(sim, dtype, fuse_c3=False)
+    x = plan.alloc(n, hb, wb, 4, zero=True)
+    x.as_tensor().copy_(canvas)
+    yolo = model.model
+    feats = yolo.backbone.emit(plan, x)
+    logits = yolo.head.emit(plan, feats)
+    ag = yolo.anchor_generator
+    rescale = torch.zeros(n, 3, dtype=torch.float32)
+    for i, im in enumerate(imgs):   # transform.py:354-367: gain and pad of each image inside the canvas
+        h0, w0 = int(im.shape[-2]), int(im.shape[-1])
+        gain = min(hb / h0, wb / w0)
+        rescale[i] = torch.tensor([gain, (wb - w0 * gain) / 2, (hb - h0 * gain) / 2])
+    pb = plan.postprocess(logits, [float(s_) for s_ in ag.strides], ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
+    assert int(pb.status[1]) == 0, pb.status.tolist()
+    plan.handle = None
+    for i, r in enumerate(ref):
+        c = int(pb.count[i])
+        gb, gs, gl = pb.boxes[i, :c].numpy(), pb.scores[i, :c].numpy(), pb.labels[i, :c].numpy()
+        rb, rs, rl = r["boxes"].numpy(), r["scores"].numpy(), r["labels"].numpy()
+        nr = len(rs)
+        assert nr > 0 and abs(nr - c) <= max(3, nr // 10), (nr, c)
+        need = [j for j in range(nr) if rs[j] >= max(thr, float(rs.min())) + 0.03]   # references near the threshold / the top-k cut need not survive fp16 storage
+        hit = 0
+        for j in need:
+            cand = np.where((gl == rl[j]) & (np.abs(gs - rs[j]) < 0.05))[0]
+            if len(cand):
+                x1, y1 = np.maximum(gb[cand, 0], rb[j, 0]), np.maximum(gb[cand, 1], rb[j, 1])
+                x2, y2 = np.minimum(gb[cand, 2], rb[j, 2]), np.minimum(gb[cand, 3], rb[j, 3])
+                inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+                iou = inter / ((gb[cand, 2] - gb[cand, 0]) * (gb[cand, 3] - gb[cand, 1]) + (rb[j, 2] - rb[j, 0]) * (rb[j, 3] - rb[j, 1]) - inter)
+                hit += int(iou.max() >= 0.5)
+        print(f"image {i}: {nr} reference detections, {c} from the simulator, {hit}/{len(need)} matched")
+        assert hit >= 0.9 * len(need)
