@@ -21,8 +21,9 @@ from test_hipsim_kernels import sim  # noqa: F401  (the module-scoped fixture th
 class _SimLib:
     """libyolort_amd.so's plan interface, executing instead of recording"""
 
-    def __init__(self, sim_lib, real_lib):
+    def __init__(self, sim_lib, real_lib, substitute=None):
         self.sim, self.real, self.n_ops, self.tiles = sim_lib, real_lib, 0, []
+        self.substitute = substitute or {}   # tile id -> tile id (e.g. the row-transposed-store form of a tile)
 
     def _done(self, rc, what):
         if rc != 0:
@@ -58,6 +59,8 @@ class _SimLib:
         d = dref._obj
         if d.tile == 0:
             d.tile = self._tile(d)
+        if d.out_dtype == d.dtype:
+            d.tile = self.substitute.get(int(d.tile), int(d.tile))
         self.tiles.append(int(d.tile))
         return self._done(self.sim.sim_conv2d(C.byref(d)), "sim_conv2d")
 
@@ -82,10 +85,10 @@ class _SimLib:
         return self.real.ymi_conv_build_ktab(*a)
 
 
-def _sim_plan(sim_lib, dtype, fuse_c3):
+def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None):
     from yolort_amd import _lib, engine
     p = engine.Plan.__new__(engine.Plan)   # Plan.__init__ insists on an MI355X; the attributes it would set:
-    p.lib = _SimLib(sim_lib, _lib.load(require_gpu=False))
+    p.lib = _SimLib(sim_lib, _lib.load(require_gpu=False), substitute)
     p.device, p.dtype, p.handle = torch.device("cpu"), dtype, C.c_void_p(1)
     p.keep, p.names, p.meta, p.bytes_allocated, p.stream = [], [], [], 0, None
     p.zeros = torch.zeros(1024, dtype=torch.uint8)
@@ -95,8 +98,8 @@ def _sim_plan(sim_lib, dtype, fuse_c3):
     return p
 
 
-def _run_backbone(sim_lib, model, img, dtype, fuse_c3):
-    plan = _sim_plan(sim_lib, dtype, fuse_c3)
+def _run_backbone(sim_lib, model, img, dtype, fuse_c3, substitute=None):
+    plan = _sim_plan(sim_lib, dtype, fuse_c3, substitute)
     n, _, h, w = img.shape
     x = plan.alloc(n, h, w, 4, zero=True)
     x.as_tensor()[..., :3] = img.permute(0, 2, 3, 1).to(dtype)
@@ -121,6 +124,13 @@ def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
     assert plan_sep.num_ops == 47 and plan_fused.num_ops == 45, (plan_sep.num_ops, plan_fused.num_ops)   # the C3 at 160^2-equivalent: three launches -> one
     assert plan_fused.names[2].endswith(".fused") and plan_fused.lib.tiles[2] == -1
     for a, b in zip(sep, fused):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+    # the row-transposed-store tiles (141 / 142 = tiles 12 / 21: StoreEpilogueTP) in place of their base tiles, everywhere in the graph --
+    # plain, residual, split, upsampled-copy and chained launches included (the last three fall back to the plain stores inside the kernel)
+    tp, plan_tp = _run_backbone(sim, model, img, dtype, fuse_c3=False, substitute={12: 141, 21: 142})
+    assert sum(t in (141, 142) for t in plan_tp.lib.tiles) >= 15
+    for a, b in zip(sep, tp):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
     sd = {k: v.float() for k, v in model.state_dict().items()}
