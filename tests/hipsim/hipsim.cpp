@@ -9,6 +9,7 @@ namespace hipsim {
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 int g_max_lds = 0;
 long g_launches = 0;
+const void* g_kernarg = nullptr;
 
 namespace {
 constexpr size_t STACK = 256 * 1024;

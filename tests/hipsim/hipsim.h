@@ -54,6 +54,7 @@ namespace hipsim {
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern int g_max_lds;              // largest dynamic-LDS size a launch asked for (checked by the driver against its arrays)
 extern long g_launches;
+extern const void* g_kernarg;       // the running launch's first kernel argument (kernels read a single by-value block through the kernarg segment pointer)
 
 void yield();
 void wave_sync();                  // every lane of the calling lane's wave
@@ -151,10 +152,14 @@ inline unsigned long long ballot(bool p) {
 
 inline void global_load_lds16(const void* g, void* lds_wave_uniform) { memcpy((unsigned char*)lds_wave_uniform + lane_id() * 16, g, 16); }
 
+inline const void* first_arg_address() { return nullptr; }
+template <class A0, class... A>
+inline const void* first_arg_address(const A0& a0, const A&...) { return &a0; }
 template <class K, class... A>
 inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
     if ((int)lds > g_max_lds) g_max_lds = (int)lds;
     ++g_launches;
+    g_kernarg = first_arg_address(args...);
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) run_block([&]() { kernel(args...); }, grid, block, dim3(bx, by, bz));
@@ -208,6 +213,8 @@ inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { mems
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
+#define __logf(x) logf(x)   /* fast-math intrinsics: the accurate libm forms (the head's pre-filter threshold carries a margin for exactly this) */
+#define __expf(x) expf(x)
 #define __fmul_rn(a, b) ((float)(a) * (float)(b))   /* the simulator build uses -ffp-contract=off: no fused multiply-add */
 #define __fadd_rn(a, b) ((float)(a) + (float)(b))
 #define __fsub_rn(a, b) ((float)(a) - (float)(b))
@@ -215,7 +222,7 @@ inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { mems
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }   // one thread runs at a time
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
-#define __builtin_amdgcn_kernarg_segment_ptr() ((const void*)nullptr)
+#define __builtin_amdgcn_kernarg_segment_ptr() (hipsim::g_kernarg)
 #define __umulhi(a, b) ((unsigned)(((uint64_t)(unsigned)(a) * (uint64_t)(unsigned)(b)) >> 32))
 // HIP's device-side integer min / max overloads
 template <class T> inline T min(T a, T b) { return b < a ? b : a; }

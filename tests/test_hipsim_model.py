@@ -78,6 +78,15 @@ class _SimLib:
         rc = self.sim.ymi_postprocess(dref, None)
         return self._done(rc, "ymi_postprocess")
 
+    def ymi_plan_add_post_begin(self, h, dref):
+        return self._done(self.sim.ymi_post_begin(dref, None), "ymi_post_begin")
+
+    def ymi_plan_add_head_decode_group(self, h, descs, n_levels, dref):
+        return self._done(self.sim.sim_conv_head_decode_group(descs, n_levels, dref), "sim_conv_head_decode_group")
+
+    def ymi_plan_add_post_finish(self, h, dref):
+        return self._done(self.sim.ymi_post_finish(dref, None), "ymi_post_finish")
+
     def ymi_postprocess_ws_bytes(self, *a):
         return self.sim.ymi_postprocess_ws_bytes(*a)
 
@@ -178,8 +187,18 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim):
         h0, w0 = int(im.shape[-2]), int(im.shape[-1])
         gain = min(hb / h0, wb / w0)
         rescale[i] = torch.tensor([gain, (wb - w0 * gain) / 2, (hb - h0 * gain) / 2])
-    pb = plan.postprocess(logits, [float(s_) for s_ in ag.strides], ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
+    strides = [float(s_) for s_ in ag.strides]
+    pb = plan.postprocess(logits, strides, ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
     assert int(pb.status[1]) == 0, pb.status.tolist()
+    # the shipped form: the decode fused into the head convolution, all levels in one launch (post_begin -> head group -> post_finish);
+    # its slab must equal the unfused form's bit for bit
+    assert yolo.head.can_fuse_decode(plan, feats)
+    pf, pd = plan.post_desc([(f.h, f.w) for f in feats], n, strides, ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
+    plan.post_begin(pd)
+    yolo.head.emit_fused(plan, feats, pd)
+    plan.post_finish(pd, pf.total_anchors)
+    assert int(pf.status[1]) == 0, pf.status.tolist()
+    assert torch.equal(pf.count, pb.count) and torch.equal(pf.labels, pb.labels) and torch.equal(pf.scores, pb.scores) and torch.equal(pf.boxes, pb.boxes)
     plan.handle = None
     for i, r in enumerate(ref):
         c = int(pb.count[i])
