@@ -92,7 +92,9 @@ void run_block(const std::function<void()>& body, dim3 grid, dim3 block, dim3 bi
     while (ndone < n) {
         b.progress = false;
         ndone = 0;
-        for (int i = 0; i < n; ++i) {
+        static const bool reverse = getenv("HIPSIM_REVERSE") != nullptr;   // debugging aid: schedule the lanes of a block in descending order
+        for (int ii = 0; ii < n; ++ii) {
+            const int i = reverse ? n - 1 - ii : ii;
             if (b.lanes[i].done) {
                 ++ndone;
                 continue;

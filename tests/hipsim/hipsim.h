@@ -160,6 +160,8 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
     if ((int)lds > g_max_lds) g_max_lds = (int)lds;
     ++g_launches;
     g_kernarg = first_arg_address(args...);
+    static const bool trace = getenv("HIPSIM_TRACE") != nullptr;   // debugging aid: one line per launch
+    if (trace) fprintf(stderr, "hipsim launch %ld: grid (%u, %u, %u) block %u lds %zu\n", g_launches, grid.x, grid.y, grid.z, block.x, lds);
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) run_block([&]() { kernel(args...); }, grid, block, dim3(bx, by, bz));
