@@ -39,13 +39,13 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem"]   # translation units, compiled in parallel (~70 s on 8 cores)
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
     csrc = os.path.join(ROOT, "yolort_amd", "csrc")
     srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp", "sim_fill.h")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
            [os.path.join(ROOT, "include", "yolort_amd.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-psabi", "-Wno-pass-failed"]
+        flags = ["-std=c++17", os.environ.get("HIPSIM_OPT", "-O0"), "-fPIC", "-ffp-contract=off", "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-Wno-unused-function", "-Wno-psabi", "-Wno-pass-failed"]
         # postprocess.hip declares STATIC __shared__ arrays: its unit is built with -D__shared__=static from a copy of the source in
         # which `extern __shared__` lost the keyword (the only textual change any kernel source sees here)
         with open(os.path.join(csrc, "postprocess.hip")) as f:
