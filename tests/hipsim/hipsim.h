@@ -150,6 +150,29 @@ inline unsigned long long ballot(bool p) {
     return m;
 }
 
+// v_mfma_f32_32x32x2_f32: lane (hi, r) supplies A[row r][k = hi] and B[k = hi][column r]; per output an fmaf chain over k = 0, 1
+inline f32x16_t mfma_32x32x2f32(float a, float b, f32x16_t c) {
+    unsigned char* d = wave_deposit();
+    const int l = lane_id(), hi = l >> 5, r = l & 31;
+    memcpy(d + l * 64, &a, 4);
+    memcpy(d + l * 64 + 4, &b, 4);
+    wave_sync();
+    for (int g = 0; g < 4; ++g)
+        for (int e = 0; e < 4; ++e) {
+            const int row = g * 8 + hi * 4 + e;
+            float acc = c[g * 4 + e];
+            for (int k = 0; k < 2; ++k) {
+                float av, bv;
+                memcpy(&av, d + (k * 32 + row) * 64, 4);
+                memcpy(&bv, d + (k * 32 + r) * 64 + 4, 4);
+                acc = fmaf(av, bv, acc);
+            }
+            c[g * 4 + e] = acc;
+        }
+    wave_sync();
+    return c;
+}
+
 inline void global_load_lds16(const void* g, void* lds_wave_uniform) { memcpy((unsigned char*)lds_wave_uniform + lane_id() * 16, g, 16); }
 
 inline const void* first_arg_address() { return nullptr; }
@@ -196,6 +219,7 @@ inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { mems
 #define __syncthreads() hipsim::block_sync()
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipsim::mfma_32x32x16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipsim::mfma_32x32x16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipsim::mfma_32x32x2f32(a, b, c)
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipsim::permlane32_swap(a, b)
 #define __builtin_amdgcn_readfirstlane(v) hipsim::readfirstlane(v)
 #define __builtin_amdgcn_exp2f(v) exp2f(v)

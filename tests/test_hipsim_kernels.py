@@ -39,7 +39,7 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem", "sim_kernels_f32"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
     csrc = os.path.join(ROOT, "yolort_amd", "csrc")
     srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp", "sim_fill.h")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
@@ -52,7 +52,7 @@ def sim():
             text = f.read()
         with open(os.path.join(out_dir, "postprocess.sim.hip"), "w") as f:
             f.write(text.replace("extern __shared__", "extern"))
-        extra = {"sim_kernels_post": ["-D__shared__=static", "-I", out_dir, "-I", csrc], "sim_kernels_stem": ["-D__shared__=static"]}
+        extra = {"sim_kernels_post": ["-D__shared__=static", "-I", out_dir, "-I", csrc], "sim_kernels_stem": ["-D__shared__=static"], "sim_kernels_f32": ["-D__shared__=static"]}
         procs = [subprocess.Popen([cxx, *flags, *extra.get(u, []), "-c", os.path.join(SIM_DIR, u + ".cpp"), "-o", os.path.join(out_dir, u + ".o")]) for u in units]
         assert all(p.wait() == 0 for p in procs), "the simulator build failed"
         subprocess.run([cxx, "-shared", "-o", so] + [os.path.join(out_dir, u + ".o") for u in units], check=True)
@@ -534,3 +534,33 @@ def test_stem_kernels_logic(sim, cout, hw):
         outs.append(yb.view()[..., :cout].clone())
         assert (outs[-1].float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("k,s_,cin,cout", [(1, 1, 64, 96), (3, 1, 32, 40), (3, 2, 48, 64), (6, 2, 4, 32)])
+def test_fp32_parity_kernel_logic(sim, k, s_, cin, cout):
+    """csrc/conv_f32.hip (fp32 parity mode): exact fp32 arithmetic -- against torch's fp32 convolution to rounding-order accuracy"""
+    from yolort_amd import engine
+    from yolort_amd._lib import ACT_SILU, ConvDesc, YMI_F32
+    g = torch.Generator().manual_seed(k * 10 + cin)
+    n, h, w, p = 2, 13, 10, k // 2 if k != 6 else 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g) * 0.1
+    r = None
+    ref = F.silu(F.conv2d(x, wt, bias, s_, p))
+    ho, wo = ref.shape[2], ref.shape[3]
+    pc = engine.PackedConv(wt, bias, None, torch.float32, torch.device("cpu"), cin_pad=(cin + 7) // 8 * 8)
+    xb = torch.zeros(n, h, w, pc.cin)
+    xb[..., :cin] = x.permute(0, 2, 3, 1)
+    yb = torch.zeros(n, ho, wo, cout)
+    d = ConvDesc()
+    d.x, d.w, d.bias, d.y = xb.data_ptr(), pc.w.data_ptr(), pc.bias.data_ptr(), yb.data_ptr()
+    kt = pc.ktab(w, pc.cin)
+    d.ktab = kt.data_ptr()
+    d.n, d.h, d.w_in, d.cin, d.x_cstride = n, h, w, pc.cin, pc.cin
+    d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = ho, wo, cout, pc.cout_pad, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = k, k, s_, s_, p, p, pc.k_pad
+    d.act, d.dtype, d.out_dtype, d.tile = ACT_SILU, YMI_F32, YMI_F32, -100
+    _check(sim, sim.sim_conv2d(C.byref(d)))
+    got = yb.permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())

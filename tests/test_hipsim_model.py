@@ -81,6 +81,9 @@ class _SimLib:
     def ymi_postprocess_ws_bytes(self, *a):
         return self.sim.ymi_postprocess_ws_bytes(*a)
 
+    def ymi_plan_add_copy_view(self, h, x, xcs, npix, c, y, ycs, dt):
+        return self._done(self.sim.ymi_copy_view(x, xcs, npix, c, y, ycs, dt, None), "ymi_copy_view")
+
     def ymi_conv_build_ktab(self, *a):
         return self.real.ymi_conv_build_ktab(*a)
 
@@ -94,7 +97,9 @@ def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None):
     p.zeros = torch.zeros(1024, dtype=torch.uint8)
     p.conv_descs, p.io = {}, {}
     p.chain_1x1, p.chain_cv3, p.use_v1, p.fuse_c3 = True, False, False, fuse_c3
-    p.autotune, p.use_tile_table, p.fp32 = False, False, False
+    p.autotune, p.use_tile_table, p.fp32 = False, False, dtype == torch.float32
+    if p.fp32:   # fp32 parity mode (engine.Plan.__init__): one launch per reference conv, no fused pairs / chains
+        p.use_v1, p.chain_1x1, p.chain_cv3, p.fuse_c3 = True, False, False, False
     return p
 
 
@@ -203,3 +208,59 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim):
                 hit += int(iou.max() >= 0.5)
         print(f"image {i}: {nr} reference detections, {c} from the simulator, {hit}/{len(need)} matched")
         assert hit >= 0.9 * len(need)
+
+
+def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim):
+    """the fp32 parity mode (csrc/conv_f32.hip, fp32 pool / upsample / logits: `YOLOv5.set_compute_dtype(torch.float32)` on the GPU) end to end
+    on the simulator, yolov5n on two differently shaped images, against the fp32 oracle with the DIRECT checks of SURVEY.md 8d:
+    equal counts, equal labels, |score difference| <= 1e-4, IoU >= 1 - 1e-3"""
+    from oracle import yolov5_oracle as O
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    from test_hipsim_kernels import _sim_letterbox
+    sim.ymi_copy_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    arch, dtype, S, thr = "yolov5_darknet_pan_n_r60", torch.float32, 96, 0.25
+    model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr)
+    model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.5))
+    model = model.float().eval()
+    imgs = [synth_images(1, 72, 96, seed=21)[0], synth_images(1, 96, 60, seed=22)[0]]
+    with torch.no_grad():
+        ref = O.yolov5_forward(imgs, {k: v.float() for k, v in model.state_dict().items()}, size=(S, S), score_thresh=thr)
+    canvas, _ = _sim_letterbox(sim, imgs, S, dtype)
+    n, hb, wb, _ = canvas.shape
+    plan = _sim_plan(sim, dtype, fuse_c3=False)
+    x = plan.alloc(n, hb, wb, 4, zero=True)
+    x.as_tensor().copy_(canvas)
+    yolo = model.model
+    feats = yolo.backbone.emit(plan, x)
+    logits = yolo.head.emit(plan, feats)
+    ag = yolo.anchor_generator
+    rescale = torch.zeros(n, 3, dtype=torch.float32)
+    for i, im in enumerate(imgs):
+        h0, w0 = int(im.shape[-2]), int(im.shape[-1])
+        gain = min(hb / h0, wb / w0)
+        rescale[i] = torch.tensor([gain, (wb - w0 * gain) / 2, (hb - h0 * gain) / 2])
+    pb = plan.postprocess(logits, [float(s_) for s_ in ag.strides], ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
+    assert int(pb.status[1]) == 0, pb.status.tolist()
+    plan.handle = None
+    total = paired = 0
+    for i, r in enumerate(ref):
+        c = int(pb.count[i])
+        gb, gs, gl = pb.boxes[i, :c].numpy(), pb.scores[i, :c].numpy(), pb.labels[i, :c].numpy()
+        rb, rs, rl = r["boxes"].numpy(), r["scores"].numpy(), r["labels"].numpy()
+        assert c == len(rs), (c, len(rs))
+        used = np.zeros(c, bool)
+        for j in range(len(rs)):   # a reference detection is paired with an unused detection of the same label, score within 1e-4, IoU >= 1 - 1e-3
+            cand = np.where((gl == rl[j]) & (np.abs(gs - rs[j]) <= 1e-4) & ~used)[0]
+            if not len(cand):
+                continue
+            x1, y1 = np.maximum(gb[cand, 0], rb[j, 0]), np.maximum(gb[cand, 1], rb[j, 1])
+            x2, y2 = np.minimum(gb[cand, 2], rb[j, 2]), np.minimum(gb[cand, 3], rb[j, 3])
+            inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+            iou = inter / ((gb[cand, 2] - gb[cand, 0]) * (gb[cand, 3] - gb[cand, 1]) + (rb[j, 2] - rb[j, 0]) * (rb[j, 3] - rb[j, 1]) - inter)
+            if iou.max() >= 1 - 1e-3:
+                used[cand[int(iou.argmax())]] = True
+                paired += 1
+        total += len(rs)
+    print(f"fp32 parity mode on the simulator: {paired} of {total} reference detections paired (same label, |dscore| <= 1e-4, IoU >= 1 - 1e-3)")
+    assert total > 50 and paired == total
