@@ -70,6 +70,9 @@ def sim():
     lib.ymi_postprocess.argtypes, lib.ymi_postprocess.restype = [C.POINTER(PostDesc), C.c_void_p], C.c_int
     lib.ymi_post_begin.argtypes, lib.ymi_post_finish.argtypes = [C.POINTER(PostDesc), C.c_void_p], [C.POINTER(PostDesc), C.c_void_p]
     lib.ymi_batched_nms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ymi_copy_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ymi_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.ymi_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ymi_spp_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.ymi_upsample2x.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return lib
@@ -564,3 +567,20 @@ def test_fp32_parity_kernel_logic(sim, k, s_, cin, cout):
     _check(sim, sim.sim_conv2d(C.byref(d)))
     got = yb.permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_layout_edges_and_view_copy(sim):
+    """the module-level API edges (NCHW <-> NHWC view, fp32 <-> fp16) and the strided channel-slice copy are exact"""
+    from yolort_amd._lib import YMI_F16, YMI_F32
+    x = torch.randn(2, 13, 7, 9, generator=torch.Generator().manual_seed(3))
+    nhwc = Buf(2, 7, 9, 24, torch.float16)                      # 13 channels padded to 16 inside a 24-wide buffer
+    _check(sim, sim.ymi_nchw_to_nhwc(x.data_ptr(), 2, 13, 7, 9, YMI_F32, nhwc.slice_c(8, 16).ptr, 24, 16, YMI_F16, None))
+    v = nhwc.view().float()
+    assert torch.equal(v[..., 8:21], x.half().float().permute(0, 2, 3, 1)) and v[..., :8].abs().max().item() == 0 and v[..., 21:].abs().max().item() == 0
+    back = torch.zeros(2, 13, 7, 9)
+    _check(sim, sim.ymi_nhwc_to_nchw(nhwc.slice_c(8, 16).ptr, 24, 2, 13, 7, 9, YMI_F16, back.data_ptr(), YMI_F32, None))
+    assert torch.equal(back, x.half().float())
+    dst = Buf(2, 7, 9, 40, torch.float16)
+    _check(sim, sim.ymi_copy_view(nhwc.slice_c(8, 16).ptr, 24, 2 * 7 * 9, 16, dst.slice_c(16, 16).ptr, 40, YMI_F16, None))
+    d = dst.view().float()
+    assert torch.equal(d[..., 16:32], v[..., 8:24]) and d[..., :16].abs().max().item() == 0 and d[..., 32:].abs().max().item() == 0
