@@ -344,11 +344,11 @@ def test_row_transposed_store_tile_with_channel_split(sim):
     assert outs[1][1].float()[..., :64].abs().max().item() == 0
 
 
-def _sim_letterbox(sim, imgs, size, out_dtype, c_out=4):
+def _sim_letterbox(sim, imgs, size, out_dtype, c_out=4, div=32):
     """the product's host recipe (YOLOTransform.geometry: reference transform.py:53-97, 297-330) + ymi_letterbox on the simulator"""
     from yolort_amd._lib import YMI_U8_HWC, dtype_code
     from yolort_amd.models.transform import YOLOTransform
-    tr = YOLOTransform(size, size)
+    tr = YOLOTransform(size, size, size_divisible=div)
     (hb, wb), sizes, pads = tr.geometry([tr.image_hw(im) for im in imgs])
     n = len(imgs)
     imgs = [im.contiguous() for im in imgs]

@@ -21,8 +21,8 @@ from test_hipsim_kernels import sim  # noqa: F401  (the module-scoped fixture th
 class _SimLib:
     """libyolort_amd.so's plan interface, executing instead of recording"""
 
-    def __init__(self, sim_lib, real_lib, substitute=None):
-        self.sim, self.real, self.n_ops, self.tiles = sim_lib, real_lib, 0, []
+    def __init__(self, sim_lib, real_lib, substitute=None, small_tiles=False):
+        self.sim, self.real, self.n_ops, self.tiles, self.small_tiles = sim_lib, real_lib, 0, [], small_tiles
         self.substitute = substitute or {}   # tile id -> tile id (e.g. the row-transposed-store form of a tile)
 
     def _done(self, rc, what):
@@ -32,8 +32,7 @@ class _SimLib:
         return self.n_ops - 1
 
     # tile choice among the instantiations of the simulator build (the GPU build takes them from its pinned table)
-    @staticmethod
-    def _tile(d):
+    def _tile(self, d):
         if d.cin == 8 and d.kh == 6:
             return 41
         pointwise = d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1
@@ -44,6 +43,8 @@ class _SimLib:
             if pointwise and d.cin <= 128:
                 return 120 + k1 // 32
             return {32: 13, 64: 12}[k1]
+        if self.small_tiles and d.n * d.ho * d.wo <= 256 and d.cout_pad > 32:   # few pixels: the 64-pixel tiles (half the padded work of the 128-pixel ones)
+            return 27 if d.cout_pad <= 64 else 24
         return 26 if d.cout_pad <= 32 else (27 if d.cout_pad <= 64 else 21)
 
     def ymi_plan_create(self):
@@ -88,10 +89,10 @@ class _SimLib:
         return self.real.ymi_conv_build_ktab(*a)
 
 
-def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None):
+def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None, small_tiles=False):
     from yolort_amd import _lib, engine
     p = engine.Plan.__new__(engine.Plan)   # Plan.__init__ insists on an MI355X; the attributes it would set:
-    p.lib = _SimLib(sim_lib, _lib.load(require_gpu=False), substitute)
+    p.lib = _SimLib(sim_lib, _lib.load(require_gpu=False), substitute, small_tiles)
     p.device, p.dtype, p.handle = torch.device("cpu"), dtype, C.c_void_p(1)
     p.keep, p.names, p.meta, p.bytes_allocated, p.stream = [], [], [], 0, None
     p.zeros = torch.zeros(1024, dtype=torch.uint8)
@@ -154,7 +155,8 @@ def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
         assert err <= 2e-2 * max(1.0, scale)
 
 
-def test_yolov5n_detections_on_the_simulator_vs_oracle(sim):
+@pytest.mark.parametrize("arch,S,div,gain", [("yolov5_darknet_pan_n_r60", 96, 32, 0.5), ("yolov5_darknet_pan_l6_r60", 128, 64, 4.0)])
+def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain):
     """letterbox -> backbone + PAN -> (unfused) head -> decode / sort / NMS / top-k, every kernel on the simulator, driven by the product's
     emitters and its host recipe; against the oracle's fp32 forward with the matching criterion of __graft_entry__.smoke().
     (The head runs in its unfused form -- fp32 logits + decode kernel.  The shipped fused head-decode launch keeps a wave-private worklist
@@ -164,17 +166,17 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim):
     from yolort_amd.models import YOLOv5
     from yolort_amd.utils.synth import synth_images, synth_weights
     from test_hipsim_kernels import _sim_letterbox
-    arch, dtype, S, thr = "yolov5_darknet_pan_n_r60", torch.float16, 96, 0.1
-    model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr)
-    model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.5))
+    dtype, thr = torch.float16, 0.1   # the second case is a P6 model: IntermediateLevelP6, four pyramid levels, size_divisible = 64 (yolo.py:622-834)
+    model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr, **(dict(size_divisible=div) if div != 32 else {}))
+    model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=gain))
     model = model.to(dtype).eval()
-    imgs = [synth_images(1, 72, 96, seed=21)[0], synth_images(1, 96, 60, seed=22)[0]]
+    imgs = [synth_images(1, 3 * S // 4, S, seed=21)[0], synth_images(1, S, 5 * S // 8, seed=22)[0]][: 2 if div == 32 else 1]   # (one image for the 135-conv model: time)
     with torch.no_grad():
-        ref = O.yolov5_forward(imgs, {k: v.float() for k, v in model.state_dict().items()}, size=(S, S), score_thresh=thr)
+        ref = O.yolov5_forward(imgs, {k: v.float() for k, v in model.state_dict().items()}, size=(S, S), size_divisible=div, score_thresh=thr)
 
-    canvas, sizes = _sim_letterbox(sim, [im.to(dtype) for im in imgs], S, dtype)       # (n, hb, wb, 4) NHWC4, as the plan's input view
+    canvas, sizes = _sim_letterbox(sim, [im.to(dtype) for im in imgs], S, dtype, div=div)       # (n, hb, wb, 4) NHWC4, as the plan's input view
     n, hb, wb, _ = canvas.shape
-    plan = _sim_plan(sim, dtype, fuse_c3=False)
+    plan = _sim_plan(sim, dtype, fuse_c3=False, small_tiles=div != 32)
     x = plan.alloc(n, hb, wb, 4, zero=True)
     x.as_tensor().copy_(canvas)
     yolo = model.model
