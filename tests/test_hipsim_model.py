@@ -155,8 +155,9 @@ def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
         assert err <= 2e-2 * max(1.0, scale)
 
 
-@pytest.mark.parametrize("arch,S,div,gain", [("yolov5_darknet_pan_n_r60", 96, 32, 0.5), ("yolov5_darknet_pan_l6_r60", 128, 64, 4.0)])
-def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain):
+@pytest.mark.parametrize("arch,S,div,gain,dtype", [("yolov5_darknet_pan_n_r60", 96, 32, 0.5, torch.float16), ("yolov5_darknet_pan_l6_r60", 128, 64, 4.0, torch.float16),
+                                                 ("yolov5_darknet_pan_m_r60", 64, 32, 2.0, torch.bfloat16)])
+def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, dtype):
     """letterbox -> backbone + PAN -> (unfused) head -> decode / sort / NMS / top-k, every kernel on the simulator, driven by the product's
     emitters and its host recipe; against the oracle's fp32 forward with the matching criterion of __graft_entry__.smoke().
     (The head runs in its unfused form -- fp32 logits + decode kernel.  The shipped fused head-decode launch keeps a wave-private worklist
@@ -166,17 +167,18 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain):
     from yolort_amd.models import YOLOv5
     from yolort_amd.utils.synth import synth_images, synth_weights
     from test_hipsim_kernels import _sim_letterbox
-    dtype, thr = torch.float16, 0.1   # the second case is a P6 model: IntermediateLevelP6, four pyramid levels, size_divisible = 64 (yolo.py:622-834)
+    thr = 0.1   # second case: a P6 model (IntermediateLevelP6, four pyramid levels, size_divisible = 64; yolo.py:622-834); third: yolov5m in bf16 --
+    #             widths 48 / 96 / 192 ...: channel counts that are not multiples of 32 take the im2col-table form of the implicit GEMM
     model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr, **(dict(size_divisible=div) if div != 32 else {}))
     model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=gain))
     model = model.to(dtype).eval()
-    imgs = [synth_images(1, 3 * S // 4, S, seed=21)[0], synth_images(1, S, 5 * S // 8, seed=22)[0]][: 2 if div == 32 else 1]   # (one image for the 135-conv model: time)
+    imgs = [synth_images(1, 3 * S // 4, S, seed=21)[0], synth_images(1, S, 5 * S // 8, seed=22)[0]][: 2 if arch.endswith("_n_r60") else 1]   # (one image for the larger models: time)
     with torch.no_grad():
         ref = O.yolov5_forward(imgs, {k: v.float() for k, v in model.state_dict().items()}, size=(S, S), size_divisible=div, score_thresh=thr)
 
     canvas, sizes = _sim_letterbox(sim, [im.to(dtype) for im in imgs], S, dtype, div=div)       # (n, hb, wb, 4) NHWC4, as the plan's input view
     n, hb, wb, _ = canvas.shape
-    plan = _sim_plan(sim, dtype, fuse_c3=False, small_tiles=div != 32)
+    plan = _sim_plan(sim, dtype, fuse_c3=False, small_tiles=not arch.endswith("_n_r60"))
     x = plan.alloc(n, hb, wb, 4, zero=True)
     x.as_tensor().copy_(canvas)
     yolo = model.model
@@ -209,7 +211,7 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain):
                 iou = inter / ((gb[cand, 2] - gb[cand, 0]) * (gb[cand, 3] - gb[cand, 1]) + (rb[j, 2] - rb[j, 0]) * (rb[j, 3] - rb[j, 1]) - inter)
                 hit += int(iou.max() >= 0.5)
         print(f"image {i}: {nr} reference detections, {c} from the simulator, {hit}/{len(need)} matched")
-        assert hit >= 0.9 * len(need)
+        assert hit >= (0.9 if dtype == torch.float16 else 0.8) * len(need)   # bf16 storage: 8 mantissa bits (the GPU suite's bf16 bound is looser still)
 
 
 def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim):
