@@ -1,11 +1,9 @@
-"""First GPU run of the fused one-Bottleneck C3 launch (csrc/c3_fused32.hip, ymi_c3_fused).
+"""The fused one-Bottleneck C3 launch (csrc/c3_fused32.hip, ymi_c3_fused) and the row-transposed-store tiles.
 
-The kernel was written at the end of round 2 with no GPU time left: it cross-compiles (122 VGPRs, no scratch, 63.75 KB of LDS)
-and its book-keeping agrees with a lane-level model (tools/c3_fused_index_model.py), but it has NOT run on an MI355X yet.  It is
-opt-in in the product (YOLORT_AMD_FUSE_C3=1) and these tests are opt-in too (YOLORT_AMD_EXPERIMENTAL=1) so that an unverified
-kernel cannot take the GPU suite down; tools/gpu_calls/gpu_r3_c3fused.sh runs them and the A/B bench.
+Both were written blind at the end of round 2 (CPU simulator only) and gated; their first GPU run (round 3, tools/gpu_calls/gpu_r3_c3fused.sh:
+22 passed) un-gated them -- the fused launch is the default for yolov5s body.2 now (YOLORT_AMD_FUSE_C3=0 restores the separate launches).
 
-What they pin once enabled: the fused launch is BIT-IDENTICAL to the three separate launches (same rounding points, same k
+What they pin: the fused launch is BIT-IDENTICAL to the three separate launches (same rounding points, same k
 order on top of the bias) on ragged sizes, channel-slice views and both 16-bit types, agrees with the fp32 torch evaluation of
 common.py:172-173 / :115-116 within the per-launch tolerance, and leaves yolov5s detections unchanged end to end.
 """
@@ -15,8 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("YOLORT_AMD_EXPERIMENTAL", "0") != "1", reason="unverified kernel: set YOLORT_AMD_EXPERIMENTAL=1")]
+pytestmark = [pytest.mark.gpu]
 
 
 @pytest.fixture(scope="module")

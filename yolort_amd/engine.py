@@ -126,7 +126,7 @@ def tile_key_str(key: Tuple, dtype: torch.dtype) -> str:
     """stable text form of a conv launch's shape key (the JSON table's key)"""
     n, h, w, cin, cout, kh, kw, s, p, xcs, ycs, odt, res, split, up2, chain = key
     return (f"n{n} {h}x{w} c{cin}->{cout} k{kh}x{kw} s{s[0]}x{s[1]} p{p[0]}x{p[1]} xcs{xcs} ycs{ycs} odt{odt} res{int(bool(res))} split{split} "
-            f"up2{int(bool(up2))} chain{int(bool(chain))} {str(dtype).replace('torch.', '')}")
+            f"up2{int(bool(up2))} chain{int(chain)} {str(dtype).replace('torch.', '')}")
 
 
 def tile_table() -> Dict[str, int]:
@@ -170,10 +170,10 @@ class Plan:
         # +-0 end to end (the pixel-major producer tiles it needs cost what the saved launch gains) -> off by default
         self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
-        # a whole one-Bottleneck C3 of 32 hidden channels in ONE launch (csrc/c3_fused32.hip; yolov5s backbone.body.2).  OPT-IN:
-        # written at the end of round 2 with no GPU time left -- cross-compiled and checked against a lane-level index model
-        # (tools/c3_fused_index_model.py) only; tests/test_c3_fused_gpu.py and tools/gpu_calls/gpu_r3_c3fused.sh are its first GPU run
-        self.fuse_c3 = os.environ.get("YOLORT_AMD_FUSE_C3", "0") == "1"
+        # a whole one-Bottleneck C3 of 32 hidden channels in ONE launch (csrc/c3_fused32.hip; yolov5s backbone.body.2).  Default since
+        # round 3: bit-identical to the three launches it replaces (tests/test_c3_fused_gpu.py) and 91 vs 196 us on the 160x160 level of
+        # the bs-32 yolov5s plan (profiles/r03a_c3fused_ab.txt); YOLORT_AMD_FUSE_C3=0 restores the separate launches
+        self.fuse_c3 = os.environ.get("YOLORT_AMD_FUSE_C3", "1") != "0"
         # Tile selection is DETERMINISTIC: a pinned per-(shape, dtype) table for gfx950 committed in-tree
         # (yolort_amd/data/tiles_gfx950.json, produced by tools/tune_tiles.py on an MI355X) and, for shapes it does not hold,
         # the library's shape heuristic (tile 0).  Different tiles accumulate K in different orders, so a timing-based choice
@@ -304,7 +304,10 @@ class Plan:
                                  "chain_y": None if chain is None else chain[1], "chain_x2": None if chain is None or len(chain) < 3 else chain[2],
                                  "stride": s, "pad": p}
         if tile == 0 and d.zeros:
-            tkey = (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None, chain is not None)
+            tkey = (x.n, x.h, x.w, pc.cin, pc.cout, pc.kh, pc.kw, s, p, x.cs, out.cs, dtype_code(out.dtype), res is not None, split, up2_out is not None,
+                    # chain kind: 0 none, 1 chained 1x1 over this launch's output, 2 + the second source's channels (cv3 over the concat) -- the
+                    # candidate tiles differ per kind, so a table entry must not be applied across kinds
+                    0 if chain is None else (1 if len(chain) < 3 or chain[2] is None else 2 + chain[2].c))
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
             elif self.use_tile_table:
@@ -341,10 +344,10 @@ class Plan:
         if d.cin % 32 == 0 and d.kh * d.kw <= 32:
             cands = cands + [t + 50 for t in cands]   # the same tiles with the software-pipelined main loop (61..65, 71..77)
             cands = cands + ([69, 70] if d.cout_pad > 32 else []) + ([66, 68] if d.cout_pad >= 128 else [])   # 3-stage / 256-pixel tiles
-        if os.environ.get("YOLORT_AMD_TUNE_TP", "0") == "1" and d.out_dtype == d.dtype and d.y2_mode == 0 and chain is None and d.cin % 32 == 0 and d.kh * d.kw <= 32 and \
+        if os.environ.get("YOLORT_AMD_TUNE_TP", "1") != "0" and d.out_dtype == d.dtype and d.y2_mode == 0 and chain is None and d.cin % 32 == 0 and d.kh * d.kw <= 32 and \
                 d.k_pad == d.kh * d.kw * d.cin:
-            # row-transposed-store forms of tiles 12 / 21 / 66 / 61 / 71 and of the 8-wave implicit GEMM (141-145, 151-155): opt-in
-            # candidates (written at the end of round 2, executed on the CPU simulator only: tests/test_hipsim_kernels.py)
+            # row-transposed-store forms of tiles 12 / 21 / 66 / 61 / 71 and of the 8-wave implicit GEMM (141-145, 151-155): bit-identical
+            # to their base tiles (tests/test_c3_fused_gpu.py, tests/test_hipsim_kernels.py), offered to the tuner since round 3
             cands = cands + [t for t, base in ((141, 12), (142, 21), (143, 66), (144, 61), (145, 71)) if base in cands]
             cands = cands + ([155] if d.cout_pad > 128 else []) + ([151] if d.cout_pad > 64 else []) + ([152] if 32 < d.cout_pad <= 128 else [])
         if d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1 and d.cin % 32 == 0 and d.cin <= 128 and d.k_pad == d.cin and d.out_dtype == d.dtype and d.y2_mode == 0 and d.cout % 32 == 0:

@@ -37,6 +37,7 @@ def synth_state_dict(
     obj_bias: float = -4.0,
     cls_bias: float = -1.0,
     num_outputs: int = 85,
+    bn_gamma=(0.75, 1.25),
 ) -> Dict[str, torch.Tensor]:
     """Fill a state_dict (keys/shapes taken from `template`) with the seeded recipe.
 
@@ -54,7 +55,7 @@ def synth_state_dict(
             fan_in = shape[1] * shape[2] * shape[3]
             v = _fp16_round(rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in))
         elif key.endswith(".bn.weight"):
-            v = (0.75 + 0.5 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+            v = (np.float32(bn_gamma[0]) + np.float32(bn_gamma[1] - bn_gamma[0]) * rng.random(shape, dtype=np.float32)).astype(np.float32)
         elif key.endswith(".bn.bias"):
             v = (0.2 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
         elif key.endswith(".bn.running_mean"):
@@ -102,6 +103,40 @@ def load_synth_bn(sd: Dict[str, torch.Tensor], arch: str, seed: int = 0, path: O
 
 def synth_weights(template: Dict[str, torch.Tensor], arch: str, seed: int = 0, **kw) -> Dict[str, torch.Tensor]:
     return load_synth_bn(synth_state_dict(template, seed=seed, **kw), arch, seed)
+
+
+# ---- the CONDITIONED recipe (round 3): the parity workload that can carry a tolerance --------------------------------------
+# With BatchNorm weights around 1 every Conv-BN-SiLU of a random network amplifies a relative perturbation (a rounding) by
+# sqrt(chi), chi = gamma^2 E[silu'(z)^2] / Var(silu(z)) = 1.21 for z ~ N(0,1): x10 over the ~25 layers in sequence between the
+# image and a head (measured: fp16 storage reaches the logits as 4.4e-3 relative, x2500 for an fp32 rounding -- DESIGN.md section 2).
+# chi >= 1 for any variance-normalising network (Gaussian Poincare inequality) and -> 1 as the activation becomes linear:
+# gamma in [0.3, 0.6] gives chi = 1.1 (measured: 1.5e-3, the no-amplification floor of 25 fp16 roundings).  Head gain 1.0 and an
+# objectness bias TUNED on a seeded batch so that a few dozen (anchor, class) pairs per image pass the threshold -- sparse,
+# well separated detections like a trained detector's, instead of 1000 near-tied candidates per image competing in the NMS.
+COND_GAMMA = (0.3, 0.6)
+COND_HEAD_GAIN = 1.0
+
+
+def cond_bn_path(arch: str, seed: int) -> str:
+    return os.path.join(_DATA, f"synth_bn_{arch}_s{seed}_cond.npz")
+
+
+def conditioned_weights(template: Dict[str, torch.Tensor], arch: str, seed: int = 0, path: Optional[str] = None) -> Dict[str, torch.Tensor]:
+    """The conditioned recipe: `synth_state_dict` with COND_GAMMA / COND_HEAD_GAIN, the BatchNorm statistics and the tuned objectness
+    bias from the committed calibration file (oracle/make_synth_bn.py --cond)."""
+    path = path or cond_bn_path(arch, seed)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"no committed conditioned calibration for arch={arch} seed={seed}: {path} (run oracle/make_synth_bn.py --cond)")
+    z = np.load(path)
+    sd = synth_state_dict(template, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=float(z["__obj_bias__"]), bn_gamma=COND_GAMMA)
+    prefix = "model." if any(k.startswith("model.") for k in sd) else ""
+    for k in z.files:
+        if k.startswith("__"):
+            continue
+        if prefix + k not in sd:
+            raise KeyError(f"calibration key {prefix + k} not in state_dict")
+        sd[prefix + k] = torch.from_numpy(z[k].astype(np.float32))
+    return sd
 
 
 def synth_images(n: int, h: int = 640, w: int = 640, seed: int = 1) -> torch.Tensor:

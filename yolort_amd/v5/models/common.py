@@ -117,7 +117,7 @@ class C3(HipModule):
     def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "c3") -> View:
         c_ = self.cv1.conv.out_channels
         nb = len(self.m)
-        # opt-in (YOLORT_AMD_FUSE_C3=1, engine.Plan.fuse_c3): the whole block in one launch when it is the instance
+        # default (YOLORT_AMD_FUSE_C3=0 turns it off, engine.Plan.fuse_c3): the whole block in one launch when it is the instance
         # csrc/c3_fused32.hip holds -- 64 -> 64, one shortcut Bottleneck of 32 hidden channels (yolov5s backbone.body.2)
         if (getattr(plan, "fuse_c3", False) and not plan.use_v1 and nb == 1 and c_ == 32 and x.c == 64 and self.cv3.conv.out_channels == 64
                 and isinstance(self.m[0], Bottleneck) and self.m[0].add and self.m[0].cv1.conv.kernel_size == (1, 1) and self.m[0].cv2.conv.kernel_size == (3, 3)
