@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import yolov5_oracle as O  # noqa: E402
-from yolort_amd.utils.synth import synth_bn_path, synth_images, synth_state_dict  # noqa: E402
+from yolort_amd.utils.synth import COND_GAMMA, COND_HEAD_GAIN, COND_SIZE, cond_bn_path, cond_images, synth_bn_path, synth_images, synth_state_dict  # noqa: E402
 
 
 def reference_template(arch: str):
@@ -55,7 +55,73 @@ def calibrate(arch: str, seed: int = 0, calib_hw: int = 0, calib_n: int = 0):
           "->", synth_bn_path(arch, seed), os.path.getsize(synth_bn_path(arch, seed)) // 1024, "KB")
 
 
+# ---- the conditioned recipe (yolort_amd/utils/synth.py: COND_*): BatchNorm statistics at the resolution the parity workload runs at, and the
+# objectness bias tuned so that about COND_TARGET (anchor, class) pairs per image pass the threshold on the seeded tuning batch ----
+COND = {a: (s, 2) for a, s in COND_SIZE.items()}   # (resolution, calibration images)
+COND_TARGET = 10
+COND_THRESH = 0.25
+
+
+def photo_images():
+    """the reference's two asset photos as decoded (tests/golden/*.png, written by tests/golden/make_golden.py from test/assets/*.jpg), CHW fp32 / 255"""
+    from PIL import Image
+    out = []
+    for name in ("bus", "zidane"):
+        a = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", name + ".png")).convert("RGB"))
+        out.append(torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32) / 255.0)
+    return out
+
+
+def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, thr: float = COND_THRESH, photo: bool = False):
+    S, n = COND[arch]
+    try:
+        tmpl = reference_template(arch)
+    except Exception:
+        from yolort_amd.models import yolo as Y
+        tmpl = Y.__dict__[arch]().state_dict()
+    sd = synth_state_dict(tmpl, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=0.0, bn_gamma=COND_GAMMA)
+    div = 64 if arch.endswith("6_r60") else 32
+    imgs = photo_images() if photo else cond_images(arch, seed)
+    batch, _ = O.letterbox(imgs, S, S, div)
+    calib = batch if photo else synth_images(n, S, S, seed=1000 + seed)
+    O.CALIB.active = True
+    try:
+        with torch.no_grad():
+            O.backbone(calib, sd, "backbone")
+    finally:
+        O.CALIB.active = False
+    with torch.no_grad():
+        ho = O.head(O.backbone(batch, sd, "backbone"), sd, "head")
+    obj = torch.cat([h[..., 4].flatten() for h in ho])
+    pc = torch.sigmoid(torch.cat([h[..., 5:].flatten(0, -2) for h in ho]))
+    lo, hi = -14.0, 6.0
+    for _ in range(48):   # bisection on the candidate count (monotone in the bias)
+        mid = 0.5 * (lo + hi)
+        if int((torch.sigmoid(obj + mid)[:, None] * pc > thr).sum()) > target * len(imgs):
+            hi = mid
+        else:
+            lo = mid
+    bias = round(0.5 * (lo + hi), 3)
+    stats = {k: v.numpy().astype(np.float32) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    stats["__obj_bias__"] = np.float32(bias)
+    out = cond_bn_path(arch, seed, "photo" if photo else "cond")
+    np.savez(out, **stats)
+    cand = int((torch.sigmoid(obj + bias)[:, None] * pc > thr).sum())
+    print(arch, "conditioned" + (" (photos)" if photo else "") + ": obj bias", bias, "candidates", cand, "on", len(imgs), "images ->", out, os.path.getsize(out) // 1024, "KB")
+
+
 if __name__ == "__main__":
+    if "--cond" in sys.argv:
+        photo = "--photo" in sys.argv
+        args = [a for a in sys.argv[1:] if a not in ("--cond", "--photo")]
+        seed = 0
+        for a in list(args):
+            if a.startswith("--seed="):
+                seed = int(a.split("=")[1])
+                args.remove(a)
+        for a in args or list(COND):
+            calibrate_conditioned(a, seed, photo=photo)
+        sys.exit(0)
     archs = sys.argv[1:] or ["yolov5_darknet_pan_n_r60", "yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60", "yolov5_darknet_pan_l6_r60"]
     for a in archs:
         calibrate(a)

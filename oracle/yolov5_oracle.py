@@ -160,6 +160,10 @@ class _Emulate:
 
     def __init__(self) -> None:
         self.dtype = None
+        # optional torch.Generator: every rounded tensor takes one extra ulp-level relative perturbation on a random half of its elements --
+        # a different, equally valid rounding history (another summation order / tile).  tests/golden/make_golden.py uses a few of them to
+        # measure the tolerance a 16-bit path can be held to on a workload BEFORE the tolerance is written into a GPU test.
+        self.jitter = None
 
 
 EMULATE = _Emulate()
@@ -178,7 +182,15 @@ TRACE = _Trace()
 
 
 def _q(x: Tensor) -> Tensor:
-    return x.to(EMULATE.dtype).to(torch.float32) if EMULATE.dtype is not None else x
+    if EMULATE.dtype is None:
+        return x
+    y = x.to(EMULATE.dtype).to(torch.float32)
+    if EMULATE.jitter is not None:
+        g = EMULATE.jitter
+        ulp = 2.0 ** (-11 if EMULATE.dtype == torch.float16 else -8)
+        sgn = (torch.rand(y.shape, generator=g) < 0.5).to(torch.float32) * (torch.randint(0, 2, y.shape, generator=g).to(torch.float32) * 2 - 1)
+        y = (y * (1 + sgn * ulp)).to(EMULATE.dtype).to(torch.float32)
+    return y
 
 
 def conv_bn_silu(x: Tensor, sd: Dict[str, Tensor], p: str, stride: int = 1, pad: Optional[int] = None) -> Tensor:

@@ -106,7 +106,212 @@ def e2e_golden(arch="yolov5_darknet_pan_n_r60", tag="n", sizes=((160, 120), (96,
     np.savez_compressed(os.path.join(HERE, f"e2e_{tag}.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 3: goldens that can carry a tolerance.  (1) the CONDITIONED workload (yolort_amd/utils/synth.py COND_*): reference detections,
+# the reference's own fp32-vs-fp64 reproducibility, and the tolerance a 16-bit evaluation can be held to, measured with jittered
+# storage emulations BEFORE it is written into a GPU test.  (2) the reference's asset photos through `predict(path)`.
+# ---------------------------------------------------------------------------------------------------------------------------
+COND_TAGS = {"yolov5_darknet_pan_n_r60": "n", "yolov5_darknet_pan_s_r60": "s", "yolov5_darknet_pan_m_r60": "m", "yolov5_darknet_pan_l6_r60": "l6"}
+
+
+def _np_dets(dets):
+    return [{k: v.detach().cpu().numpy() for k, v in d.items()} for d in dets]
+
+
+def _reference_model(arch, S, thr, sd, dtype=torch.float32):
+    kw = dict(size_divisible=64) if arch.endswith("6_r60") else {}
+    model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr, nms_thresh=0.45, **kw)
+    model.load_state_dict(sd)
+    return model.eval().to(dtype)
+
+
+def _emulated(imgs, sd, S, div, thr, dtype, jitter_seed=None):
+    from oracle import yolov5_oracle as O
+    O.EMULATE.dtype = dtype
+    O.EMULATE.jitter = None if jitter_seed is None else torch.Generator().manual_seed(jitter_seed)
+    try:
+        with torch.no_grad():
+            return _np_dets(O.yolov5_forward(imgs, sd, size=(S, S), size_divisible=div, score_thresh=thr))
+    finally:
+        O.EMULATE.dtype, O.EMULATE.jitter = None, None
+
+
+def _tolerance_of(ref, runs, thr):
+    """the loosest (min IoU, max |dscore|) over the runs, pairing with generous bounds; unpaired = detections no generous pairing explains"""
+    sys.path.insert(0, ROOT)
+    import bench
+    worst = {"min_iou": 1.0, "max_dscore": 0.0, "unexplained": 0, "at_cut": 0, "paired": 10 ** 9}
+    for got in runs:
+        c = bench.direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)
+        worst["min_iou"] = min(worst["min_iou"], c["min_iou"])
+        worst["max_dscore"] = max(worst["max_dscore"], c["max_dscore"])
+        worst["unexplained"] = max(worst["unexplained"], c["unexplained"])
+        worst["at_cut"] = max(worst["at_cut"], c["at_cut"])
+        worst["paired"] = min(worst["paired"], c["paired"])
+    return worst
+
+
+def cond_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2, 3), verbose=True):
+    """reference detections of the conditioned workload + how reproducible they are (fp64, jittered fp16 / bf16 storage)"""
+    import bench
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import COND_SIZE, cond_images, conditioned_weights
+    S = COND_SIZE[arch]
+    div = 64 if arch.endswith("6_r60") else 32
+    kw = dict(size_divisible=64) if div == 64 else {}
+    tmpl = YOLOv5(arch=arch, size=(S, S), **kw).state_dict()
+    sd = conditioned_weights(tmpl, arch, seed)
+    imgs = cond_images(arch, seed)
+    with torch.no_grad():
+        ref = _np_dets(_reference_model(arch, S, thr, sd).predict(imgs))                    # the UNMODIFIED reference, fp32
+        ref64 = _np_dets(_reference_model(arch, S, thr, sd, torch.float64).predict([im.double() for im in imgs]))   # ... and in float64
+        ora = _np_dets(O.yolov5_forward(imgs, sd, size=(S, S), size_divisible=div, score_thresh=thr))
+    for r in ref64:
+        r["boxes"], r["scores"] = r["boxes"].astype(np.float32), r["scores"].astype(np.float32)
+    c64 = bench.direct_checks(ref, ref64, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    cor = bench.direct_checks(ref, ora, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    # margins of the discrete decisions of the reference run: score gaps between consecutive detections of an image (label-sequence
+    # equality needs |dscore| below half of it) and the distance of every detection from the threshold
+    gap, thr_margin = 1.0, 1.0
+    for r in ref:
+        s = r["scores"]
+        if len(s) > 1:
+            gap = min(gap, float(np.min(-np.diff(s))))
+        if len(s):
+            thr_margin = min(thr_margin, float(s.min() - thr))
+    tol = {}
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        tol[name] = _tolerance_of(ref, [_emulated(imgs, sd, S, div, thr, dt, j) for j in jitters], thr)
+    out = {"arch": arch, "seed": seed, "S": S, "thr": thr, "dets": [len(r["scores"]) for r in ref], "fp64": c64, "oracle": cor, "min_score_gap": gap,
+           "thr_margin": thr_margin, "tol": tol}
+    if verbose:
+        print(json.dumps(out))
+    return out, ref
+
+
+def cond_ok(ev):
+    """a seed is usable when the reference reproduces itself exactly in fp64 (every detection paired at 1 - 1e-3, same label sequence), the
+    restatement agrees, the discrete margins are wide against fp32 noise, and no 16-bit rounding history loses a detection outright"""
+    n = len(ev["dets"])
+    ok64 = all(ev[k]["unexplained"] == 0 and ev[k]["at_cut"] == 0 and ev[k]["images_labels_equal"] == n for k in ("fp64", "oracle"))
+    low = "bf16" if ev["arch"].endswith("_m_r60") else "fp16"   # the 16-bit type the architecture's BASELINE config runs in
+    return (ok64 and sum(1 for d in ev["dets"] if d >= 2) >= 2 and max(ev["dets"]) <= 150 and ev["min_score_gap"] >= 1e-4 and ev["thr_margin"] >= 5e-5
+            and ev["tol"][low]["unexplained"] == 0 and ev["tol"][low]["min_iou"] >= (0.9 if low == "bf16" else 0.97))
+
+
+def cond_golden(arch, seeds=range(0, 40)):
+    """searches the seed range for a usable conditioned workload, commits its calibration file and the reference's detections"""
+    import subprocess
+    from yolort_amd.utils.synth import cond_bn_path
+    tag = COND_TAGS[arch]
+    for seed in seeds:
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", f"--seed={seed}", arch], check=True, capture_output=True)
+        ev, ref = cond_evaluate(arch, seed)
+        if cond_ok(ev):
+            out = {"meta": json.dumps(ev)}
+            for i, r in enumerate(ref):
+                for k in ("boxes", "scores", "labels"):
+                    out[f"det{i}_{k}"] = r[k]
+            np.savez_compressed(os.path.join(HERE, f"cond_{tag}.npz"), **out)
+            print("conditioned golden", tag, "seed", seed, "dets", ev["dets"], "tolerances", ev["tol"])
+            return seed
+        os.remove(cond_bn_path(arch, seed))
+    raise RuntimeError(f"no usable seed for {arch} in {list(seeds)}")
+
+
+ASSETS = "/root/reference/test/assets"
+
+
+def photo_pngs():
+    """the reference's asset photos, decoded (PIL = libjpeg-turbo, what torchvision.io.read_image wraps) and committed losslessly: the GPU box has
+    no /root/reference, `predict(path)` there reads these PNGs and gets the identical uint8 arrays"""
+    from PIL import Image
+    for name in ("bus", "zidane"):
+        a = np.asarray(Image.open(os.path.join(ASSETS, name + ".jpg")).convert("RGB"))
+        Image.fromarray(a).save(os.path.join(HERE, name + ".png"), optimize=True)
+        b = np.asarray(Image.open(os.path.join(HERE, name + ".png")).convert("RGB"))
+        assert np.array_equal(a, b)
+        print(name, a.shape, os.path.getsize(os.path.join(HERE, name + ".png")) // 1024, "KB")
+
+
+def photo_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2)):
+    """`model.predict([bus.jpg, zidane.jpg])` of the UNMODIFIED reference (its own default_loader on the JPEG files) with the conditioned weights
+    calibrated on the photos"""
+    import bench
+    from oracle import yolov5_oracle as O
+    from oracle.make_synth_bn import photo_images
+    from yolort_amd.utils.synth import COND_SIZE, conditioned_weights
+    S = COND_SIZE[arch]
+    div = 64 if arch.endswith("6_r60") else 32
+    kw = dict(size_divisible=64) if div == 64 else {}
+    sd = conditioned_weights(YOLOv5(arch=arch, size=(S, S), **kw).state_dict(), arch, seed, variant="photo")
+    paths = [os.path.join(ASSETS, n + ".jpg") for n in ("bus", "zidane")]
+    imgs = photo_images()
+    with torch.no_grad():
+        ref = _np_dets(_reference_model(arch, S, thr, sd).predict(paths))
+        one = _np_dets(_reference_model(arch, S, thr, sd).predict(paths[0]))     # a single path: another canvas (the batch maximum differs)
+        ref64 = _np_dets(_reference_model(arch, S, thr, sd, torch.float64).predict([im.double() for im in imgs]))
+        ora = _np_dets(O.yolov5_forward(imgs, sd, size=(S, S), size_divisible=div, score_thresh=thr))
+    for r in ref64:
+        r["boxes"], r["scores"] = r["boxes"].astype(np.float32), r["scores"].astype(np.float32)
+    c64 = bench.direct_checks(ref, ref64, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    cor = bench.direct_checks(ref, ora, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    gap, thr_margin = 1.0, 1.0
+    for r in ref + one:
+        s = r["scores"]
+        if len(s) > 1:
+            gap = min(gap, float(np.min(-np.diff(s))))
+        if len(s):
+            thr_margin = min(thr_margin, float(s.min() - thr))
+    tol = {}
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        tol[name] = _tolerance_of(ref, [_emulated(imgs, sd, S, div, thr, dt, j) for j in jitters], thr)
+    ev = {"arch": arch, "seed": seed, "S": S, "thr": thr, "dets": [len(r["scores"]) for r in ref], "dets_single": [len(r["scores"]) for r in one], "fp64": c64,
+          "oracle": cor, "min_score_gap": gap, "thr_margin": thr_margin, "tol": tol}
+    print(json.dumps(ev))
+    return ev, ref, one
+
+
+def photo_golden(arch, seeds=range(0, 30)):
+    import subprocess
+    from yolort_amd.utils.synth import cond_bn_path
+    tag = COND_TAGS[arch]
+    for seed in seeds:
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", "--photo", f"--seed={seed}", arch], check=True, capture_output=True)
+        ev, ref, one = photo_evaluate(arch, seed)
+        n = len(ev["dets"])
+        ok = (all(ev[k]["unexplained"] == 0 and ev[k]["at_cut"] == 0 and ev[k]["images_labels_equal"] == n for k in ("fp64", "oracle"))
+              and min(ev["dets"]) >= 2 and max(ev["dets"]) <= 100 and ev["min_score_gap"] >= 1e-4 and ev["thr_margin"] >= 5e-5)
+        if ok:
+            out = {"meta": json.dumps(ev)}
+            for i, r in enumerate(ref):
+                for k in ("boxes", "scores", "labels"):
+                    out[f"det{i}_{k}"] = r[k]
+            for k in ("boxes", "scores", "labels"):
+                out[f"single_{k}"] = one[0][k]
+            np.savez_compressed(os.path.join(HERE, f"photo_{tag}.npz"), **out)
+            print("photo golden", tag, "seed", seed, "dets", ev["dets"], "single", ev["dets_single"], "tolerances", ev["tol"])
+            return seed
+        os.remove(cond_bn_path(arch, seed, "photo"))
+    raise RuntimeError(f"no usable seed for {arch} in {list(seeds)}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "photo":
+        if not os.path.exists(os.path.join(HERE, "bus.png")):
+            photo_pngs()
+        seeds = [int(a) for a in sys.argv[2:] if a.isdigit()]
+        for a in [a for a in sys.argv[2:] if not a.isdigit()] or ["yolov5_darknet_pan_s_r60"]:
+            photo_golden(a, seeds or range(0, 30))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cond":
+        seeds = [int(a) for a in sys.argv[2:] if a.isdigit()]   # usage: cond [arch ...] [seed ...]
+        for a in [a for a in sys.argv[2:] if not a.isdigit()] or list(COND_TAGS):
+            cond_golden(a, seeds or range(0, 40))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cond-eval":
+        cond_evaluate(sys.argv[2], int(sys.argv[3]))
+        sys.exit(0)
     letterbox_golden()
     anchors_decode_golden()
     e2e_golden()

@@ -47,3 +47,49 @@ int sim_conv2d_v2(const ymi::ConvArgs& a, const ymi_conv_desc* d) {
     if (d->out_dtype != d->dtype) { ymi::set_error("sim_conv2d: fp32 outputs through tile 21 only"); return YMI_EINVAL; }
     return d->dtype == YMI_F16 ? sim_v2<YMI_F16>(a, is1x1, d->tile) : sim_v2<YMI_BF16>(a, is1x1, d->tile);
 }
+
+// ---- the fused detection head (head_decode.hpp: 1x1 head conv with sigmoid / anchor decode / multi-label threshold in its epilogue, all
+// levels in one launch).  The host side mirrors conv_igemm.hip's head_decode_prepare / conv_head_decode_group_launch (that file, the
+// dispatcher of every tile group, is not part of this build -- like sim_fill.h mirrors its fill_conv_args).  Anchor-split form only
+// (one anchor per block: what the product launches), K + 5 <= 96 outputs per anchor.
+#include "sim_fill.h"
+extern "C" int sim_conv_head_decode_group(const ymi_conv_desc* descs, int n_levels, const ymi_post_desc* post) {
+    using namespace ymi;
+    if (descs == nullptr || post == nullptr || n_levels < 1 || n_levels > YMI_MAX_LEVELS || n_levels != post->num_levels) { set_error("sim_conv_head_decode_group: bad arguments"); return YMI_EINVAL; }
+    const int K = post->num_classes + 5, ra = (K + 31) / 32 * 32, tna = ra / 32;
+    const PostLayout L = post_layout(post);
+    const Workspace w = carve(post->ws, post->n, L.total_anchors, post->cand_cap);
+    if (post->ws_bytes < (int64_t)w.total) { set_error("sim_conv_head_decode_group: workspace too small"); return YMI_EINVAL; }
+    static HeadGroupArgs g;   // static: the kernels read it through the "kernarg segment pointer"
+    memset(&g, 0, sizeof(g));
+    g.n = n_levels;
+    int blocks = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const ymi_conv_desc* d = &descs[l];
+        if (d->cout != 3 * ra || d->cout_pad != 3 * ra || d->cin % 32 || d->k_pad != d->cin) { set_error("sim_conv_head_decode_group: level %d is not an anchor-padded pointwise head", l); return YMI_EINVAL; }
+        sim_fill(d, g.a[l]);
+        g.a[l].nblk_m = cdiv(g.a[l].M, 128);
+        g.a[l].nblk_n = 3;
+        HeadDecodeArgs& h = g.h[l];
+        h.stride = post->stride[l];
+        for (int k = 0; k < 6; ++k) h.anc[k] = post->anchors[l][k];
+        h.K = K;
+        h.level_off = 0;
+        for (int j = 0; j < l; ++j) h.level_off += 3 * post->lh[j] * post->lw[j];
+        h.sink = make_sink(post, w, L);
+    }
+    for (int l = n_levels - 1; l >= 0; --l) {
+        g.first_block[l] = blocks;
+        blocks += g.a[l].nblk_m * g.a[l].nblk_n;
+    }
+    g.first_block[n_levels] = blocks;
+    if (blocks == 0) return YMI_OK;
+    const bool f16 = descs[0].dtype == YMI_F16;
+    switch (tna) {
+        case 1: return f16 ? launch_head_group<YMI_F16, 1>(g, nullptr) : launch_head_group<YMI_BF16, 1>(g, nullptr);
+        case 3: return f16 ? launch_head_group<YMI_F16, 3>(g, nullptr) : launch_head_group<YMI_BF16, 3>(g, nullptr);
+        default: break;
+    }
+    set_error("sim_conv_head_decode_group: anchor padding %d is not instantiated in the simulator build", ra);
+    return YMI_EINVAL;
+}

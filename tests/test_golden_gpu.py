@@ -1,0 +1,139 @@
+"""End-to-end parity against detections of the UNMODIFIED reference, on workloads that can carry a tolerance (round 3).
+
+Two committed golden sets, both produced in the build container by tests/golden/make_golden.py from the reference itself
+(`yolort.models.YOLOv5(...).predict(...)`, CPU fp32) with the CONDITIONED synthetic weights (yolort_amd/utils/synth.py, COND_*):
+
+  * `cond_<tag>.npz`  -- four seeded U[0,1) images of mixed shapes (identity, two paddings, one down-scale);
+  * `photo_<tag>.npz` -- the reference's asset photos test/assets/{bus,zidane}.jpg through `predict([path, path])` and `predict(path)`
+    (reference yolov5.py:203-228); the decoded arrays are committed as tests/golden/{bus,zidane}.png, so `default_loader` here
+    decodes the identical uint8 pixels.
+
+Each golden carries, measured when it was made: the reference's own fp32-vs-float64 reproducibility (every detection paired at
+IoU >= 1 - 1e-3, identical label sequences -- the workload CAN carry the north-star tolerance, unlike round 2's saturated
+noise-image workload), the margins of its discrete decisions (smallest score gap, distance from the threshold) and the tolerance
+a 16-bit evaluation was observed to meet under several independent rounding histories (jittered storage emulation).
+
+What is asserted here:
+  * fp32 parity mode: EVERY reference detection paired with the same label, IoU >= 1 - 1e-3, |dscore| <= 1e-4; equal counts and
+    identical label SEQUENCES in every image; nothing unexplained, nothing excused at the cut.
+  * production 16-bit path, STATED tolerance:  fp16  IoU >= 0.98 and |dscore| <= 1e-2 on the benchmarked architecture (yolov5s) and yolov5l6;
+                                                     IoU >= 0.95 and |dscore| <= 3e-2 on yolov5n (a quarter of the channels: less averaging per output);
+                                                     photos: IoU >= 0.90, |dscore| <= 3e-2
+                                               bf16  IoU >= 0.90 and |dscore| <= 6e-2 (yolov5m)
+    every reference detection further than the score tolerance from the threshold must be paired; nothing else may appear.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bench import direct_checks
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+ARCH = {"n": "yolov5_darknet_pan_n_r60", "s": "yolov5_darknet_pan_s_r60", "m": "yolov5_darknet_pan_m_r60", "l6": "yolov5_darknet_pan_l6_r60"}
+# stated 16-bit tolerances (min IoU, max |dscore|); the goldens' measured figures (meta["tol"]) sit inside them with a factor ~2 to spare
+TOL = {("cond", "s"): (0.98, 1e-2), ("cond", "l6"): (0.98, 1e-2), ("cond", "n"): (0.95, 3e-2), ("cond", "m"): (0.90, 6e-2), ("photo", "s"): (0.90, 3e-2)}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from yolort_amd import _lib
+    _lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _golden(kind, tag):
+    path = os.path.join(GOLD, f"{kind}_{tag}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not committed")
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    n = len(meta["dets"])
+    ref = [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(n)]
+    single = {k: z[f"single_{k}"] for k in ("boxes", "scores", "labels")} if "single_boxes" in z.files else None
+    return meta, ref, single
+
+
+def _model(meta, dev, dtype, variant):
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import conditioned_weights
+    arch, S = meta["arch"], meta["S"]
+    kw = dict(size_divisible=64) if arch.endswith("6_r60") else {}
+    m = YOLOv5(arch=arch, size=(S, S), score_thresh=meta["thr"], nms_thresh=0.45, **kw)
+    m.load_state_dict(conditioned_weights(m.state_dict(), arch, meta["seed"], variant=variant))
+    m = m.to(dev).eval()
+    if dtype == torch.float32:
+        m.set_compute_dtype(torch.float32)
+    else:
+        m = m.to(dtype)
+    return m
+
+
+def _np(d):
+    return {k: v.detach().float().cpu().numpy() if k != "labels" else v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def _assert_fp32(ref, got, thr, what):
+    c = direct_checks(ref, got, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    print(what, "fp32 parity mode:", c)
+    n = len(ref)
+    assert c["ref_dets"] >= 10
+    assert c["paired"] == c["ref_dets"] == c["hip_dets"], c
+    assert c["unexplained"] == 0 and c["at_cut"] == 0, c
+    assert c["images_equal_count"] == n and c["images_labels_equal"] == n, c
+    assert c["min_iou"] >= 1 - 1e-3 and c["max_dscore"] <= 1e-4, c
+
+
+def _assert_16bit(ref, got, thr, tol, what):
+    iou_min, ds = tol
+    c = direct_checks(ref, got, thr, score_eps=ds, iou_min=iou_min)
+    print(what, f"16-bit path, stated tolerance IoU >= {iou_min}, |dscore| <= {ds}:", c)
+    assert c["unexplained"] == 0, c                       # every detection beyond the tolerance from the threshold is paired
+    assert c["paired"] >= c["ref_dets"] - c["at_cut"] and c["at_cut"] <= max(4, c["ref_dets"] // 3), c
+    assert c["min_iou"] >= iou_min and c["max_dscore"] <= ds, c
+
+
+@pytest.mark.parametrize("tag", ["s", "n", "m", "l6"])
+def test_conditioned_workload_fp32_mode_reproduces_the_reference_exactly(dev, tag):
+    from yolort_amd.utils.synth import cond_images
+    meta, ref, _ = _golden("cond", tag)
+    m = _model(meta, dev, torch.float32, "cond")
+    imgs = cond_images(meta["arch"], meta["seed"])
+    got = [_np(d) for d in m.predict([im.to(dev) for im in imgs])]
+    _assert_fp32(ref, got, meta["thr"], f"cond_{tag}")
+
+
+@pytest.mark.parametrize("tag,dtype", [("s", torch.float16), ("n", torch.float16), ("m", torch.bfloat16), ("l6", torch.float16)])
+def test_conditioned_workload_16bit_path_meets_the_stated_tolerance(dev, tag, dtype):
+    from yolort_amd.utils.synth import cond_images
+    meta, ref, _ = _golden("cond", tag)
+    m = _model(meta, dev, dtype, "cond")
+    imgs = cond_images(meta["arch"], meta["seed"])
+    got = [_np(d) for d in m.predict([im.to(dev).to(dtype) for im in imgs])]
+    _assert_16bit(ref, got, meta["thr"], TOL[("cond", tag)], f"cond_{tag}")
+
+
+@pytest.mark.parametrize("tag", ["s"])
+def test_predict_paths_of_the_reference_photos_fp32_mode(dev, tag):
+    """`predict([bus, zidane])` and `predict(bus)` through default_loader (PIL decode -> uint8 HWC -> the letterbox kernel's fused permute + /255)"""
+    meta, ref, single = _golden("photo", tag)
+    m = _model(meta, dev, torch.float32, "photo")
+    paths = [os.path.join(GOLD, "bus.png"), os.path.join(GOLD, "zidane.png")]
+    got = [_np(d) for d in m.predict(paths)]
+    _assert_fp32(ref, got, meta["thr"], f"photo_{tag}")
+    one = [_np(d) for d in m.predict(paths[0])]
+    c = direct_checks([single], one, meta["thr"], score_eps=1e-4, iou_min=1 - 1e-3)
+    print("single path:", c)
+    assert c["paired"] == c["ref_dets"] == c["hip_dets"] and c["images_labels_equal"] == 1, c
+
+
+@pytest.mark.parametrize("tag,dtype", [("s", torch.float16)])
+def test_predict_paths_of_the_reference_photos_16bit(dev, tag, dtype):
+    meta, ref, _ = _golden("photo", tag)
+    m = _model(meta, dev, dtype, "photo")
+    got = [_np(d) for d in m.predict([os.path.join(GOLD, "bus.png"), os.path.join(GOLD, "zidane.png")])]
+    _assert_16bit(ref, got, meta["thr"], TOL[("photo", tag)], f"photo_{tag}")

@@ -69,6 +69,7 @@ def sim():
     lib.ymi_postprocess_ws_bytes.argtypes, lib.ymi_postprocess_ws_bytes.restype = [C.c_int, C.c_int, C.c_int], C.c_int64
     lib.ymi_postprocess.argtypes, lib.ymi_postprocess.restype = [C.POINTER(PostDesc), C.c_void_p], C.c_int
     lib.ymi_post_begin.argtypes, lib.ymi_post_finish.argtypes = [C.POINTER(PostDesc), C.c_void_p], [C.POINTER(PostDesc), C.c_void_p]
+    lib.sim_conv_head_decode_group.argtypes, lib.sim_conv_head_decode_group.restype = [C.POINTER(ConvDesc), C.c_int, C.POINTER(PostDesc)], C.c_int
     lib.ymi_batched_nms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ymi_copy_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.ymi_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -388,6 +389,28 @@ def test_letterbox_kernels_vs_oracle(sim, kernel, monkeypatch):
     assert torch.equal(hwc8, got8)   # the interleaved ingest equals the planar one bit for bit
 
 
+def test_letterbox_tile_whose_columns_map_to_one_uint8_source_column(sim, monkeypatch):
+    """an up-scaled uint8 planar image whose resized region ends one column into a 128-column tile ((pl + wr - 1) % 128 == 0): the tile
+    stages ONE source column (span 1, one 16-byte chunk per staged row) -- the chunk -> (row, column) reciprocal wrapped to 0 there and only
+    plane 0 / row 0 was staged.  The tiled kernel must equal the per-pixel kernel bit for bit."""
+    from yolort_amd._lib import dtype_code
+    g = torch.Generator().manual_seed(5)
+    outs = {}
+    for knob in ("default", "pixel"):
+        monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
+        if knob != "default":
+            monkeypatch.setenv("YOLORT_AMD_LETTERBOX", knob)
+        for hin, win, hr, wr, pt, pl, hb, wb in [(8, 65, 16, 129, 0, 0, 32, 160), (9, 33, 27, 257, 3, 0, 32, 288), (5, 40, 10, 125, 2, 4, 32, 160)]:
+            im = torch.randint(0, 256, (3, hin, win), generator=torch.Generator().manual_seed(hin * win), dtype=torch.uint8).contiguous()
+            ptrs = (C.c_void_p * 1)(im.data_ptr())
+            geom = (C.c_int32 * 6)(hin, win, hr, wr, pt, pl)
+            out = torch.full((1, hb, wb, 4), 7.0, dtype=torch.float32)
+            _check(sim, sim.ymi_letterbox(ptrs, geom, 1, dtype_code(torch.uint8), out.data_ptr(), hb, wb, 4, dtype_code(torch.float32), C.c_float(114.0), None))
+            outs.setdefault(knob, []).append(out)
+    for a, b in zip(outs["default"], outs["pixel"]):
+        assert torch.equal(a, b)
+
+
 def test_letterbox_identity_sizes_are_exact(sim):
     from oracle import yolov5_oracle as O
     from yolort_amd.utils.synth import synth_images
@@ -500,6 +523,96 @@ def test_postprocess_vs_oracle(sim, thr, k):
         gain, px, py = rescale[i].tolist()
         want = (r["boxes"] - torch.tensor([px, py, px, py])) / gain
         np.testing.assert_allclose(boxes[i, :c].numpy(), want.numpy(), rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype,nc", [(torch.float16, 80), (torch.bfloat16, 11)])
+def test_fused_head_decode_equals_the_unfused_head(sim, dtype, nc):
+    """conv_head_decode_group_kernel (head_decode.hpp: 1x1 head conv of box_head.py:74 with the sigmoid / anchor decode / multi-label threshold of
+    :328-360, :418 in its epilogue, all levels in one launch) against the unfused form -- fp32 logits from the implicit GEMM, then decode_kernel --
+    through the rest of the post-process: counts, labels, order, scores and boxes IDENTICAL.  Waves span two images at the 3x5 / 5x7 levels
+    (the record buffer changes image mid-wave) and the threshold is low enough for the worklist to drain more than once per wave.  The per-wave
+    worklist / record buffer hand data between lanes through LDS: on the simulator (lanes not in lockstep) this passes only with the wave
+    fences of head_decode.hpp, and it passes under both lane orders (HIPSIM_REVERSE=1)."""
+    from oracle import yolov5_oracle as O
+    from yolort_amd import engine
+    from yolort_amd._lib import ACT_NONE, PostDesc, dtype_code
+    from yolort_amd.models.box_head import YOLOHead
+    cpu = torch.device("cpu")
+    g = torch.Generator().manual_seed(3 + nc)
+    n, thr, k = 3, 0.05, 100
+    chans, shapes = [32, 64, 96], [(12, 13), (5, 7), (3, 5)]
+    head = YOLOHead(chans, 3, [8, 16, 32], nc).eval()
+    kk = nc + 5
+    with torch.no_grad():
+        for m in head.head:
+            m.weight.copy_((torch.randn(m.weight.shape, generator=g) * (1.5 / m.weight.shape[1] ** 0.5)).to(dtype).float())
+            b = torch.zeros(3, kk)
+            b[:, 4], b[:, 5:] = -1.5, -2.5
+            m.bias.copy_(b.view(-1))
+    feats = [torch.randn(n, c, h, w, generator=g).to(dtype).float() for c, (h, w) in zip(chans, shapes)]
+    xs = [Buf(n, h, w, c, dtype, fill=f.permute(0, 2, 3, 1)) for f, c, (h, w) in zip(feats, chans, shapes)]
+    strides, anchors = O.anchors_for(3)
+    total_anchors = sum(3 * h * w for h, w in shapes)
+    rescale = torch.tensor([[1.0, 0.0, 0.0]] * n, dtype=torch.float32)
+
+    def post_desc(cap, logits=None):
+        out = dict(boxes=torch.zeros(n, k, 4), scores=torch.zeros(n, k), labels=torch.zeros(n, k, dtype=torch.int64), count=torch.zeros(n, dtype=torch.int32),
+                   status=torch.zeros(4, dtype=torch.int32), ws=torch.full((int(sim.ymi_postprocess_ws_bytes(n, total_anchors, cap)),), 0x7f, dtype=torch.uint8))
+        d = PostDesc()
+        for i, (h, w) in enumerate(shapes):
+            d.lh[i], d.lw[i], d.stride[i] = h, w, float(strides[i])
+            for j in range(6):
+                d.anchors[i][j] = float(anchors[i][j])
+            if logits is not None:
+                d.logits[i], d.lcstride[i] = logits[i].data_ptr(), logits[i].shape[3]
+        d.num_levels, d.n, d.num_classes = 3, n, nc
+        d.score_thresh, d.nms_thresh, d.detections_per_img = thr, 0.45, k
+        d.rescale = rescale.data_ptr()
+        d.out_boxes, d.out_scores, d.out_labels, d.out_count = out["boxes"].data_ptr(), out["scores"].data_ptr(), out["labels"].data_ptr(), out["count"].data_ptr()
+        d.status, d.ws, d.ws_bytes, d.cand_cap, d.flags = out["status"].data_ptr(), out["ws"].data_ptr(), out["ws"].numel(), cap, 1   # exact full pass: no score prefix
+        return d, out
+
+    cap = n * 16384
+    # ---- unfused: fp32 logits (tile 21) + ymi_postprocess ----
+    logits = []
+    for i, (xb, (h, w)) in enumerate(zip(xs, shapes)):
+        pc = head.packed(i, dtype, cpu, chans[i])
+        cs = (3 * kk + 3) // 4 * 4
+        lg = torch.zeros(n, h, w, cs, dtype=torch.float32)
+        d = _conv_desc(xb, pc, Buf(n, h, w, 4, dtype), 21)
+        d.y, d.y_cstride, d.act, d.out_dtype = lg.data_ptr(), cs, ACT_NONE, dtype_code(torch.float32)
+        _check(sim, sim.sim_conv2d(C.byref(d)))
+        logits.append(lg)
+    d_ref, ref = post_desc(cap, logits)
+    _check(sim, sim.ymi_postprocess(C.byref(d_ref), None))
+    assert ref["status"].tolist()[1] == 0 and int(ref["count"].sum()) > 30
+    # ---- fused: post_begin, ONE head launch for the three levels, post_finish ----
+    from yolort_amd._lib import ConvDesc
+    arr = (ConvDesc * 3)()
+    keep = []
+    for i, (xb, (h, w)) in enumerate(zip(xs, shapes)):
+        pc = head.packed_anchor_major(i, dtype, cpu, chans[i])
+        keep.append(pc)
+        cd = _conv_desc(xb, pc, xb, 0)
+        cd.y, cd.y_cstride, cd.act, cd.out_dtype = None, 0, ACT_NONE, dtype_code(torch.float32)
+        C.memmove(C.byref(arr, i * C.sizeof(ConvDesc)), C.byref(cd), C.sizeof(ConvDesc))
+    d_f, got = post_desc(cap)
+    _check(sim, sim.ymi_post_begin(C.byref(d_f), None))
+    _check(sim, sim.sim_conv_head_decode_group(arr, 3, C.byref(d_f)))
+    _check(sim, sim.ymi_post_finish(C.byref(d_f), None))
+    assert got["status"].tolist()[1] == 0
+    assert torch.equal(got["count"], ref["count"])
+    for key in ("labels", "scores", "boxes"):
+        for i in range(n):
+            c = int(ref["count"][i])
+            assert torch.equal(got[key][i, :c], ref[key][i, :c]), (key, i)
+    # and against the oracle's decode of the same logits: counts and labels exact
+    heads = [lg[..., : 3 * kk].reshape(n, h, w, 3, kk).permute(0, 3, 1, 2, 4).contiguous() for lg, (h, w) in zip(logits, shapes)]
+    want = O.postprocess(O.decode(heads, strides, anchors), thr, 0.45, k)
+    for i, r in enumerate(want):
+        c = int(got["count"][i])
+        assert c == len(r["scores"])
+        np.testing.assert_array_equal(got["labels"][i, :c].numpy(), r["labels"].numpy())
 
 
 @pytest.mark.parametrize("cout,hw", [(32, (64, 96)), (48, (40, 64)), (16, (32, 64))])

@@ -79,6 +79,16 @@ class _SimLib:
         rc = self.sim.ymi_postprocess(dref, None)
         return self._done(rc, "ymi_postprocess")
 
+    # the fused head: counters, ONE launch for all levels (candidates straight into the workspace), sort / NMS / top-k
+    def ymi_plan_add_post_begin(self, h, dref):
+        return self._done(self.sim.ymi_post_begin(dref, None), "ymi_post_begin")
+
+    def ymi_plan_add_head_decode_group(self, h, arr, n_levels, dref):
+        return self._done(self.sim.sim_conv_head_decode_group(arr, n_levels, dref), "sim_conv_head_decode_group")
+
+    def ymi_plan_add_post_finish(self, h, dref):
+        return self._done(self.sim.ymi_post_finish(dref, None), "ymi_post_finish")
+
     def ymi_postprocess_ws_bytes(self, *a):
         return self.sim.ymi_postprocess_ws_bytes(*a)
 
@@ -155,14 +165,14 @@ def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
         assert err <= 2e-2 * max(1.0, scale)
 
 
-@pytest.mark.parametrize("arch,S,div,gain,dtype", [("yolov5_darknet_pan_n_r60", 96, 32, 0.5, torch.float16), ("yolov5_darknet_pan_l6_r60", 128, 64, 4.0, torch.float16),
-                                                 ("yolov5_darknet_pan_m_r60", 64, 32, 2.0, torch.bfloat16)])
-def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, dtype):
-    """letterbox -> backbone + PAN -> (unfused) head -> decode / sort / NMS / top-k, every kernel on the simulator, driven by the product's
+@pytest.mark.parametrize("arch,S,div,gain,dtype,fused_head", [("yolov5_darknet_pan_n_r60", 96, 32, 0.5, torch.float16, False), ("yolov5_darknet_pan_n_r60", 96, 32, 0.5, torch.float16, True),
+                                                            ("yolov5_darknet_pan_l6_r60", 128, 64, 4.0, torch.float16, True), ("yolov5_darknet_pan_m_r60", 64, 32, 2.0, torch.bfloat16, False)])
+def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, dtype, fused_head):
+    """letterbox -> backbone + PAN -> head -> decode / sort / NMS / top-k, every kernel on the simulator, driven by the product's
     emitters and its host recipe; against the oracle's fp32 forward with the matching criterion of __graft_entry__.smoke().
-    (The head runs in its unfused form -- fp32 logits + decode kernel.  The shipped fused head-decode launch keeps a wave-private worklist
-    in LDS and relies on the lockstep of a wave between its writes and reads; lanes are fibers here, so that kernel is out of the simulator's
-    reach: tried, and the records depended on the order the lanes were scheduled in.  The GPU suite compares the two forms bit for bit.)"""
+    The head runs in its unfused form (fp32 logits + decode kernel) or -- since round 3, when its per-wave worklist got its wave fences -- as
+    the shipped fused head-decode launch (all levels in one launch: what the product records); yolov5m's head inputs are not 32-aligned
+    (the product takes the unfused form there too)."""
     from oracle import yolov5_oracle as O
     from yolort_amd.models import YOLOv5
     from yolort_amd.utils.synth import synth_images, synth_weights
@@ -183,7 +193,6 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, 
     x.as_tensor().copy_(canvas)
     yolo = model.model
     feats = yolo.backbone.emit(plan, x)
-    logits = yolo.head.emit(plan, feats)
     ag = yolo.anchor_generator
     rescale = torch.zeros(n, 3, dtype=torch.float32)
     for i, im in enumerate(imgs):   # transform.py:354-367: gain and pad of each image inside the canvas
@@ -191,7 +200,15 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, 
         gain = min(hb / h0, wb / w0)
         rescale[i] = torch.tensor([gain, (wb - w0 * gain) / 2, (hb - h0 * gain) / 2])
     strides = [float(s_) for s_ in ag.strides]
-    pb = plan.postprocess(logits, strides, ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
+    if fused_head:   # what YOLO._build_entry records (models/yolo.py): post_begin, the fused heads of all levels in ONE launch, post_finish
+        assert yolo.head.can_fuse_decode(plan, feats)
+        pb, pd = plan.post_desc([(f.h, f.w) for f in feats], n, strides, ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
+        plan.post_begin(pd)
+        yolo.head.emit_fused(plan, feats, pd)
+        plan.post_finish(pd, pb.total_anchors)
+    else:
+        logits = yolo.head.emit(plan, feats)
+        pb = plan.postprocess(logits, strides, ag.anchor_grids, yolo.num_classes, thr, 0.45, 300, 32768 * n, rescale=rescale)
     assert int(pb.status[1]) == 0, pb.status.tolist()
     plan.handle = None
     for i, r in enumerate(ref):

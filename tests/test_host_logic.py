@@ -203,3 +203,78 @@ def test_coco_ap_known_answer_from_the_published_protocol():
     ev.update([d], [{"boxes": g["boxes"], "labels": g["labels"]}])
     out = ev.compute()
     assert abs(out["AP"] - 100 * want) < 1e-6 and abs(out["AP50"] - 100 * (51 + 50 * 2 / 3) / 101) < 1e-6 and abs(out["AP75"] - 100 * (51 + 50 * 2 / 3) / 101) < 1e-6
+
+
+def test_coco_max_dets_is_per_image_and_category():
+    """pycocotools cuts `_dts[imgId, catId]` at maxDets -- per (image, category).  150 high-scoring class-0 false positives
+    must not push a correct, low-scoring class-1 detection out of the evaluation (a per-image cap scored it 0.0)."""
+    import numpy as np
+
+    from yolort_amd.utils.metrics import coco_ap
+    fp = np.tile(np.array([[500, 500, 520, 520]], np.float32), (150, 1)) + np.arange(150, dtype=np.float32)[:, None]
+    g = {"boxes": np.array([[0, 0, 10, 10]], np.float32), "labels": np.array([1]), "scores": np.ones(1, np.float32)}
+    d = {"boxes": np.concatenate([fp, g["boxes"]]), "labels": np.array([0] * 150 + [1]), "scores": np.concatenate([np.linspace(0.99, 0.5, 150), [0.1]]).astype(np.float32)}
+    assert coco_ap([g], [d], num_classes=2, max_dets=100) == 1.0
+    assert coco_ap([g], [d], num_classes=2) == 1.0
+    # ... and within a category the cut is by score: 101 class-1 detections, the correct one scoring lowest, max_dets 100 -> never seen
+    d2 = {"boxes": np.concatenate([fp[:100], g["boxes"]]), "labels": np.ones(101, int), "scores": np.concatenate([np.linspace(0.99, 0.5, 100), [0.1]]).astype(np.float32)}
+    assert coco_ap([g], [d2], num_classes=2, max_dets=100) == 0.0
+    assert coco_ap([g], [d2], num_classes=2) > 0.0
+
+
+def test_coco_area_ranges_known_answer():
+    """COCO's small / medium / large lines (pycocotools evaluateImg: ground truth outside the range is ignored, a detection matched to it is
+    ignored, an unmatched detection outside the range is ignored).  One class: g_small 20x20 (area 400), g_large 100x100 (10 000);
+    d1 0.9 == g_large, d2 0.8 == g_small, d3 0.7 a 200x200 false positive, d4 0.6 a 10x10 false positive.
+      all:    TP TP FP FP -> AP 1.0                      small:  d1 ignored (matched to an ignored box), d2 TP, d3 ignored (unmatched, area out of
+      range), d4 FP after full recall -> AP 1.0          large:  d1 TP, d2 ignored, d3 FP after full recall, d4 ignored -> 1.0
+      medium: no ground truth in range -> not scored (-1)
+    and with d2 moved off its box:  small: d2' (unmatched, area 400 in range) FP, recall 0 -> AP 0;  large unchanged"""
+    import numpy as np
+
+    from yolort_amd.utils.metrics import COCO_AREA_RNG, DetectionEvaluator, coco_ap
+    g = {"boxes": np.array([[0, 0, 20, 20], [100, 100, 200, 200]], np.float32), "labels": np.zeros(2, int), "scores": np.ones(2, np.float32)}
+    d = {"boxes": np.array([[100, 100, 200, 200], [0, 0, 20, 20], [300, 300, 500, 500], [600, 600, 610, 610]], np.float32), "labels": np.zeros(4, int),
+         "scores": np.array([0.9, 0.8, 0.7, 0.6], np.float32)}
+    assert coco_ap([g], [d], 1) == 1.0
+    assert coco_ap([g], [d], 1, area_rng=COCO_AREA_RNG["small"]) == 1.0
+    assert coco_ap([g], [d], 1, area_rng=COCO_AREA_RNG["large"]) == 1.0
+    assert coco_ap([g], [d], 1, area_rng=COCO_AREA_RNG["medium"]) is None
+    d2 = dict(d, boxes=d["boxes"].copy())
+    d2["boxes"][1] = [700, 700, 720, 720]
+    assert coco_ap([g], [d2], 1, area_rng=COCO_AREA_RNG["small"]) == 0.0
+    assert coco_ap([g], [d2], 1, area_rng=COCO_AREA_RNG["large"]) == 1.0
+    # small range where the false positive d4 (area 100, in range) outranks the true positive: precision 1/2 at full recall
+    d3 = dict(d, scores=np.array([0.9, 0.5, 0.7, 0.6], np.float32))
+    assert abs(coco_ap([g], [d3], 1, area_rng=COCO_AREA_RNG["small"]) - 0.5) < 1e-9
+    ev = DetectionEvaluator(1)
+    ev.update([d], [{"boxes": g["boxes"], "labels": g["labels"]}])
+    out = ev.compute()
+    assert out["APs"] == 100.0 and out["APl"] == 100.0 and out["APm"] == -1.0 and out["AP"] == 100.0
+
+
+def test_evaluator_consumes_the_gathered_slab():
+    import numpy as np
+    import torch
+
+    from yolort_amd import dist as ydist
+    from yolort_amd.utils.metrics import DetectionEvaluator
+    rng = np.random.default_rng(0)
+
+    def mk(n):
+        xy = rng.random((n, 2)) * 300
+        wh = rng.random((n, 2)) * 60 + 10
+        return {"boxes": torch.tensor(np.concatenate([xy, xy + wh], 1), dtype=torch.float32), "scores": torch.tensor(rng.random(n), dtype=torch.float32),
+                "labels": torch.tensor(rng.integers(0, 3, n))}
+
+    dets = [mk(7), mk(0), mk(12)]
+    slab = ydist.dets_to_slab(dets, k=16)
+    a, b = DetectionEvaluator(3), DetectionEvaluator(3)
+    tg = [{"boxes": d["boxes"], "labels": d["labels"]} for d in dets]
+    a.update(dets, tg)
+    b.update_from_slab(slab, tg)
+    assert a.compute() == b.compute() and b.compute()["AP"] == 100.0
+    stale = (slab[0], slab[1], slab[2], torch.tensor([7, ydist.SLAB_STALE, 12], dtype=torch.int32))
+    import pytest
+    with pytest.raises(ValueError):
+        DetectionEvaluator(3).update_from_slab(stale, tg)

