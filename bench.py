@@ -195,13 +195,58 @@ def direct_checks(ref, got, thr, k=300, score_eps=5e-4, iou_min=1 - 1e-3):
     return out
 
 
+def conditioned_parity(args, dev):
+    """The parity claim on the workload that can carry it (tests/test_golden_gpu.py): the CONDITIONED synthetic network of this architecture
+    (yolort_amd/utils/synth.py COND_*) on its four seeded images, against detections of the UNMODIFIED reference committed as
+    tests/golden/cond_<tag>.npz (made by tests/golden/make_golden.py in the build container) -- no oracle involved at run time.
+      fp32 parity mode : every detection paired, same label, IoU >= 1 - 1e-3, |dscore| <= 1e-4, identical label sequences
+      production 16-bit: the stated tolerance of tests/test_golden_gpu.py (TOL)"""
+    import numpy as np
+
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import cond_images, conditioned_weights
+
+    tag = {"yolov5_darknet_pan_n_r60": "n", "yolov5_darknet_pan_s_r60": "s", "yolov5_darknet_pan_m_r60": "m", "yolov5_darknet_pan_l6_r60": "l6"}.get(args.arch)
+    path = os.path.join(ROOT, "tests", "golden", f"cond_{tag}.npz")
+    if tag is None or not os.path.exists(path):
+        return None
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    ref = [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(len(meta["dets"]))]
+    tol = {"s": (0.98, 1e-2), "l6": (0.98, 1e-2), "n": (0.95, 3e-2), "m": (0.90, 6e-2)}[tag]
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    S, thr = meta["S"], meta["thr"]
+    imgs = cond_images(args.arch, meta["seed"])
+    dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    out = {"workload": f"conditioned {args.arch} (BN gamma 0.3-0.6, head gain 1.0, tuned objectness bias; seed {meta['seed']}), 4 seeded images of mixed shapes at "
+                       f"{S}, thr {thr}; ground truth = detections of the UNMODIFIED reference (tests/golden/cond_{tag}.npz)",
+           "reference_self_reproducibility_fp64": meta["fp64"]}
+    for name, dtype in (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16)):
+        m = YOLOv5(arch=args.arch, size=(S, S), score_thresh=thr, nms_thresh=0.45, detections_per_img=300, **kw)
+        m.load_state_dict(conditioned_weights(m.state_dict(), args.arch, meta["seed"]))
+        m = m.to(dev).eval()
+        m = m.set_compute_dtype(torch.float32) if dtype == torch.float32 else m.to(dtype)
+        got = [_npd(d) for d in m.forward([im.to(dev) if dtype == torch.float32 else im.to(dev).to(dtype) for im in imgs])]
+        if dtype == torch.float32:
+            out[name] = direct_checks(ref, got, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+        else:
+            c = direct_checks(ref, got, thr, score_eps=tol[1], iou_min=tol[0])
+            c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": tol[1]}
+            c["map_vs_ref_50_95"] = coco_ap(ref, got)
+            out[name] = c
+        del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def parity_sample(args, model, images_gpu, images_cpu, sd, k):
-    """'mAP vs ref' on a bounded sample: HIP detections scored against the oracle's as ground truth, plus the
-    direct checks of the fp32 parity mode"""
+    """'mAP vs ref' of the BENCHMARK workload on a bounded sample: HIP detections scored against the oracle's as ground truth.
+    This workload (U[0,1) noise images, BN gamma ~ 1, ~1000 near-tied candidates per image, 300 kept) is the throughput workload -- it stresses
+    the post-process -- and cannot carry a tight tolerance: a rounding is amplified ~2500x on its way to the logits (DESIGN.md section 2);
+    the parity CLAIM is `conditioned_parity` above."""
     import numpy as np
 
     from oracle import yolov5_oracle as O
-    from yolort_amd.models import YOLOv5
 
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     thr = args.score_thresh
@@ -240,18 +285,10 @@ def parity_sample(args, model, images_gpu, images_cpu, sd, k):
     out = {"images": k, "ref_dets": total, "matched_iou50": round(matched / max(total, 1), 4),
            "median_iou": round(float(np.median(ious)), 4) if ious else None,
            "map_vs_ref_50_95": round(ap, 4) if ap is not None else None,
-           "note": f"oracle (fp32 CPU restatement of the reference) detections as ground truth; the production path stores {args.dtype}"}
+           "note": f"benchmark (saturated noise-image) workload, oracle (fp32 CPU restatement of the reference) detections as ground truth; the production path stores {args.dtype}"}
     if emu is not None:
         ap_emu = coco_ap(refs, [_npd(r) for r in emu])
         out["map_of_oracle_with_emulated_16bit_storage"] = round(ap_emu, 4) if ap_emu is not None else None
-    # fp32 parity mode of the same model (csrc/conv_f32.hip) against the same oracle detections: the north-star tolerance
-    m32 = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=thr, nms_thresh=0.45, detections_per_img=300, **kw)
-    m32.load_state_dict(sd)
-    m32 = m32.to(images_gpu[0].device).eval().set_compute_dtype(torch.float32)
-    got32 = m32.forward([im.to(images_gpu[0].device) for im in cpu])
-    out["fp32_parity_mode_direct_checks"] = direct_checks(refs, [_npd(d) for d in got32], thr)
-    del m32
-    torch.cuda.empty_cache()
     return out
 
 
@@ -363,6 +400,30 @@ def main():
     excl = {k: _elapsed(v) for k, v in yolo.bracket.items()}
     yolo.bracket = None
     mean = lambda v: (sum(v) / len(v)) if v else 0.0  # noqa: E731
+    dyn = None
+    if rank == 0 and world == 1 and args.shapes == "fixed" and not args.no_cpu_baseline:
+        # secondary measurement ("<config>dyn"): the same model on a stream of the 8 cycled image sizes of SURVEY 8d, scaled to this config's
+        # size -- a fixed-size stream never runs the letterbox kernel (the stem reads the planar images), so its HBM figure comes from here
+        sc = args.size / 1280.0
+        dyn_cpu = [synth_images(1, max(32, int(h * sc)), max(32, int(w * sc)), seed=7000 + i)[0] for i, (h, w) in enumerate(C3_SHAPES * ((args.batch + 7) // 8))][: args.batch]
+        dyn_gpu = [im.to(dev).to(dtype) for im in dyn_cpu]
+        for _ in range(3):
+            collect(model.forward_async(dyn_gpu))
+        torch.cuda.synchronize()
+        yolo.bracket = {"pre": ([], []), "conv": ([], []), "post": ([], [])}
+        for _ in range(n_excl):
+            collect(model.forward_async(dyn_gpu))
+            torch.cuda.synchronize()
+        ex2 = {k: _elapsed(v) for k, v in yolo.bracket.items()}
+        yolo.bracket = None
+        in_b = sum(im.numel() * im.element_size() for im in dyn_gpu)
+        hb, wb = e.x.h, e.x.w   # portrait and landscape shapes in one batch: the canvas is the full size x size square, the fixed stream's own plan
+        if ex2["pre"]:
+            ms = mean(ex2["pre"])
+            lbb = in_b + args.batch * hb * wb * 4 * 2
+            dyn = {"workload": f"{args.config}dyn: the same model, bs {args.batch}, the 8 cycled image sizes of SURVEY 8d scaled by {sc:g} -> canvas {hb}x{wb}",
+                   "letterbox_tile2_kernel": {"ms": round(ms, 4), "algorithmic_bytes": lbb, "achieved_GBps": round(lbb / ms / 1e6, 1), "frac_of_hbm_peak": round(lbb / (ms * 1e-3) / HBM_PEAK, 4)},
+                   "conv_ms_per_step_serial": round(mean(ex2["conv"]), 4)}
 
     if rank == 0:
         conv_meta = [m for m in e.plan.meta if m["kind"] == "conv"]
@@ -420,24 +481,41 @@ def main():
                        "gather_second_rounds_rank0": second_rounds[0],
                        "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                        "candidates_per_step_rank0": n_cand, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
+            # `frac` is the PER-LAYER fraction SURVEY.md 8d prescribes (sum over the conv launches of max(flops / MFMA peak, bytes / HBM peak),
+            # divided by the measured conv time) in the SERIAL regime; achieved / peak / frac_hbm are the plain bytes-over-time view of the
+            # same measurement.  The two regimes are spelled out: `serial` = one batch in flight (what rocprofv3's kernel durations add up
+            # to); `pipelined` = the timed region, `batches_in_flight` batches on separate streams filling each other's launch gaps and
+            # partial waves -- the regime `value` is measured in (its step time also holds the letterbox / post-process launches).
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0,
+                         "frac_definition": "per-layer bound (SURVEY 8d): sum_l max(flops_l / 2.5 PFLOP/s, bytes_l / 8 TB/s) / measured serial conv time; 49 of 60 yolov5s layers are HBM-bound",
+                         "frac_hbm": round(achieved * 1e9 / HBM_PEAK, 4),
                          "traffic": traffic,
-                         "kernel": "conv family: conv_igemm_v2_kernel, conv_igemm8_kernel, conv_halo8_kernel, conv3x3_c32_kernel, conv1x1_stream_kernel, conv_stem_planar_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
-                         "launches_per_step": n_conv, "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2), "conv_ms_per_step": round(conv_s * 1e3, 4),
-                         "timing": f"HIP events on the plan's stream around the conv launches, one batch in flight, mean of {n_excl} steps right after the timed region",
-                         "algorithmic_bytes_per_step": bytes_step, "algorithmic_bytes_per_launch": round(bytes_step / max(n_conv, 1)), "algorithmic_flops_per_step": flops_step,
-                         "tflops": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0,
-                         "per_layer_bound_ms": round(bound_s * 1e3, 4), "frac_of_per_layer_bound": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0,
-                         "in_timed_region": {"batches_in_flight": depth, "conv_ms_per_step": round(conv_s_region * 1e3, 4),
-                                             "note": "event brackets inside the timed region: a batch's conv launches share the GPU with its neighbours' kernels"},
-                         "from_step_time": {"frac": round(bytes_step / step_s / HBM_PEAK, 4), "frac_of_per_layer_bound": round(bound_s / step_s, 4),
-                                            "note": "algorithmic conv bytes / ms_per_step: upper bound (the step also holds letterbox + post-process)"},
+                         "kernel": "conv family: conv_igemm_v2_kernel, conv_igemm8_kernel, conv_halo8_kernel, conv3x3_c32_kernel, conv1x1_stream_kernel, c3_fused32_kernel, conv_stem_planar_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
+                         "launches_per_step": n_conv, "algorithmic_bytes_per_step": bytes_step, "algorithmic_bytes_per_launch": round(bytes_step / max(n_conv, 1)),
+                         "algorithmic_flops_per_step": flops_step, "per_layer_bound_ms": round(bound_s * 1e3, 4),
+                         "serial": {"conv_ms_per_step": round(conv_s * 1e3, 4), "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2),
+                                    "frac_of_per_layer_bound": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0, "frac_of_hbm_peak": round(achieved * 1e9 / HBM_PEAK, 4),
+                                    "tflops": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0,
+                                    "timing": f"HIP events on the plan's stream around the conv launches, one batch in flight, mean of {n_excl} steps right after the timed region"},
+                         "pipelined": {"batches_in_flight": depth, "ms_per_step": round(step_s * 1e3, 4),
+                                       "frac_of_per_layer_bound": round(bound_s / step_s, 4), "frac_of_hbm_peak": round(bytes_step / step_s / HBM_PEAK, 4),
+                                       "tflops": round(flops_step / step_s / 1e12, 2),
+                                       "conv_bracket_ms": round(conv_s_region * 1e3, 4),
+                                       "note": "per-layer bound / ms_per_step of the timed region: a LOWER bound on the conv stack's fraction there (the step also holds the "
+                                               "post-process launches); conv_bracket_ms = event brackets around one batch's conv launches while they share the GPU with its neighbours' kernels"},
                          "other_kernels": kernels},
         }
+        if dyn is not None:
+            out["roofline"]["other_kernels"]["dynamic_shape_stream"] = dyn
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.float().cpu() for k, v in model.state_dict().items()}
             k_par = 4 if args.size <= 640 else 2
-            out["parity"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
+            cp = conditioned_parity(args, dev)
+            out["parity"] = {} if cp is None else dict(cp)
+            if cp is not None:   # the headline of the block: the fp32 parity mode's direct checks against the reference's detections
+                out["parity"]["unexplained"] = cp["fp32_parity_mode"]["unexplained"] + cp[f"production_{args.dtype}"]["unexplained"]
+            out["parity"]["benchmark_workload"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
         if args.per_op and world == 1:
             # the per-op profile replays the recorded plan from its NHWC4 input buffer: fill it through the letterbox
