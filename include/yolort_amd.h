@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 2
+#define YMI_ABI_VERSION 3
 
 /* error codes */
 #define YMI_OK 0
@@ -242,6 +242,17 @@ typedef struct ymi_post_desc {
  * to contiguous (3, H, W) images of dtype d->dtype (16-byte aligned, W % 8 == 0).  Output is bit-identical to
  * ymi_letterbox + ymi_conv2d.  Replaces yolort/models/darknetv6.py:81 + common.py:69-70 on that input. */
 int ymi_conv_stem_planar(const ymi_conv_desc* d, const void* const* imgs, int n_imgs, void* stream);
+
+/* The first TWO layers of the r6.0 backbone in one launch, for the same fixed-size streams: `stem` as for ymi_conv_stem_planar
+ * with 32 output channels (its y is not written), `body1` = Conv(32, 64, k=3, s=2, p=1) + BN + SiLU over the stem's output
+ * (its x is not read) -- yolort/models/darknetv6.py:81 and :85-86 with common.py:69-70.  The stem's output, the largest
+ * activation of the network, never reaches memory.  Output is bit-identical to ymi_conv_stem_planar + ymi_conv2d. */
+int ymi_stem_body1_planar(const ymi_conv_desc* stem, const ymi_conv_desc* body1, const void* const* imgs, int n_imgs, void* stream);
+
+/* Measurement aid (bench.py): one wave spins for `spin_us` microseconds of the constant 100 MHz clock and writes
+ * {shader-clock cycles, 100 MHz ticks} to out[0..1] (device memory) -- the shader clock the chip runs at while whatever else
+ * is in flight on other streams executes.  Asynchronous on `stream`. */
+int ymi_clock_probe(uint64_t* out, int spin_us, void* stream);
 
 int64_t ymi_postprocess_ws_bytes(int n, int total_anchors, int cand_cap);
 int ymi_postprocess(const ymi_post_desc* d, void* stream);

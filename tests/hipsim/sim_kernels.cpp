@@ -26,12 +26,14 @@ constexpr int SIM_LDS = 160 * 1024;
 alignas(16) unsigned char f3_sm[SIM_LDS];
 alignas(16) unsigned char st_sm[SIM_LDS];
 alignas(16) unsigned char c32_sm[SIM_LDS];
+alignas(16) unsigned char sb_sm[SIM_LDS];
 alignas(16) uint16_t smem[SIM_LDS / 2];
 }  // namespace ymi
 
 #include "../../yolort_amd/csrc/c3_fused32.hip"
 #include "../../yolort_amd/csrc/conv1x1_stream.hip"
 #include "../../yolort_amd/csrc/conv3x3_c32.hip"
+#include "../../yolort_amd/csrc/stem_body1_fused.hip"
 
 int sim_conv2d_gemm(const ymi::ConvArgs& a, const ymi_conv_desc* d);
 int sim_conv2d_stem(const ymi::ConvArgs& a, const ymi_conv_desc* d);   // sim_kernels_stem.cpp
@@ -50,6 +52,14 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     if ((d->tile >= 11 && d->tile <= 119) || (d->tile >= 141 && d->tile <= 159)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
     ymi::set_error("sim_conv2d: tile %d is not part of the simulator build", d->tile);
     return YMI_EINVAL;
+}
+// stem + body.1 in one launch, from planar images (csrc/stem_body1_fused.hip)
+extern "C" int sim_stem_body1_planar(const ymi_conv_desc* stem, const ymi_conv_desc* body1, const void* const* imgs, int n_imgs) {
+    ymi::ConvArgs a1, a2;
+    sim_fill(stem, a1);
+    sim_fill(body1, a2);
+    if (n_imgs != stem->n || n_imgs != body1->n) { ymi::set_error("sim_stem_body1_planar: %d images for batches of %d / %d", n_imgs, stem->n, body1->n); return YMI_EINVAL; }
+    return ymi::stem_body1_planar_launch(a1, a2, imgs, stem->dtype, nullptr);
 }
 extern "C" const char* sim_last_error(void) { return ymi::g_err; }
 extern "C" int sim_max_lds(void) { return hipsim::g_max_lds; }

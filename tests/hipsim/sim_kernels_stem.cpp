@@ -14,3 +14,4 @@ extern "C" int sim_conv_stem_planar(const ymi_conv_desc* d, const void* const* i
     if (n_imgs != d->n) { ymi::set_error("sim_conv_stem_planar: %d images for a batch of %d", n_imgs, d->n); return YMI_EINVAL; }
     return ymi::conv_stem_planar_launch(a, imgs, d->dtype, d->out_dtype, nullptr);
 }
+

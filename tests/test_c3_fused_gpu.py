@@ -153,3 +153,29 @@ def test_row_transposed_store_tiles_equal_their_base_tiles(dev, tile, base, cout
                        (torch.float16, (8, 128, 80, 80, 1, 1, False))]:
         a, b = run(base, dtype, *cfg), run(tile, dtype, *cfg)
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)), cfg
+
+
+def test_fused_stem_body1_leaves_yolov5s_detections_unchanged(dev, monkeypatch):
+    """stem + body.1 as ONE launch from the planar images (csrc/stem_body1_fused.hip, ymi_stem_body1_planar: the default for fixed-size yolov5s
+    streams since round 3) against the two launches (YOLORT_AMD_FUSE_STEM=0): identical detections, bit for bit; the per-launch parity test
+    (tests/test_parity_gpu.py) compares body.1's output itself"""
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_s_r60"
+    outs = []
+    for shape in ((640, 640), (352, 608)):
+        imgs = [im.to(dev).half() for im in synth_images(3, *shape, seed=5)]
+        res = []
+        for knob in ("0", "1"):
+            monkeypatch.setenv("YOLORT_AMD_FUSE_STEM", knob)
+            model = YOLOv5(arch=arch, size=(640, 640), score_thresh=0.25)
+            model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.4))
+            model = model.to(dev).half().eval()
+            res.append(model.predict(imgs))
+            torch.cuda.synchronize()
+            e = next(iter(model.model._entries.values()))
+            assert e.plan.stem_body1_fusable() == (knob == "1")
+        assert sum(len(a["scores"]) for a in res[0]) > 0
+        for a, b in zip(*res):
+            for k in ("scores", "labels", "boxes"):
+                assert torch.equal(a[k], b[k]), (shape, k)

@@ -65,6 +65,7 @@ def sim():
     lib.ymi_letterbox.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     lib.ymi_nms_ws_bytes.argtypes, lib.ymi_nms_ws_bytes.restype = [C.c_int], C.c_int64
     lib.sim_conv_stem_planar.argtypes, lib.sim_conv_stem_planar.restype = [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int], C.c_int
+    lib.sim_stem_body1_planar.argtypes, lib.sim_stem_body1_planar.restype = [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int], C.c_int
     from yolort_amd._lib import PostDesc
     lib.ymi_postprocess_ws_bytes.argtypes, lib.ymi_postprocess_ws_bytes.restype = [C.c_int, C.c_int, C.c_int], C.c_int64
     lib.ymi_postprocess.argtypes, lib.ymi_postprocess.restype = [C.POINTER(PostDesc), C.c_void_p], C.c_int
@@ -650,6 +651,68 @@ def test_stem_kernels_logic(sim, cout, hw):
         outs.append(yb.view()[..., :cout].clone())
         assert (outs[-1].float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,hw", [(1, (64, 64)), (2, (40, 104)), (1, (36, 72)), (2, (128, 160))])
+def test_fused_stem_body1_equals_the_two_launches(sim, dtype, n, hw):
+    """csrc/stem_body1_fused.hip: Conv(3, 32, 6, 2, 2) -> Conv(32, 64, 3, 2, 1) (darknetv6.py:81, :85-86) in one launch from the planar images,
+    the stem's output living only in LDS -- BIT-IDENTICAL to conv_stem_planar_kernel followed by conv3x3_c32_kernel<2> (what the plan records
+    for yolov5s), on sizes whose tiles are ragged in both directions and whose stem patch crosses the image border on every side"""
+    from yolort_amd import engine
+    from yolort_amd._lib import ACT_SILU, ConvDesc, dtype_code
+    cpu = torch.device("cpu")
+    if dtype == torch.bfloat16 and n * hw[0] * hw[1] > 10000:
+        pytest.skip("the large case runs once (fp16)")
+    g = torch.Generator().manual_seed(7 + hw[0])
+    h, w = hw
+    x = torch.rand(n, 3, h, w, generator=g).to(dtype)
+    w0 = (torch.randn(32, 3, 6, 6, generator=g) / 8).to(dtype).float()
+    b0 = torch.randn(32, generator=g) * 0.2
+    w1 = (torch.randn(64, 32, 3, 3, generator=g) / 12).to(dtype).float()
+    b1 = torch.randn(64, generator=g) * 0.2
+    pc0 = engine.PackedConv(w0, b0, None, dtype, cpu, stem_superpixel=True)
+    pc1 = engine.PackedConv(w1, b1, None, dtype, cpu)
+    hs, ws = h // 2, w // 2
+    ho, wo = (hs - 1) // 2 + 1, (ws - 1) // 2 + 1
+    xb = Buf(n, h, w, 4, dtype)     # never read on the planar paths; its tail is the zero page
+    imgs = [x[i].contiguous() for i in range(n)]
+    ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in imgs])
+
+    def stem_desc(yb):
+        d = ConvDesc()
+        d.x, d.w, d.bias, d.y = xb.ptr, pc0.w.data_ptr(), pc0.bias.data_ptr(), yb.ptr
+        d.n, d.h, d.w_in, d.cin, d.x_cstride = n, h, w // 2, 8, 8
+        d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = hs, ws, 32, pc0.cout_pad, yb.cs
+        d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = 6, 3, 2, 1, 2, 1, pc0.k_pad
+        d.act, d.dtype, d.out_dtype, d.tile = ACT_SILU, dtype_code(dtype), dtype_code(dtype), 41
+        d.zeros = xb.zeros
+        return d
+
+    # ---- the two launches ----
+    s_out = Buf(n, hs, ws, 32, dtype)
+    _check(sim, sim.sim_conv_stem_planar(C.byref(stem_desc(s_out)), ptrs, n))
+    y_sep = Buf(n, ho, wo, 64, dtype)
+    kt = pc1.ktab(ws, 32)
+    d1 = _conv_desc(s_out, pc1, y_sep, 131, k=3, pad=1, stride=2)
+    d1.ktab = kt.data_ptr()
+    _check(sim, sim.sim_conv2d(C.byref(d1)))
+    # ---- one launch (into a channel slice of a wider buffer: nothing outside the slice is written) ----
+    wide = Buf(n, ho, wo, 96, dtype)
+    y_f = wide.slice_c(16, 64)
+    dummy = Buf(n, hs, ws, 32, dtype)
+    d1f = _conv_desc(dummy, pc1, y_f, 131, k=3, pad=1, stride=2)
+    d1f.ktab = kt.data_ptr()
+    _check(sim, sim.sim_stem_body1_planar(C.byref(stem_desc(dummy)), C.byref(d1f), ptrs, n))
+    assert float(dummy.view().float().abs().max()) == 0.0            # the stem's output buffer is untouched
+    got = y_f.view()
+    assert torch.equal(got.view(torch.int16), y_sep.view().view(torch.int16)), f"max difference {(got.float() - y_sep.view().float()).abs().max().item()}"
+    assert float(wide.view()[..., :16].float().abs().max()) == 0.0 and float(wide.view()[..., 80:].float().abs().max()) == 0.0
+    # and against torch (two chained layers: twice the per-launch bound)
+    mid = F.silu(F.conv2d(x.float(), w0, b0, 2, 2)).to(dtype).float()
+    ref = F.silu(F.conv2d(mid, w1, b1, 2, 1)).permute(0, 2, 3, 1)
+    tol = 4e-3 if dtype == torch.float16 else 3.2e-2
+    assert (got.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("k,s_,cin,cout", [(1, 1, 64, 96), (3, 1, 32, 40), (3, 2, 48, 64), (6, 2, 4, 32)])

@@ -10,6 +10,8 @@
     (yolov5n thr 0.45, 2 images) and configs[1] (yolov5s, bs 32).
   * in-kernel box rescale (transform.py:354-367) against the oracle's scale_coords, to 1 ulp.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -205,16 +207,29 @@ def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size
         print("   %.2e  %s  tile %s  %s" % w)
     n_ref_convs = sum(1 for k in known if ".head." not in k)
     assert checked >= n_ref_convs, f"only {checked} of the reference's {n_ref_convs} conv layers were exercised"
-    # the stem as the benchmark runs it (straight from the planar images) equals op 0 on the letterboxed batch
+    # the first layers as the benchmark runs them -- straight from the planar images, the stem alone (ymi_conv_stem_planar) or stem + body.1 as one
+    # launch (ymi_stem_body1_planar, when the plan offers it) -- equal ops 0 (and 1) on the letterboxed batch bit for bit
     if not dynamic and plan.stem_planar_ok(imgs, (size, size)):
         _fill(plan.io[0]["x"], torch.stack(imgs_cpu).to(dtype).float(), dtype)
-        plan.run(0, 1)
+        plan.run(0, 2)
         torch.cuda.synchronize()
-        a = plan.io[0]["y"].as_tensor().clone()
-        plan.io[0]["y"].as_tensor().zero_()
-        plan.stem_from_planar(imgs)
-        torch.cuda.synchronize()
-        assert torch.equal(a, plan.io[0]["y"].as_tensor()), "planar stem differs from the letterbox + NHWC4 stem"
+        y0, y1 = plan.io[0]["y"].as_tensor().clone(), plan.io[1]["y"].as_tensor().clone()
+        os.environ["YOLORT_AMD_FUSE_STEM"] = "0"
+        try:
+            plan.io[0]["y"].as_tensor().zero_()
+            assert plan.stem_from_planar(imgs) == 1
+            torch.cuda.synchronize()
+            assert torch.equal(y0, plan.io[0]["y"].as_tensor()), "planar stem differs from the letterbox + NHWC4 stem"
+        finally:
+            del os.environ["YOLORT_AMD_FUSE_STEM"]
+        if plan.stem_body1_fusable():
+            plan.io[0]["y"].as_tensor().zero_()
+            plan.io[1]["y"].as_tensor().zero_()
+            assert plan.stem_from_planar(imgs) == 2
+            torch.cuda.synchronize()
+            assert torch.equal(y1, plan.io[1]["y"].as_tensor()), "fused stem + body.1 differs from the two launches"
+            assert float(plan.io[0]["y"].as_tensor().abs().max()) == 0.0     # the stem's output never reaches memory
+            print("fused stem + body.1: bit-identical to the two launches")
 
 
 # ------------------------------------------------------------------------------------------------

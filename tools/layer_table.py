@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
-CONV_LIKE = ("ymi::conv", "spp_pool")     # kernels that correspond 1:1 to plan ops of kind conv / pool (incl. the fused head)
+CONV_LIKE = ("ymi::conv", "spp_pool", "ymi::c3_fused", "ymi::stem_body1")     # kernels that correspond 1:1 to plan ops of kind conv / pool (incl. the fused head)
 STEM = ("conv_stem", "letterbox")     # first kernel of a step
 
 
@@ -26,7 +26,7 @@ def dispatches_from_stats(db):
 
 
 def split_steps(disp, n_steps):
-    starts = [i for i, d in enumerate(disp) if d[0].startswith("void ymi::letterbox") or "conv_stem" in d[0]]
+    starts = [i for i, d in enumerate(disp) if d[0].startswith("void ymi::letterbox") or "conv_stem" in d[0] or "stem_body1" in d[0]]
     # a letterbox launch directly followed by a stem is ONE step start
     clean = []
     for i in starts:
@@ -74,7 +74,7 @@ def main():
                 seq.append((kn, s, s + 1, {}))
             seq[seen[did]][3][cn] = v
         # same step splitting as for the trace, keeping the counter dicts
-        starts = [i for i, d in enumerate(seq) if "conv_stem" in d[0] or "letterbox" in d[0]]
+        starts = [i for i, d in enumerate(seq) if "conv_stem" in d[0] or "letterbox" in d[0] or "stem_body1" in d[0]]
         clean = []
         for i in starts:
             if clean and i - clean[-1] <= 2 and "letterbox" in seq[clean[-1]][0]:

@@ -42,9 +42,13 @@ def main():
     torch.cuda.synchronize()
     e = next(iter(m.model._entries.values()))
     if a.ops:
+        ops = [{"name": n, **meta} for n, meta in zip(e.plan.names, e.plan.meta)]
+        if c["shapes"] != "dynamic" and e.plan.stem_body1_fusable():   # ops 0 and 1 run as ONE launch (ymi_stem_body1_planar): one table row, both layers' algorithmic work
+            o0, o1 = ops[0], ops[1]
+            ops = [{**o0, "name": o0["name"] + "+" + o1["name"].split(".")[-1], "flops": o0["flops"] + o1["flops"], "bytes": o0["bytes"] + o1["bytes"],
+                    "ref_convs": 2, "tile": -2, "shape": "stem 3->32 k6 s2 + 32->64 k3 s2 (one launch)"}] + ops[2:]
         with open(a.ops, "w") as f:
-            json.dump({"config": a.config, "steps": a.steps, "batch": c["batch"],
-                       "ops": [{"name": n, **meta} for n, meta in zip(e.plan.names, e.plan.meta)]}, f, indent=1)
+            json.dump({"config": a.config, "steps": a.steps, "batch": c["batch"], "ops": ops}, f, indent=1)
     for _ in range(a.steps):
         m.forward(imgs)
         torch.cuda.synchronize()

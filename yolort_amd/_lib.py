@@ -52,7 +52,7 @@ class C3Desc(C.Structure):
     ]
 
 
-ABI_VERSION = 2   # include/yolort_amd.h YMI_ABI_VERSION
+ABI_VERSION = 3   # include/yolort_amd.h YMI_ABI_VERSION
 POST_EXACT_FULL = 1
 
 
@@ -85,6 +85,8 @@ _SIGS = {
     "ymi_c3_fused": (C.c_int, [C.POINTER(C3Desc), C.c_void_p]),
     "ymi_plan_add_c3_fused": (C.c_int, [C.c_void_p, C.POINTER(C3Desc)]),
     "ymi_conv_stem_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "ymi_stem_body1_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "ymi_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ymi_conv_build_ktab": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "ymi_spp_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ymi_upsample2x": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

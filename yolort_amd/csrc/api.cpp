@@ -114,6 +114,31 @@ extern "C" int ymi_device_count(void) {
     return n;
 }
 
+// ---- measurement aid: the shader clock while the chip is busy (s_memtime counts shader cycles, s_memrealtime a constant 100 MHz) ----
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = t1 - t0;
+    out[1] = r1 - r0;
+}
+extern "C" int ymi_clock_probe(uint64_t* out, int spin_us, void* stream) {
+    YMI_REQUIRE(out != nullptr && spin_us >= 1 && spin_us <= 100000, "ymi_clock_probe: out must be device memory, 1 <= spin_us <= 100000");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, (unsigned long long)spin_us * 100ull);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("ymi_clock_probe: launch failed: %s", hipGetErrorString(e));
+        return YMI_EHIP;
+    }
+    return YMI_OK;
+}
+
 extern "C" ymi_plan* ymi_plan_create(void) { return new (std::nothrow) ymi_plan(); }
 
 static void drop_graph(ymi_plan* p) {

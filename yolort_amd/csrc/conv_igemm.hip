@@ -306,6 +306,27 @@ extern "C" int ymi_conv_stem_planar(const ymi_conv_desc* d, const void* const* i
     return conv_stem_planar_launch(a, imgs, d->dtype, d->out_dtype, (hipStream_t)stream);
 }
 
+extern "C" int ymi_stem_body1_planar(const ymi_conv_desc* stem, const ymi_conv_desc* body1, const void* const* imgs, int n_imgs, void* stream) {
+    using namespace ymi;
+    YMI_REQUIRE(stem != nullptr && body1 != nullptr && imgs != nullptr, "ymi_stem_body1_planar: null argument");
+    YMI_REQUIRE(stem->w && stem->bias && stem->zeros && body1->w && body1->bias && body1->y, "ymi_stem_body1_planar: null buffer (both weights / biases, the zero page and body1.y are required)");
+    YMI_REQUIRE(n_imgs == stem->n && n_imgs == body1->n && n_imgs >= 1, "ymi_stem_body1_planar: %d images for descriptors of batch %d / %d", n_imgs, stem->n, body1->n);
+    YMI_REQUIRE((stem->dtype == YMI_F16 || stem->dtype == YMI_BF16) && body1->dtype == stem->dtype && stem->out_dtype == stem->dtype && body1->out_dtype == stem->dtype,
+                "ymi_stem_body1_planar: both convolutions must compute and store F16 or BF16");
+    YMI_REQUIRE(stem->ho == (stem->h + 2 * stem->ph - stem->kh) / stem->sh + 1 && stem->wo == (stem->w_in + 2 * stem->pw - stem->kw) / stem->sw + 1, "ymi_stem_body1_planar: inconsistent stem output size");
+    YMI_REQUIRE(body1->y_cstride % 8 == 0, "ymi_stem_body1_planar: y_cstride must be a multiple of 8");
+    for (int i = 0; i < n_imgs; ++i) YMI_REQUIRE(imgs[i] != nullptr && ((uintptr_t)imgs[i] & 15) == 0, "ymi_stem_body1_planar: image %d is null or not 16-byte aligned", i);
+    ymi_conv_desc d1 = *stem, d2 = *body1;
+    d1.x = stem->zeros;                              // neither input pointer is read: keep the zero-page offset check of the shared argument builder trivially true
+    d1.y = body1->y;
+    d2.x = body1->zeros ? body1->zeros : stem->zeros;
+    d2.zeros = d2.x;
+    ConvArgs a1, a2;
+    { const int rc_args = fill_conv_args(&d1, a1); if (rc_args != YMI_OK) return rc_args; }
+    { const int rc_args = fill_conv_args(&d2, a2); if (rc_args != YMI_OK) return rc_args; }
+    return stem_body1_planar_launch(a1, a2, imgs, stem->dtype, (hipStream_t)stream);
+}
+
 extern "C" int ymi_conv_head_decode_group(const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* post, void* stream) {
     return ymi::conv_head_decode_group_launch(convs, n_levels, post, (hipStream_t)stream);
 }

@@ -527,12 +527,29 @@ class Plan:
     def post_finish(self, d: PostDesc, total_anchors: int) -> None:
         self._record(self.lib.ymi_plan_add_post_finish(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0, bytes=0.0, shape=f"A={total_anchors}")
 
-    def stem_from_planar(self, images: Sequence[Tensor], stream: Optional[torch.cuda.Stream] = None) -> None:
+    def stem_from_planar(self, images: Sequence[Tensor], stream: Optional[torch.cuda.Stream] = None) -> int:
         """op 0 (the stem conv in super-pixel form) computed straight from planar (3, H, W) images of the compute dtype:
-        identity-size batches skip the letterbox pass and its NHWC4 round trip (ymi_conv_stem_planar)"""
+        identity-size batches skip the letterbox pass and its NHWC4 round trip (ymi_conv_stem_planar).  When op 1 is
+        Conv(32, 64, 3, 2, 1) over op 0's output (yolov5s: darknetv6.py:81, :85-86) both run as ONE launch and the stem's output
+        never reaches memory (ymi_stem_body1_planar; YOLORT_AMD_FUSE_STEM=0 keeps them apart).  Returns the number of leading plan
+        ops it has covered (1 or 2): the caller runs the plan from there."""
         d = self.conv_descs[0]
         ptrs = (C.c_void_p * len(images))(*[im.data_ptr() for im in images])
+        if self.stem_body1_fusable():
+            check(self.lib.ymi_stem_body1_planar(C.byref(d), C.byref(self.conv_descs[1]), ptrs, len(images), _lib.stream_ptr(stream)), "ymi_stem_body1_planar")
+            return 2
         check(self.lib.ymi_conv_stem_planar(C.byref(d), ptrs, len(images), _lib.stream_ptr(stream)), "ymi_conv_stem_planar")
+        return 1
+
+    def stem_body1_fusable(self) -> bool:
+        if os.environ.get("YOLORT_AMD_FUSE_STEM", "1") == "0" or self.fp32:
+            return False
+        d0, d1 = self.conv_descs.get(0), self.conv_descs.get(1)
+        if d0 is None or d1 is None or 1 not in self.io or self.io[1]["x"] is None or self.io[0]["y"] is None:
+            return False
+        return (d0.cout == 32 and d0.out_dtype == d0.dtype and d0.act == ACT_SILU and self.io[1]["x"].ptr == self.io[0]["y"].ptr and self.io[1]["x"].cs == 32
+                and d1.cin == 32 and d1.cout == 64 and (d1.kh, d1.kw, d1.sh, d1.sw, d1.ph, d1.pw) == (3, 3, 2, 2, 1, 1) and d1.k_pad == 288 and d1.act == ACT_SILU
+                and not d1.res and not d1.chain_w and d1.cout_split == 0 and d1.y2_mode == 0 and d1.out_dtype == d1.dtype == d0.dtype and d1.y_cstride % 8 == 0)
 
     def stem_planar_ok(self, images: Sequence[Tensor], canvas_hw: Tuple[int, int]) -> bool:
         d = self.conv_descs.get(0)

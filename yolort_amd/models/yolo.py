@@ -353,8 +353,8 @@ class YOLO(nn.Module):
         x_old = e_old.x
         with torch.cuda.device(x_old.base.device), torch.cuda.stream(e2.main_stream):
             if planar is not None and e2.plan.stem_planar_ok(planar, (x_old.h, x_old.w)):
-                e2.plan.stem_from_planar(planar)
-                return self._submit_entry(e2, rescale_rows, 1, planar=planar).result()
+                first_op = e2.plan.stem_from_planar(planar)
+                return self._submit_entry(e2, rescale_rows, first_op, planar=planar).result()
             if planar is not None:
                 raise YmiError("internal: a planar-stem batch cannot be re-run on a plan without the planar stem")
             e2.x.base.copy_(x_old.base)

@@ -92,13 +92,14 @@ class YOLOv5(nn.Module):
             # the stem reads the planar images itself, the letterbox pass and its NHWC4 copy are skipped (bit-identical)
             planar = model.stem_from_planar and identity and e.plan.stem_planar_ok(images, (hb, wb))
             ev0 = None
+            first_op = 0
             if planar:
                 for im in images:
                     im.record_stream(e.main_stream)
                 if model.bracket is not None:   # measurement hook: the conv bracket starts with the stem
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record(torch.cuda.current_stream())
-                e.plan.stem_from_planar(images)
+                first_op = e.plan.stem_from_planar(images)   # 1, or 2 when the stem and body.1 ran as one launch
             elif model.bracket is not None:
                 l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 l0.record(torch.cuda.current_stream())
@@ -108,7 +109,6 @@ class YOLOv5(nn.Module):
                 model.bracket["pre"][1].append(l1)
             else:
                 self.transform.letterbox_into(images, e.x, sizes, pads)
-            first_op = 1 if planar else 0
             rows = rows_cached
             if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
                 pend = model._submit_entry(e, None, first_op, ev0, planar=images if planar else None)
