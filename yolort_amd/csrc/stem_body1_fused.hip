@@ -12,7 +12,7 @@
 //            LDS patch conv3x3_c32_kernel<2> reads: columns split by parity, 64-byte pixels, 16-byte chunks XOR-swizzled;
 //   stage 2  the 3x3 stride-2 convolution from that patch, folded weights resident in LDS in fragment order, one 32-pixel x
 //            32-cout tile per wave, the shared epilogue.
-// Both weight matrices (9 + 36 KiB) are loaded once per block; the planar patch of tile i+1 is DMA'd while stage 2 of tile i runs.
+// Both weight matrices are loaded once per block (the stem's 9 KiB into registers, body.1's 36 KiB into LDS); the planar patch of tile i+1 is DMA'd while stage 2 of tile i runs.
 // Results are BIT-IDENTICAL to the two separate launches (tests/test_hipsim_kernels.py on the CPU simulator, tests/test_ops_gpu.py).
 #include "conv_common.hpp"
 
@@ -32,14 +32,13 @@ struct SbImgs {
     const uint16_t* img[SB_MAX_IMGS];
 };
 
-constexpr int SB_W1 = 9 * 1024, SB_W2 = 36 * 1024, SB_B2 = 256, SB_PLANAR = SB_PIECES * 1024, SB_PATCH = ((SB_PPIX + 15) / 16) * 1024;
-constexpr int SB_LDS = SB_W1 + SB_W2 + SB_B2 + SB_PLANAR + SB_PATCH;   // 9 + 36 + 0.25 + 18 + 36 KiB
+constexpr int SB_W1 = 0, SB_W2 = 36 * 1024, SB_B2 = 256, SB_PLANAR = SB_PIECES * 1024, SB_PATCH = ((SB_PPIX + 15) / 16) * 1024;
+constexpr int SB_LDS = SB_W1 + SB_W2 + SB_B2 + SB_PLANAR + SB_PATCH;   // 36 + 0.25 + 18 + 36 KiB (the stem weights live in registers)
 
 template <int DT>
 __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs a1, const ConvArgs a2, const SbImgs pl, int tiles_x, int tiles_y, int ntiles) {
     typedef typename Mfma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_sm[];
-    frag* w1l = reinterpret_cast<frag*>(sb_sm);                                         // stem weights   [s][64 lanes] x 16 B
     frag* w2l = reinterpret_cast<frag*>(sb_sm + SB_W1);                                 // body.1 weights [(tap*2 + ks)*2 + i][64 lanes] x 16 B
     f32x4* b2l = reinterpret_cast<f32x4*>(sb_sm + SB_W1 + SB_W2);                       // body.1 bias    [2 tiles][4 groups][2 halves]
     uint16_t* planar = reinterpret_cast<uint16_t*>(sb_sm + SB_W1 + SB_W2 + SB_B2);      // [3 planes][38 rows][80 px]
@@ -53,8 +52,6 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
 
     // ---- resident weights ----
     {
-        const uint16_t* wr = a1.w + (int64_t)px * a1.k_pad + 8 * hi;       // stem: fragment s = rows 0..31, k = 16 s + 8 hi .. +7
-        for (int s = wave; s < 9; s += 8) w1l[s * 64 + lane] = *reinterpret_cast<const frag*>(wr + 16 * s);
         for (int f = wave; f < 36; f += 8) {                                 // body.1: fragment (ts, i) = rows i*32 + px, k = ts*16 + 8 hi .. +7
             const int i = f & 1, ts = f >> 1;
             w2l[f * 64 + lane] = *reinterpret_cast<const frag*>(a2.w + (int64_t)(i * 32 + px) * a2.k_pad + ts * 16 + hi * 8);
@@ -66,6 +63,13 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
     }
     f32x4 bias1[1][4];
     load_bias<1>(a1, 0, hi, bias1);
+    // stem weights: the 9 k16 fragments of this lane's cout row stay in REGISTERS for the whole kernel (36 VGPRs; one 8-wave block per CU leaves 256 per lane)
+    frag wf1[9];
+    {
+        const uint16_t* wr = a1.w + (int64_t)px * a1.k_pad + 8 * hi;       // fragment s = rows 0..31, k = 16 s + 8 hi .. +7
+#pragma unroll
+        for (int s = 0; s < 9; ++s) wf1[s] = *reinterpret_cast<const frag*>(wr + 16 * s);
+    }
 
     // ---- planar patch DMA geometry (fixed per lane): entry e = (plane, row, segment of 8 pixels) ----
     int e_plane[3], e_row[3], e_col[3];
@@ -134,6 +138,9 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
 
     int idx = blockIdx.x;
     if (idx < ntiles) issue_planar(idx);
+    // (A counted wait -- vmcnt(2): only the previous tile's two output stores may stay outstanding -- measured equal to waiting for everything:
+    //  profiles/r03g_fused_stem_wait_ab.txt.  What bounds the tile is the vector ALU: 32 quarter-rate transcendentals (v_exp_f32 + v_rcp_f32 of the
+    //  SiLUs) and ~95 other VALU instructions per 32-pixel stem group against 9 MFMAs.)
     for (; idx < ntiles; idx += gridDim.x) {
         int img, oy0, ox0;
         tile_origin(idx, img, oy0, ox0);
@@ -146,15 +153,23 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
             if (wave + 8 * j < SB_GROUPS) {   // wave-uniform
                 f32x16 acc[1][1];
                 init_acc<1, 1>(acc, bias1);
+                // all 27 planar reads of the group first, then the 9 MFMAs: left to itself the compiler reads, waits and multiplies step by step
+                // (one LDS round trip per MFMA, two waves per SIMD to hide it -- measured 5.4 us per tile)
+                uint32_t rr[9], gg[9], bb[9];
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     // tap = 2s + hi -> (ky, kx') = (tap / 3, tap % 3): compile-time per half
                     const int tap0 = 2 * s, tap1 = 2 * s + 1;
                     const int o0 = (tap0 / 3) * SB_IC + 2 * (tap0 % 3), o1 = (tap1 / 3) * SB_IC + 2 * (tap1 % 3);
                     const uint16_t* p0 = planar + s1_off[j] + (hi ? o1 : o0);
-                    const uint32_t r = *reinterpret_cast<const uint32_t*>(p0);
-                    const uint32_t g = *reinterpret_cast<const uint32_t*>(p0 + PLANE_HALFS);
-                    const uint32_t b = *reinterpret_cast<const uint32_t*>(p0 + 2 * PLANE_HALFS);
+                    rr[s] = *reinterpret_cast<const uint32_t*>(p0);
+                    gg[s] = *reinterpret_cast<const uint32_t*>(p0 + PLANE_HALFS);
+                    bb[s] = *reinterpret_cast<const uint32_t*>(p0 + 2 * PLANE_HALFS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    const uint32_t r = rr[s], g = gg[s], b = bb[s];
                     u32x4 q;
                     q[0] = (r & 0xffffu) | (g << 16);        // R0 G0
                     q[1] = b & 0xffffu;                      // B0 0
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
                     q[3] = b >> 16;                          // B1 0
                     frag af;
                     __builtin_memcpy(&af, &q, 16);
-                    acc[0][0] = Mfma<DT>::run(w1l[s * 64 + lane], af, acc[0][0]);
+                    acc[0][0] = Mfma<DT>::run(wf1[s], af, acc[0][0]);
                 }
                 const u32x2 norv[4] = {};
                 u32x4 o[2];
@@ -192,9 +207,17 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
             for (int e = 0; e < 4; ++e) acc2[0][0][g * 4 + e] = b[e];
         }
 #pragma unroll
-        for (int ts = 0; ts < 18; ++ts) {   // (tap, k16 half)
-            const frag fa = *reinterpret_cast<const frag*>(patch + ((ts & 1) ? (ea[ts >> 1] ^ 32) : ea[ts >> 1]));
-            acc2[0][0] = Mfma<DT>::run(w2l[(ts * 2 + ct) * 64 + lane], fa, acc2[0][0]);
+        for (int half = 0; half < 2; ++half) {   // 18 (tap, k16 half) steps in two batches of nine: the 18 LDS reads of a batch first, then its MFMAs
+            frag fa[9], fw[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const int ts = half * 9 + u;
+                fa[u] = *reinterpret_cast<const frag*>(patch + ((ts & 1) ? (ea[ts >> 1] ^ 32) : ea[ts >> 1]));
+                fw[u] = w2l[(ts * 2 + ct) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) acc2[0][0] = Mfma<DT>::run(fw[u], fa[u], acc2[0][0]);
         }
         finish_wave_tile<DT, DT, 1, 1>(a2, acc2, ct * 32, hi, [&](int, int64_t& m, bool& ok) {
             const int oy = oy0 + pr_o, ox = ox0 + pc_o;
