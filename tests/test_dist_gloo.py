@@ -51,6 +51,21 @@ def _worker(rank, world, port, q):
         ok = ok and second and len(calls) == 1 and torch.equal(b, boxes) and torch.equal(s, scores) and torch.equal(l, labels) and torch.equal(c, count)
         (b, s, l, c), second = yd.resolve_stale((b, s, l, c), final)   # nothing stale: no collective, no call
         ok = ok and not second and len(calls) == 1
+        # unequal shards (N not divisible by G): padded to ceil(N / G) rows for the one fixed-shape collective, padding dropped afterwards
+        n5 = 5
+        lo5, hi5 = yd.shard_range(n5, rank, world)
+        b, s, l, c = yd.all_gather_slab(boxes[lo5:hi5], scores[lo5:hi5], labels[lo5:hi5], count[lo5:hi5], global_n=n5)
+        ok = ok and torch.equal(b, boxes[:n5]) and torch.equal(s, scores[:n5]) and torch.equal(l, labels[:n5]) and torch.equal(c, count[:n5])
+        # every rank scores the GLOBAL batch from the gathered slab (the reference pickles per-rank results through two all_gathers,
+        # data/coco_eval.py:225-226 -> data/distributed.py:6-49): identical numbers on both ranks, equal to a single-process evaluation
+        from yolort_amd.utils.metrics import DetectionEvaluator
+        gt = [{"boxes": boxes[i, : count[i]] + (0.5 if i % 2 else 0.0), "labels": labels[i, : count[i]]} for i in range(n)]
+        ev = DetectionEvaluator(80)
+        ev.update_from_slab(yd.all_gather_slab(boxes[lo:hi], scores[lo:hi], labels[lo:hi], count[lo:hi]), gt)
+        single = DetectionEvaluator(80)
+        single.update([{"boxes": boxes[i, : count[i]], "scores": scores[i, : count[i]], "labels": labels[i, : count[i]]} for i in range(n)], gt)
+        res = ev.compute()
+        ok = ok and res == single.compute() and res["AP"] > 0
         q.put((rank, bool(ok), (lo, hi)))
     finally:
         dist.destroy_process_group()

@@ -75,15 +75,29 @@ def unpack_slab(buf: Tensor, k: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     return (buf[:, : 4 * k].reshape(n, k, 4), buf[:, 4 * k: 5 * k], buf[:, 5 * k: 6 * k].to(torch.int64), buf[:, 6 * k].to(torch.int32))
 
 
-def all_gather_slab(boxes: Tensor, scores: Tensor, labels: Tensor, count: Tensor, group=None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """One collective per batch; every rank ends up with the detections of the global batch in rank
-    order.  Requires equal shard sizes (weak scaling / N divisible by G)."""
+def all_gather_slab(boxes: Tensor, scores: Tensor, labels: Tensor, count: Tensor, group=None, global_n: Optional[int] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """One collective per batch; every rank ends up with the detections of the global batch in rank order.
+    Equal shard sizes (weak scaling / N divisible by G) need nothing else.  For a `shard_range` split of `global_n` images that leaves a
+    remainder, pass `global_n`: every rank pads its slab to ceil(N / G) rows (no extra exchange: all ranks know N and G), the collective
+    stays a single fixed-shape all-gather, and the padding rows are dropped afterwards."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return boxes, scores, labels, count
     world = dist.get_world_size(group)
     local = pack_slab(boxes, scores, labels, count)
-    out = torch.empty(world * local.shape[0], local.shape[1], device=local.device, dtype=local.dtype)
+    rows = local.shape[0]
+    if global_n is not None:
+        rank = dist.get_rank(group)
+        lo, hi = shard_range(global_n, rank, world)
+        if hi - lo != rows:
+            raise ValueError(f"rank {rank} holds {rows} images, shard_range({global_n}, {rank}, {world}) says {hi - lo}")
+        rows = -(-global_n // world)
+        if rows != local.shape[0]:
+            local = torch.cat([local, local.new_zeros(rows - local.shape[0], local.shape[1])])
+    out = torch.empty(world * rows, local.shape[1], device=local.device, dtype=local.dtype)
     dist.all_gather_into_tensor(out, local, group=group)
+    if global_n is not None and rows * world != global_n:
+        keep = torch.cat([torch.arange(r * rows, r * rows + (shard_range(global_n, r, world)[1] - shard_range(global_n, r, world)[0])) for r in range(world)]).to(out.device)
+        out = out.index_select(0, keep)
     return unpack_slab(out, scores.shape[1])
 
 

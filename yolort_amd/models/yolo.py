@@ -90,6 +90,12 @@ class PendingDetections:
         self.result()
         if self._gathered is None:
             raise YmiError("no global slab for this batch: enable YOLO.enable_distributed_gather() before submitting it")
+        seq = getattr(self, "gather_seq", None)
+        if seq is not None and isinstance(self._gathered, Tensor):
+            done = getattr(self.owner, "_gather_collected", 0)
+            if seq != done + 1:   # a skipped batch would leave the ranks in different collectives (a hang, not an error): fail loudly here instead
+                raise YmiError(f"gathered() must be called for every batch in submission order on every rank: batch {seq} asked for, batch {done + 1} is next")
+            self.owner._gather_collected = seq
         if isinstance(self._gathered, Tensor):
             k = self.entry.post.k
             first = ydist.unpack_slab(self._gathered, k)
@@ -208,7 +214,25 @@ class YOLO(nn.Module):
         cdt = compute_dtype_of(self)
         pp = self.post_process
         post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
-        key = (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode, self.post_exact_full)
+
+        def current_key():
+            return (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode, self.post_exact_full)
+
+        # Collecting an instance's outstanding batch can trigger a redo that GROWS cand_cap_per_image / sets post_exact_full -- both part of the
+        # key -- and re-enters this function: a key computed before the collection would hand back a plan of the capacity that has
+        # just overflowed.  So: when every instance of the current key is busy and the ring is full, collect the oldest FIRST, then (re)compute
+        # the key and pick the instance.
+        ring = self._ring.get(current_key())
+        if ring is not None and len(ring) >= max(1, self.pipeline_depth) and not any(c.outstanding is None and (c.done is None or c.done.query()) for c in ring):
+            oldest = ring[0]
+            if oldest.outstanding is not None:
+                oldest.outstanding.result()   # host-synchronises on that batch and detaches its results from the instance's buffers (may redo, may change the key)
+        key = current_key()
+        for stale in [k for k in self._ring if k[:7] == key[:7] and k != key]:   # rings of this shape built for a superseded capacity / exactness setting
+            for en in self._ring.pop(stale, []):
+                if en.outstanding is not None:
+                    en.outstanding.result()
+        key = current_key()
         ring = self._ring.get(key)
         if ring is None:
             if not hasattr(self.backbone, "emit"):
@@ -225,11 +249,11 @@ class YOLO(nn.Module):
             self._evict(key)
             e = self._build_entry(n, h, w, device, cdt, pp)
             ring.append(e)
-        if e is None:       # all busy: recycle the oldest
+        if e is None:       # all busy (their batches are collected but the GPU work of a later use has not drained): recycle the oldest
             e = ring.pop(0)
             ring.append(e)
             if e.outstanding is not None:
-                e.outstanding.result()   # host-synchronises on that batch and detaches its results from e's buffers
+                e.outstanding.result()
         self._entries = {key: e}
         return e
 
@@ -325,6 +349,8 @@ class YOLO(nn.Module):
             main.wait_event(e.done)
         pd = PendingDetections(self, e, rescale_rows, planar=planar)
         pd.gather_issued = gather
+        if gather:   # gathered() may hold a collective (second round): it has to be taken batch by batch, in submission order, on every rank
+            pd.gather_seq = self._gather_submitted = getattr(self, "_gather_submitted", 0) + 1
         e.outstanding = pd
         return pd
 

@@ -7,6 +7,8 @@ instead of conv2d -> BatchNorm2d -> SiLU -> cat.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -82,7 +84,21 @@ class Bottleneck(HipModule):
     def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck", t: Optional[View] = None, chain=None) -> View:
         """`t`: cv1's output when the producer of x already computed it (chained 1x1, see C3.emit);
         `chain`: a conv chained to cv2's output (C3.cv3 over the concat), passed through to Plan.conv"""
-        y = t if t is not None else self.cv1.emit(plan, x, name=name + ".cv1")
+        if t is not None:
+            y = t
+        else:
+            c_ = self.cv1.conv.out_channels
+            # a hidden width that is not a multiple of 32 (yolov5m: 48 at 320 x 320) would send the 3x3 through the im2col-TABLE form of the
+            # implicit GEMM (k32 operand chunks straddle taps: 0.13 of its bound, profiles/r02z_layer_table_c3.csv).  Instead cv1 writes its
+            # c_ channels into a zero-initialised buffer of round_up(c_, 32) channels and the 3x3 reads all of them against weights whose
+            # extra K rows are zero: the unit-tap kernels (LDS halo, resident weights) apply, for a third more bytes on this one tensor.
+            cp = (c_ + 31) // 32 * 32
+            if cp != c_ and c_ > 32 and not plan.fp32 and os.environ.get("YOLORT_AMD_PAD_HIDDEN", "1") != "0" and self.cv2.conv.groups == 1:
+                tb = plan.alloc(x.n, x.h, x.w, cp, zero=True)
+                self.cv1.emit(plan, x, out=tb.slice_c(0, c_), name=name + ".cv1")
+                y = tb
+            else:
+                y = self.cv1.emit(plan, x, name=name + ".cv1")
         return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + (".cv2+cv3" if chain is not None else ".cv2"), chain=chain)
 
 
