@@ -215,8 +215,10 @@ class YOLO(nn.Module):
         pp = self.post_process
         post_key = (pp.score_thresh, pp.nms_thresh, pp.detections_per_img) if self.fused() else None
 
+        base = (n, h, w, cdt, device.index, weights_signature(self), post_key)   # (walks every parameter: once per submission, the host side of a step is ~0.3 ms)
+
         def current_key():
-            return (n, h, w, cdt, device.index, weights_signature(self), post_key, self.cand_cap_per_image, self.fuse_head_decode, self.post_exact_full)
+            return base + (self.cand_cap_per_image, self.fuse_head_decode, self.post_exact_full)
 
         # Collecting an instance's outstanding batch can trigger a redo that GROWS cand_cap_per_image / sets post_exact_full -- both part of the
         # key -- and re-enters this function: a key computed before the collection would hand back a plan of the capacity that has
@@ -228,11 +230,12 @@ class YOLO(nn.Module):
             if oldest.outstanding is not None:
                 oldest.outstanding.result()   # host-synchronises on that batch and detaches its results from the instance's buffers (may redo, may change the key)
         key = current_key()
-        for stale in [k for k in self._ring if k[:7] == key[:7] and k != key]:   # rings of this shape built for a superseded capacity / exactness setting
-            for en in self._ring.pop(stale, []):
-                if en.outstanding is not None:
-                    en.outstanding.result()
-        key = current_key()
+        if len(self._ring) > 1:
+            for stale in [k for k in self._ring if k[:7] == base and k != key]:   # rings of this shape built for a superseded capacity / exactness setting
+                for en in self._ring.pop(stale, []):
+                    if en.outstanding is not None:
+                        en.outstanding.result()
+            key = current_key()
         ring = self._ring.get(key)
         if ring is None:
             if not hasattr(self.backbone, "emit"):
