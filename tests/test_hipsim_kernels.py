@@ -435,6 +435,15 @@ def test_spp_pool_and_upsample_exact(sim, spp_g, monkeypatch):
     got = buf.view().float().permute(0, 3, 1, 2)
     for i, k in enumerate((5, 9, 13)):
         assert torch.equal(got[:, 64 * (i + 1): 64 * (i + 2)], F.max_pool2d(x.float(), k, 1, k // 2)), f"maxpool{k} not exact"
+    if spp_g == "default":   # a 40x40 map (yolov5m / l at 1280x1280): four channel groups do not fit twice in LDS -> two groups (32-byte runs) per block
+        x4 = torch.randn(1, 32, 40, 40, generator=torch.Generator().manual_seed(8)).half()
+        b4 = Buf(1, 40, 40, 128, torch.float16)
+        b4.view()[..., :32] = x4.permute(0, 2, 3, 1)
+        _check(sim, sim.ymi_spp_pool(b4.ptr, 1, 40, 40, 32, 128, YMI_F16, None))
+        assert 100 * 1024 <= sim.sim_max_lds() <= 160 * 1024
+        g4 = b4.view().float().permute(0, 3, 1, 2)
+        for i, k in enumerate((5, 9, 13)):
+            assert torch.equal(g4[:, 32 * (i + 1): 32 * (i + 2)], F.max_pool2d(x4.float(), k, 1, k // 2)), f"40x40 maxpool{k} not exact"
     up = Buf(2, 40, 34, 96, torch.float16)
     _check(sim, sim.ymi_upsample2x(buf.ptr, 256, 2, 20, 17, 64, up.slice_c(32, 64).ptr, 96, YMI_F16, None))
     gu = up.view().float().permute(0, 3, 1, 2)

@@ -250,6 +250,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
 // patch shape for a ho x wo map: th * tw <= 256, (th+2) * (tw+2) <= 24 * 16 patch pixels; maximise the fraction of the 256
 // lanes that carry real output pixels (tile overhang counts as waste), then prefer the smaller halo
 static void choose_patch(int ho, int wo, int& th_best, int& tw_best) {
+    if (const char* e = getenv("YOLORT_AMD_H8_PATCH")) {   // tuning aid: "th,tw"
+        int th = 0, tw = 0;
+        if (sscanf(e, "%d,%d", &th, &tw) == 2 && th >= 1 && tw >= 4 && th * tw <= 256 && (th + 2) * (tw + 2) <= 24 * 16) { th_best = th; tw_best = tw; return; }
+    }
     double best = -1.0;
     th_best = 16; tw_best = 16;
     for (int tw = 4; tw <= 64 && tw <= ((wo + 3) / 4) * 4; ++tw) {

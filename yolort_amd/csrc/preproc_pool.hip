@@ -734,9 +734,8 @@ template <int DT, int G>   // G = 16-byte groups (8 channels) per pixel handled 
 __global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h, int w, int c, int cs) {
     extern __shared__ __attribute__((aligned(16))) u32x4 spp_sm[];
     const int hw = h * w;
-    u32x4* A = spp_sm;                 // [hw][G]
-    u32x4* B = spp_sm + (size_t)hw * G;
-    u32x4* Cb = spp_sm + (size_t)hw * G * 2;
+    u32x4* A = spp_sm;                 // [hw][G]: the current stage's plane (x, then mp5, mp9 -- the column pass overwrites it in place: the row pass was its last reader)
+    u32x4* B = spp_sm + (size_t)hw * G;   // row-pass scratch
     const int cg = c / (8 * G);
     const int img = blockIdx.x / cg, cc = (blockIdx.x % cg) * 8 * G;
     uint16_t* base = buf + (int64_t)img * hw * cs + cc;
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h,
     for (int p = p0; p < hw; p += PSTEP) A[p * G + sub] = *reinterpret_cast<const u32x4*>(base + (int64_t)p * cs + sub * 8);
     __syncthreads();
     u32x4* src = A;
-    u32x4* dst = Cb;
+    u32x4* dst = A;
     for (int stage = 0; stage < 3; ++stage) {
         for (int p = p0; p < hw; p += PSTEP) {   // row pass: src -> B
             const int y = p / w, x = p - y * w;
@@ -765,9 +764,6 @@ __global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h,
             dst[p * G + sub] = m;
         }
         __syncthreads();
-        u32x4* t = src;  // ping-pong A <-> Cb (B is the row-pass scratch)
-        src = dst;
-        dst = t;
     }
 }
 
@@ -887,12 +883,14 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
         return check_launch("spp_pool_f32_kernel");
     }
     YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16, "ymi_spp_pool: dtype must be F16/BF16/F32");
-    // LDS cascade form: the plane of 8*G channels three times in LDS; G = 4 (64-byte runs per pixel) when it fits, else G = 1
-    // (yolov5m/l at 1280x1280: 40x40 maps -- round 1 fell back to the 169-tap direct kernel there: 1.75 ms per step at C3)
-    int G = (c % 32 == 0) ? 4 : 1;
-    if ((size_t)h * w * G * 16 * 3 > 160 * 1024 - 512) G = 1;
-    if (const char* ge = getenv("YOLORT_AMD_SPP_G")) { const int g = atoi(ge); if (g == 1 || (g == 4 && G == 4)) G = g; }   // tuning aid
-    const size_t lds = (size_t)h * w * G * 16 * 3;
+    // LDS cascade form: the plane of 8*G channels TWICE in LDS (the stage's plane, overwritten in place by its column pass, and the row-pass scratch;
+    // three copies until round 3); G = 4 (64-byte runs per pixel) when it fits, else 2 (yolov5m/l at 1280x1280: 40x40 maps, 32-byte runs), else 1
+    // (round 1 fell back to the 169-tap direct kernel there: 1.75 ms per step at C3; round 2: G = 1, 324 us)
+    int G = (c % 32 == 0) ? 4 : ((c % 16 == 0) ? 2 : 1);
+    if (G == 4 && (size_t)h * w * G * 16 * 2 > 160 * 1024 - 512) G = 2;
+    if (G == 2 && (size_t)h * w * G * 16 * 2 > 160 * 1024 - 512) G = 1;
+    if (const char* ge = getenv("YOLORT_AMD_SPP_G")) { const int g = atoi(ge); if (g == 1 || (g == 2 && G >= 2) || (g == 4 && G == 4)) G = g; }   // tuning aid
+    const size_t lds = (size_t)h * w * G * 16 * 2;
     if (lds <= 160 * 1024 - 512) {
         dim3 g((unsigned)(n * (c / (8 * G)))), b(256);
         auto launch = [&](auto kfn) -> int {
@@ -900,8 +898,8 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
             hipLaunchKernelGGL(kfn, g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
             return check_launch("spp_pool_lds_kernel");
         };
-        if (dtype == YMI_F16) return G == 4 ? launch(spp_pool_lds_kernel<YMI_F16, 4>) : launch(spp_pool_lds_kernel<YMI_F16, 1>);
-        return G == 4 ? launch(spp_pool_lds_kernel<YMI_BF16, 4>) : launch(spp_pool_lds_kernel<YMI_BF16, 1>);
+        if (dtype == YMI_F16) return G == 4 ? launch(spp_pool_lds_kernel<YMI_F16, 4>) : (G == 2 ? launch(spp_pool_lds_kernel<YMI_F16, 2>) : launch(spp_pool_lds_kernel<YMI_F16, 1>));
+        return G == 4 ? launch(spp_pool_lds_kernel<YMI_BF16, 4>) : (G == 2 ? launch(spp_pool_lds_kernel<YMI_BF16, 2>) : launch(spp_pool_lds_kernel<YMI_BF16, 1>));
     }
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (dtype == YMI_F16) hipLaunchKernelGGL((spp_pool_kernel<YMI_F16>), grid, block, 0, (hipStream_t)stream, (uint16_t*)buf, n, h, w, c, cstride);
