@@ -114,7 +114,9 @@ def test_conditioned_workload_16bit_path_meets_the_stated_tolerance(dev, tag, dt
     m = _model(meta, dev, dtype, "cond")
     imgs = cond_images(meta["arch"], meta["seed"])
     got = [_np(d) for d in m.predict([im.to(dev).to(dtype) for im in imgs])]
-    _assert_16bit(ref, got, meta["thr"], TOL[("cond", tag)], f"cond_{tag}")
+    # (bf16, yolov5m: the score tolerance is 6e-2 and the workload's scores lie in 0.25 ... 0.31 -- almost every detection is "within the tolerance of the
+    # threshold" and may appear on one side only; what is asserted there is that nothing ELSE is unpaired and that the pairs meet the tolerance)
+    _assert_16bit(ref, got, meta["thr"], TOL[("cond", tag)], f"cond_{tag}", cut_share=1 if dtype == torch.bfloat16 else 3)
 
 
 @pytest.mark.parametrize("tag", ["s"])
