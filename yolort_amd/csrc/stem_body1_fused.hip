@@ -27,6 +27,10 @@ constexpr int SB_IR = 2 * SB_PH + 4, SB_IC = 80;         // planar patch: 38 row
 constexpr int SB_ENTRIES = 3 * SB_IR * (SB_IC / 8);      // 1140 16-byte row segments
 constexpr int SB_PIECES = (SB_ENTRIES + 63) / 64;        // 18 DMA pieces of 1 KiB
 constexpr int SB_MAX_IMGS = 32;
+#ifndef YMI_SB_PK
+#define YMI_SB_PK 0
+#endif
+constexpr bool SB_PK = YMI_SB_PK != 0;   // stage 1 SiLU with packed fp32 instructions (1) or scalar ones (0, default: 125 -> 122 us same-box, profiles/r03n)
 
 struct SbImgs {
     const uint16_t* img[SB_MAX_IMGS];
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
                 }
                 const u32x2 norv[4] = {};
                 u32x4 o[2];
-                silu_pack_subtile<DT, false>(acc[0][0], norv, o);   // the epilogue arithmetic of the separate launch: SiLU, rounding, lane swap
+                silu_pack_subtile<DT, false, true, SB_PK>(acc[0][0], norv, o);   // the epilogue arithmetic of the separate launch: SiLU, rounding, lane swap
                 // body.1 pads with zeros: stem pixels outside the stem's output are 0, not SiLU(bias)
                 const int sy = 2 * oy0 - 1 + (s1_rc[j] >> 16), sx = 2 * ox0 - 1 + (s1_rc[j] & 0xffff);
                 const bool in = s1_rc[j] >= 0 && ((unsigned)sy < (unsigned)a1.ho) && ((unsigned)sx < (unsigned)a1.wo);
