@@ -300,6 +300,16 @@ __device__ __forceinline__ void silu_pack_subtile(const f32x16& acc, const u32x2
     }
 }
 
+// 16-byte output store of the lean epilogues.  YMI_NT_STORES (build knob, A/B): nontemporal -- the packet streams towards memory instead of
+// sitting dirty in the XCD's L2 until the end-of-kernel write-back
+__device__ __forceinline__ void st16(void* p, const u32x4& v) {
+#ifdef YMI_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#else
+    *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+
 // per-lane byte offsets of one pixel group (tensors below 4 GiB: checked by the callers)
 struct LeanPix {
     unsigned mo, yo, y2o, ro;   // pixel index (0 when !ok) and its byte offsets in y / y2 / res (+ this lane half's 8- / 4-channel step)
@@ -342,14 +352,14 @@ __device__ __forceinline__ void lean_store(const ConvArgs& a, const LeanPix& p, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int co = cb + q * 16;   // a multiple of 16: the 16 channels of a packet pair are on one side of the split
-        if (a.split > 0 && co >= a.split) *reinterpret_cast<u32x4*>(y2b + (size_t)(co - a.split) * 2 + (size_t)p.y2o) = o[q];
-        else *reinterpret_cast<u32x4*>(yb + (size_t)co * 2 + (size_t)p.yo) = o[q];
+        if (a.split > 0 && co >= a.split) st16(y2b + (size_t)(co - a.split) * 2 + (size_t)p.y2o, o[q]);
+        else st16(yb + (size_t)co * 2 + (size_t)p.yo, o[q]);
         if (a.up2) {   // the same 8 channels to the 2x2 pixels of the upsampled view
             char* up = y2b + (size_t)co * 2 + (size_t)p.y2o;
-            *reinterpret_cast<u32x4*>(up) = o[q];
-            *reinterpret_cast<u32x4*>(up + up_px) = o[q];
-            *reinterpret_cast<u32x4*>(up + up_row) = o[q];
-            *reinterpret_cast<u32x4*>(up + up_row + up_px) = o[q];
+            st16(up, o[q]);
+            st16(up + up_px, o[q]);
+            st16(up + up_row, o[q]);
+            st16(up + up_row + up_px, o[q]);
         }
     }
 }
@@ -424,7 +434,7 @@ __device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, cons
             const int row = jj * RPI + row_l;
             const u32x4 v = *reinterpret_cast<const u32x4*>(tw + row * PITCH + chunk * 16);
             const int64_t mr = (int64_t)mbase + j * 32 + row;
-            if (mr < a.M) *reinterpret_cast<u32x4*>(yb + (size_t)mr * ycs + chunk * 16) = v;
+            if (mr < a.M) st16(yb + (size_t)mr * ycs + chunk * 16, v);
         }
         __builtin_amdgcn_wave_barrier();
     }
