@@ -477,8 +477,8 @@ def test_batched_nms_bit_exact_vs_oracle(sim, n, ncls, ties):
     np.testing.assert_array_equal(keep[: int(count[0])].astype(np.int64), ref)
 
 
-@pytest.mark.parametrize("thr,k", [(0.3, 300), (0.05, 50)])
-def test_postprocess_vs_oracle(sim, thr, k):
+@pytest.mark.parametrize("thr,k,saturated", [(0.3, 300, False), (0.05, 50, False), (0.3, 300, True)])
+def test_postprocess_vs_oracle(sim, thr, k, saturated):
     """ymi_postprocess on the simulator from the reference's own head-output layout: sigmoid / anchor decode, multi-label threshold, the
     per-image ranking sort, class-aware NMS, top-k and the in-kernel rescale (box_head.py:328-360, 414-427; transform.py:354-367) --
     counts, labels and order exact, scores / boxes to the rounding of expf"""
@@ -489,6 +489,12 @@ def test_postprocess_vs_oracle(sim, thr, k):
     kk = nc + 5
     shapes = [(10, 12), (5, 6), (3, 3)]
     heads = [torch.randn(n, 3, h, w, kk, generator=g) * 2.0 - 1.0 for h, w in shapes]
+    if saturated:
+        # thousands of (anchor, class) pairs with scores within 1/4096 of 1.0 -- many exactly equal -- in image 0: the score-prefix selection's boundary
+        # bin is FAT (round 3: refined by an exact radix selection on the full sort key instead of sending the image to the one-block sort)
+        ho = heads[0]
+        ho[0, :, :, :, 4] = 12.0 + torch.randn(ho[0, :, :, :, 4].shape, generator=g) * 0.3
+        ho[0, :, :, :, 5:35] = 11.0 + torch.randn(ho[0, :, :, :, 5:35].shape, generator=g).round() * 0.5   # rounded: exact score ties
     strides, anchors = O.anchors_for(3)
     ref = O.postprocess(O.decode(heads, strides, anchors), thr, 0.45, k)
     rescale = torch.tensor([[0.5, 8.0, 0.0], [1.25, 0.0, 4.0]], dtype=torch.float32)   # {gain, pad_x, pad_y} per image (scale_coords)
@@ -518,6 +524,8 @@ def test_postprocess_vs_oracle(sim, thr, k):
         _check(sim, sim.ymi_postprocess(C.byref(d), None))
         st = status.tolist()
         if st[1] == 0:
+            if saturated:
+                assert flags == 0 and st[0] <= 6144 + 4096, st   # the prefix path held: image 0 was cut to <= RANK_MAX records, no exact-full redo
             break
         if not st[1] & 1:
             flags = 1   # YMI_POST_EXACT_FULL

@@ -393,6 +393,21 @@ __device__ __forceinline__ int score_bin(uint64_t hi) {
     return b < 0 ? 0 : (b >= SEL_BINS ? SEL_BINS - 1 : b);
 }
 
+// histogram increment with the saturated case in mind: when every valid lane of the wave holds the SAME bin (thousands of records with equal or
+// near-equal scores: the case the refinement below exists for) one lane adds the wave's count -- 64 lanes hammering one LDS address serialise
+__device__ __forceinline__ void hist_add(int* hist, int bin, bool valid) {
+    const uint64_t mv = __ballot(valid);
+    if (mv == 0ull) return;
+    const int first = __builtin_ctzll(mv);
+    const int b0 = __builtin_amdgcn_readlane(bin, first);
+    const uint64_t same = __ballot(valid && bin == b0);
+    if (same == mv) {
+        if ((int)(threadIdx.x & 63) == first) atomicAdd(&hist[b0], __popcll(same));
+    } else if (valid) {
+        atomicAdd(&hist[bin], 1);
+    }
+}
+
 __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, int cap_img, int n_img, int sel_t,
                                                              int* sel_count, uint32_t* rank_g, uint32_t* rank_p) {
     __shared__ int hist[SEL_BINS];
@@ -412,7 +427,21 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
     uint32_t* lo = in_lo + (int64_t)img * cap_img;
     for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_i; i += blockDim.x) atomicAdd(&hist[score_bin(hi[i])], 1);
+    // One block streams a whole image (up to cap_img records: 2.6 MB at 218 k): four loads in flight per thread, or the pass is bound by one
+    // CU's load latency (a single 8-byte load per thread and iteration streamed ~60 GB/s)
+    for (int c0 = 0; c0 < n_i; c0 += 4 * blockDim.x) {   // (whole waves enter hist_add: its ballots need every lane)
+        uint64_t hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+            hv[u] = i < n_i ? hi[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool v = c0 + u * (int)blockDim.x + (int)threadIdx.x < n_i;
+            hist_add(hist, v ? score_bin(hv[u]) : 0, v);
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 64) {   // first wave: lane l owns bins [64 l, 64 l + 64)
         const int lane = threadIdx.x;
@@ -442,33 +471,121 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
         if (threadIdx.x == 0) { sel_count[img] = n_i; sel_count[n_img + img] = 0; }
         return;
     }
-    // in-place compaction: a chunk is read completely before any of its survivors is written, and survivors only move
-    // to positions at or before indices already read
-    const int lane = threadIdx.x & 63;
-    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int c0 = 0; c0 < n_i; c0 += blockDim.x) {
-        const int i = c0 + threadIdx.x;
-        uint64_t h = 0;
-        uint32_t l = 0;
-        bool take = false;
-        if (i < n_i) {
-            h = hi[i];
-            l = lo[i];
-            take = score_bin(h) <= bstar;
-        }
+    // Round 3: a FAT boundary bin (saturated scores: thousands of records within 1/4096 of each other, or exactly equal) used to push the
+    // image past RANK_MAX and onto the one-block-per-image sort (C3: 1.0 ms, C5: 0.33 ms of the post-process).  The cut is refined inside
+    // that bin by an exact radix selection on the records' full sort key g = ~score << 32 | lo (unique): 11 bits per level from the top, at
+    // each level the digit bins of the records that share the chosen prefix are counted, whole digit bins are kept in key order until the
+    // target is reached, and the level descends into the bin that crosses it -- until the selection fits RANK_MAX (any set "every record
+    // with key <= T" is a score-ordered prefix, so stopping early with a superset is exact).  Level 0 is the linear bin cut above, so
+    // images that never had a fat bin are selected exactly as before.
+    uint64_t sel_prefix = 0ull;   // records of bin bstar are taken iff (g >> sel_shift) <= sel_prefix
+    int sel_shift = 64;           // 64: the whole bin (no refinement)
+    if (nsel > RANK_MAX) {
+        constexpr int RB = 11, RBINS = 1 << RB;
+        __shared__ int s_digit, s_before;
+        const int lane0 = threadIdx.x & 63;
+        int before_bin = nsel - hist[bstar];          // records of the better bins (hist is intact: read-only since the scan)
+        int need = sel_t - before_bin;                // still wanted from the boundary bin (>= 1)
+        int have = before_bin;                        // taken for sure so far
+        uint64_t prefix = 0ull;
+        int shift = 64;
         __syncthreads();
-        const uint64_t m = __ballot(take);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_fill, __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (take) {
-            const int pos = base + __popcll(m & lt);
-            hi[pos] = h;
-            lo[pos] = l;
+        while (shift > 0) {
+            const int width = shift >= RB ? RB : shift;
+            const int nshift = shift - width;
+            for (int i = threadIdx.x; i < RBINS; i += blockDim.x) hist[i] = 0;   // (SEL_BINS >= RBINS; bin counts of level 0 are no longer needed)
+            __syncthreads();
+            for (int c0 = 0; c0 < n_i; c0 += 4 * blockDim.x) {
+                uint64_t hv[4];
+                uint32_t lv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // all eight loads of the thread first
+                    const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    hv[u] = i < n_i ? hi[i] : 0ull;
+                    lv[u] = i < n_i ? lo[i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bool v = c0 + u * (int)blockDim.x + (int)threadIdx.x < n_i && score_bin(hv[u]) == bstar;
+                    const uint64_t g = ((uint64_t)(uint32_t)hv[u] << 32) | lv[u];
+                    v = v && (shift >= 64 || (g >> shift) == prefix);
+                    hist_add(hist, (int)((g >> nshift) & (uint64_t)((1 << width) - 1)), v);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {   // first wave: lane l owns digits [32 l, 32 l + 32)
+                int sum = 0;
+                for (int b = 0; b < RBINS / 64; ++b) sum += hist[lane0 * (RBINS / 64) + b];
+                int incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(incl, d, 64);
+                    if (lane0 >= d) incl += t;
+                }
+                const int excl = incl - sum;
+                if (excl < need && incl >= need) {   // exactly one lane
+                    int c = excl, b = lane0 * (RBINS / 64);
+                    for (; b < lane0 * (RBINS / 64) + RBINS / 64; ++b) {
+                        if (c + hist[b] >= need) break;
+                        c += hist[b];
+                    }
+                    s_digit = b;
+                    s_before = c;
+                }
+            }
+            __syncthreads();
+            const int digit = s_digit, before = s_before, inbin = hist[digit];
+            prefix = (shift < 64 ? (prefix << width) : 0ull) | (uint64_t)digit;
+            shift = nshift;
+            if (have + before + inbin <= RANK_MAX || shift == 0) break;   // keep the whole crossing digit bin: the selection fits (or the key is exhausted: unique keys)
+            have += before;          // digit bins below the crossing one are taken whole
+            need -= before;
+            __syncthreads();
         }
+        sel_prefix = prefix;
+        sel_shift = shift;
+        __syncthreads();
+        if (threadIdx.x == 0) s_fill = 0;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { sel_count[img] = nsel; sel_count[n_img + img] = 1; }
+    // in-place compaction: a chunk is read completely before any of its survivors is written, and survivors only move to positions at or
+    // before indices already read.  Chunks of 8 records per thread (two block barriers per 8192 records: with one record per thread the
+    // barriers of this loop were most of the kernel -- 213 iterations for a 218 k-record image)
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    constexpr int CU_ = 8;
+    for (int c0 = 0; c0 < n_i; c0 += CU_ * blockDim.x) {
+        uint64_t h[CU_];
+        uint32_t l[CU_];
+        bool take[CU_];
+#pragma unroll
+        for (int u = 0; u < CU_; ++u) {
+            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+            h[u] = i < n_i ? hi[i] : 0ull;
+            l[u] = i < n_i ? lo[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < CU_; ++u) {
+            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+            const int b = score_bin(h[u]);
+            take[u] = i < n_i && (b < bstar || (b == bstar && (sel_shift >= 64 || ((((uint64_t)(uint32_t)h[u] << 32) | l[u]) >> sel_shift) <= sel_prefix)));
+        }
+        __syncthreads();   // the whole chunk has been read
+#pragma unroll
+        for (int u = 0; u < CU_; ++u) {
+            const uint64_t m = __ballot(take[u]);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_fill, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (take[u]) {
+                const int pos = base + __popcll(m & lt);
+                hi[pos] = h[u];
+                lo[pos] = l[u];
+            }
+        }
+        __syncthreads();   // its survivors are written (all at positions below c0 + 8192)
+    }
+    if (threadIdx.x == 0) { sel_count[img] = s_fill; sel_count[n_img + img] = 1; }   // s_fill == nsel when the cut was not refined
 }
 
 // ------------------------------------------------------------------------------------------
