@@ -185,7 +185,7 @@ def cond_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2, 3), verbose=True):
     out = {"arch": arch, "seed": seed, "S": S, "thr": thr, "dets": [len(r["scores"]) for r in ref], "fp64": c64, "oracle": cor, "min_score_gap": gap,
            "thr_margin": thr_margin, "tol": tol}
     if verbose:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     return out, ref
 
 
@@ -253,7 +253,7 @@ def photo_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2)):
     imgs = photo_images()
     with torch.no_grad():
         ref = _np_dets(_reference_model(arch, S, thr, sd).predict(paths))
-        one = _np_dets(_reference_model(arch, S, thr, sd).predict(paths[0]))     # a single path: another canvas (the batch maximum differs)
+        one = [_np_dets(_reference_model(arch, S, thr, sd).predict(pth))[0] for pth in paths]     # single paths: other canvases (the batch maximum differs)
         ref64 = _np_dets(_reference_model(arch, S, thr, sd, torch.float64).predict([im.double() for im in imgs]))
         ora = _np_dets(O.yolov5_forward(imgs, sd, size=(S, S), size_divisible=div, score_thresh=thr))
     for r in ref64:
@@ -272,7 +272,7 @@ def photo_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2)):
         tol[name] = _tolerance_of(ref, [_emulated(imgs, sd, S, div, thr, dt, j) for j in jitters], thr)
     ev = {"arch": arch, "seed": seed, "S": S, "thr": thr, "dets": [len(r["scores"]) for r in ref], "dets_single": [len(r["scores"]) for r in one], "fp64": c64,
           "oracle": cor, "min_score_gap": gap, "thr_margin": thr_margin, "tol": tol}
-    print(json.dumps(ev))
+    print(json.dumps(ev), flush=True)
     return ev, ref, one
 
 
@@ -285,14 +285,15 @@ def photo_golden(arch, seeds=range(0, 30)):
         ev, ref, one = photo_evaluate(arch, seed)
         n = len(ev["dets"])
         ok = (all(ev[k]["unexplained"] == 0 and ev[k]["at_cut"] == 0 and ev[k]["images_labels_equal"] == n for k in ("fp64", "oracle"))
-              and min(ev["dets"]) >= 2 and max(ev["dets"]) <= 100 and ev["min_score_gap"] >= 1e-4 and ev["thr_margin"] >= 5e-5)
+              and min(ev["dets"]) >= 2 and max(ev["dets"]) <= 100 and max(ev["dets_single"]) >= 2 and ev["min_score_gap"] >= 1e-4 and ev["thr_margin"] >= 5e-5)
         if ok:
             out = {"meta": json.dumps(ev)}
             for i, r in enumerate(ref):
                 for k in ("boxes", "scores", "labels"):
                     out[f"det{i}_{k}"] = r[k]
-            for k in ("boxes", "scores", "labels"):
-                out[f"single_{k}"] = one[0][k]
+            for j, o in enumerate(one):   # `predict(path)` of each photo alone
+                for k in ("boxes", "scores", "labels"):
+                    out[f"single{j}_{k}"] = o[k]
             np.savez_compressed(os.path.join(HERE, f"photo_{tag}.npz"), **out)
             print("photo golden", tag, "seed", seed, "dets", ev["dets"], "single", ev["dets_single"], "tolerances", ev["tol"])
             return seed
