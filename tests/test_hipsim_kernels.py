@@ -293,6 +293,45 @@ def test_halo8_3x3_kernel_logic(sim, tile, cout):
     _run_conv(sim, torch.bfloat16, tile, 1, 32, cout, 20, 20, 3, 1, seed=tile + 1)
 
 
+@pytest.mark.parametrize("tile,c_,residual", [(93, 64, True), (93, 64, False), (95, 128, True), (94, 32, True)])
+def test_halo8_with_a_chained_1x1_equals_the_two_launches(sim, tile, c_, residual):
+    """conv_halo8.hip, 8 x 1 wave forms, with the NEXT Bottleneck's 1x1 riding in the epilogue (round 3: m.j.cv2 + m.(j+1).cv1 as one launch,
+    reference common.py:115-116 twice): the 3x3's own output and the chained 1x1's output equal the two separate launches bit for bit"""
+    from yolort_amd import engine
+    dtype, cpu = torch.float16, torch.device("cpu")
+    g = torch.Generator().manual_seed(tile + c_)
+    n, h, w = 2, 11, 13
+    x = torch.randn(n, c_, h, w, generator=g).to(dtype).float()
+    w3 = (torch.randn(c_, c_, 3, 3, generator=g) / np.sqrt(9 * c_)).to(dtype).float()
+    b3 = torch.randn(c_, generator=g) * 0.1
+    w1 = (torch.randn(c_, c_, 1, 1, generator=g) / np.sqrt(c_)).to(dtype).float()
+    b1 = torch.randn(c_, generator=g) * 0.1
+    pc3, pc1 = engine.PackedConv(w3, b3, None, dtype, cpu), engine.PackedConv(w1, b1, None, dtype, cpu)
+    xb = Buf(n, h, w, c_, dtype, fill=x.permute(0, 2, 3, 1))
+    rb = None
+    if residual:
+        rb = Buf(n, h, w, c_, dtype, fill=torch.randn(n, h, w, c_, generator=g))
+    kt = pc3.ktab(w, c_)
+
+    def d3(y, chain=None):
+        d = _conv_desc(xb, pc3, y, tile, k=3, pad=1, res=rb, chain=chain)
+        d.ktab = kt.data_ptr()
+        return d
+
+    y_sep, t_sep = Buf(n, h, w, c_, dtype), Buf(n, h, w, c_, dtype)
+    _check(sim, sim.sim_conv2d(C.byref(d3(y_sep))))
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(y_sep, pc1, t_sep, 27 if c_ <= 64 else 21))))
+    y_ch, t_ch = Buf(n, h, w, c_, dtype), Buf(n, h, w, c_, dtype)
+    _check(sim, sim.sim_conv2d(C.byref(d3(y_ch, chain=(pc1, t_ch)))))
+    assert torch.equal(y_ch.view().view(torch.int16), y_sep.view().view(torch.int16))
+    assert torch.equal(t_ch.view().view(torch.int16), t_sep.view().view(torch.int16)), (t_ch.view().float() - t_sep.view().float()).abs().max().item()
+    ref = F.silu(F.conv2d(x, w3, b3, 1, 1))
+    if residual:
+        ref = ref + rb.view().float().permute(0, 3, 1, 2)
+    ref1 = F.silu(F.conv2d(ref.to(dtype).float(), w1, b1)).permute(0, 2, 3, 1)
+    assert (t_ch.view().float() - ref1).abs().max().item() <= 4e-3 * max(1.0, ref1.abs().max().item())
+
+
 @pytest.mark.parametrize("tile,cout", [(31, 128), (32, 64), (33, 32), (35, 64), (37, 128)])
 def test_halo4_3x3_kernel_logic(sim, tile, cout):
     """conv3x3_halo.hip (4-wave LDS-halo kernel)"""

@@ -240,6 +240,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
         ok = p < npix && oy < a.ho && ox < a.wo;
         m = ((int64_t)img * a.ho + oy) * a.wo + ox;
     };
+    if constexpr (ODT == DT && WAVES_M == 8 && TM == 1 && TN <= 4) {   // 8 x 1 waves: a wave owns ALL couts of its 32 pixels -- a chained 1x1 (the next
+        if (a.chain_w != nullptr) {                                     // Bottleneck's cv1, or C3.cv3) runs from the outputs in registers
+            finish_wave_tile_chain<DT, TN, TM>(a, acc, lane >> 5, lane, pix);
+            H8_STAMP(127);
+            return;
+        }
+    }
     finish_wave_tile<DT, ODT, TN, TM>(a, acc, n0 + wave_n, lane >> 5, pix);
     H8_STAMP(127);
 #ifdef YMI_STAMPS
@@ -314,9 +321,13 @@ static int halo8_variant(const ConvArgs& a, int variant, hipStream_t s) {
 }
 
 int conv_halo8_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s) {
-    YMI_REQUIRE(a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.cin % 32 == 0 && a.zeros != nullptr && a.split == 0 && a.up2 == 0 &&
-                    a.chain_w == nullptr,
+    YMI_REQUIRE(a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.cin % 32 == 0 && a.zeros != nullptr && a.split == 0 && a.up2 == 0,
                 "ymi_conv2d: the 8-wave LDS-halo kernel handles plain 3x3 stride-1 pad-1 convolutions with cin %% 32 == 0 (and needs desc.zeros)");
+    if (a.chain_w != nullptr) {   // chained 1x1: the 8 x 1 variants only, one cout block whose width is the chain's fresh K
+        const int bn = variant == 3 ? 64 : (variant == 4 ? 32 : (variant == 5 ? 128 : 0));
+        YMI_REQUIRE(bn != 0 && bn == a.chain_k && a.cout_pad == bn && out_dtype == dtype,
+                    "ymi_conv2d: this halo8 variant does not fit the chained convolution (cout width must equal %d)", a.chain_k);
+    }
     YMI_REQUIRE(a.k_pad == 9 * a.cin, "ymi_conv2d: halo8 kernel expects k_pad == 9*cin");
     if (dtype == YMI_F16) return out_dtype == YMI_F32 ? halo8_variant<YMI_F16, YMI_F32>(a, variant, s) : halo8_variant<YMI_F16, YMI_F16>(a, variant, s);
     return out_dtype == YMI_F32 ? halo8_variant<YMI_BF16, YMI_F32>(a, variant, s) : halo8_variant<YMI_BF16, YMI_BF16>(a, variant, s);

@@ -169,6 +169,10 @@ class Plan:
         # C3.cv3 chained into the last Bottleneck.cv2's launch (ymi_conv_desc.chain_x2): supported and tested, but measured
         # +-0 end to end (the pixel-major producer tiles it needs cost what the saved launch gains) -> off by default
         self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
+        # Bottleneck j's 3x3 carries Bottleneck j+1's 1x1 in its epilogue (8-wave halo kernel, 8 x 1 waves: the outputs a wave holds are the 1x1's
+        # activation fragments): one launch less per Bottleneck after the first
+        self.chain_next = os.environ.get("YOLORT_AMD_CHAIN_NEXT", "0")   # opt-in: C2 0 ... +2.5 % depending on the box, C5 -0.7 % (profiles/r03u, r03w); "0" off, "1" every hidden width the kernel takes (32 / 64 / 128), "128": only that width
+        self.chain_next = False if self.chain_next == "0" else (True if self.chain_next == "1" else int(self.chain_next))
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
         # a whole one-Bottleneck C3 of 32 hidden channels in ONE launch (csrc/c3_fused32.hip; yolov5s backbone.body.2).  Default since
         # round 3: bit-identical to the three launches it replaces (tests/test_c3_fused_gpu.py) and 91 vs 196 us on the 160x160 level of
@@ -189,6 +193,7 @@ class Plan:
         if self.fp32:
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
+            self.chain_next = False
 
     def __del__(self):
         try:
@@ -371,6 +376,9 @@ class Plan:
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
             if chain is None:   # 8-wave halo kernel (conv_halo8.hip): 256-pixel patches, <= 2 DMA pieces per wave per step
                 cands = cands + ([94] if d.cout_pad <= 32 else ([92, 93] if d.cout_pad <= 64 else [91, 92, 93, 95]))
+            else:               # ... its 8 x 1 forms take a chained 1x1 whose K is the whole cout width (round 3)
+                k1 = d.cout_split if d.cout_split > 0 else d.cout
+                cands = cands + ([94] if k1 == 32 == d.cout_pad else ([93] if k1 == 64 == d.cout_pad else ([95] if k1 == 128 == d.cout_pad else [])))
         if d.kh == 3 and d.kw == 3 and d.sh == d.sw and d.sh in (1, 2) and d.ph == 1 and d.pw == 1 and d.cin == 32 and d.cout in (32, 64) and d.k_pad == 288 and \
                 d.out_dtype == d.dtype and d.y2_mode != 2 and chain is None:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)

@@ -81,7 +81,7 @@ class Bottleneck(HipModule):
         self.cv2 = Conv(c_, c2, 3, 1, g=g, version=version)
         self.add = shortcut and c1 == c2
 
-    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck", t: Optional[View] = None, chain=None) -> View:
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "bottleneck", t: Optional[View] = None, chain=None, chain_name: Optional[str] = None) -> View:
         """`t`: cv1's output when the producer of x already computed it (chained 1x1, see C3.emit);
         `chain`: a conv chained to cv2's output (C3.cv3 over the concat), passed through to Plan.conv"""
         if t is not None:
@@ -99,7 +99,10 @@ class Bottleneck(HipModule):
                 y = tb
             else:
                 y = self.cv1.emit(plan, x, name=name + ".cv1")
-        return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + (".cv2+cv3" if chain is not None else ".cv2"), chain=chain)
+        tag = ".cv2"
+        if chain is not None:
+            tag = ".cv2+" + (chain_name or "cv3")
+        return self.cv2.emit(plan, y, out=out, res=x if self.add else None, name=name + tag, chain=chain)
 
 
 class C3(HipModule):
@@ -169,12 +172,25 @@ class C3(HipModule):
                 and isinstance(self.m[nb - 1], Bottleneck) and self.m[nb - 1].cv2.conv.kernel_size == (3, 3) and self.m[nb - 1].cv2.conv.out_channels == c_):
             o3 = out if out is not None else plan.alloc(x.n, x.h, x.w, c2)
             chain3 = (self.cv3.packed(plan.dtype, plan.device, 2 * c_), o3, cat.slice_c(c_, c_))
+        t_next = None
         for j, b in enumerate(self.m):
             kw = {}
             if j == 0 and t0 is not None:
                 kw["t"] = t0
+            elif t_next is not None:
+                kw["t"] = t_next
+            t_next = None
             if j == nb - 1 and chain3 is not None:
                 kw["chain"] = chain3
+            elif (j < nb - 1 and getattr(plan, "chain_next", False) and (plan.chain_next is True or plan.chain_next == c_) and not plan.use_v1 and c_ in (32, 64, 128) and isinstance(b, Bottleneck) and isinstance(self.m[j + 1], Bottleneck)
+                  and b.cv2.conv.kernel_size == (3, 3) and b.cv2.conv.stride == (1, 1) and b.cv2.conv.groups == 1 and b.cv2.conv.out_channels == c_
+                  and isinstance(b.cv2.act, nn.SiLU) and isinstance(self.m[j + 1].cv1.act, nn.SiLU) and self.m[j + 1].cv1.conv.kernel_size == (1, 1)
+                  and self.m[j + 1].cv1.conv.out_channels % 32 == 0 and self.m[j + 1].cv1.conv.out_channels <= 128):
+                # this Bottleneck's 3x3 carries the next one's 1x1 in its epilogue (reference :115-116 twice: x + cv2(cv1(x)), then cv1 of the next)
+                nxt = self.m[j + 1]
+                t_next = plan.alloc(x.n, x.h, x.w, nxt.cv1.conv.out_channels)
+                kw["chain"] = (nxt.cv1.packed(plan.dtype, plan.device, c_), t_next)
+                kw["chain_name"] = f"m.{j + 1}.cv1"
             y = b.emit(plan, y, out=cat.slice_c(0, c_) if j == nb - 1 else None, name=f"{name}.m.{j}", **kw)
         if not fuse:
             self.cv2.emit(plan, x, out=cat.slice_c(c_, c_), name=name + ".cv2")
