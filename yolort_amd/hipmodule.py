@@ -32,15 +32,27 @@ def weights_signature(module: nn.Module) -> Tuple:
     """changes when any parameter / buffer of the module tree is modified in place (`_version`), re-allocated or replaced (`data_ptr`): the plan
     cache's key.  Called once per submitted batch, so it must be cheap: `module.parameters()` + `module.buffers()` walk the tree through two
     recursive generators with name bookkeeping (0.4 ms per call on yolov5s -- most of the host's 0.76 ms per batch, tools/host_profile.py); here the
-    list of sub-MODULES is cached on first use (a recorded plan bakes the structure in anyway) and only their own `_parameters` / `_buffers`
-    dicts are read, so replaced Parameter objects are still seen."""
-    mods = module.__dict__.get("_ymi_modules")
-    if mods is None:
-        mods = [m for m in module.modules() if m._parameters or m._buffers]
-        module.__dict__["_ymi_modules"] = mods
+    list of sub-MODULES is cached on first use, validated by a fingerprint of every module's direct children (a replaced sub-module rebuilds it), and
+    only the modules' own `_parameters` / `_buffers` dicts are read, so replaced Parameter objects are still seen."""
+    cache = module.__dict__.get("_ymi_modules")
+    if cache is not None:   # the cached module list is valid while no sub-module has been added, removed or REPLACED (e.g. `model.head = other_head`)
+        fp = 0
+        for m in cache[1]:
+            for c in m._modules.values():
+                fp += id(c)
+        if fp != cache[0]:
+            cache = None
+    if cache is None:
+        allm = list(module.modules())
+        fp = 0
+        for m in allm:
+            for c in m._modules.values():
+                fp += id(c)
+        cache = (fp, [m for m in allm if m._modules], [m for m in allm if m._parameters or m._buffers])
+        module.__dict__["_ymi_modules"] = cache
     sig = 0
     ptr = 0
-    for m in mods:
+    for m in cache[2]:
         for t in m._parameters.values():
             if t is not None:
                 sig += t._version
