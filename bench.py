@@ -446,7 +446,7 @@ def main():
 
     if rank == 0:
         conv_meta = [m for m in e.plan.meta if m["kind"] == "conv"]
-        n_conv = len(conv_meta) - (1 if (args.shapes == "fixed" and e.plan.stem_body1_fusable()) else 0)   # stem + body.1 run as one launch on fixed-size streams
+        n_conv = len(conv_meta) - (1 if (e.plan.stem_body1_fusable() and (args.shapes == "fixed" or e.plan.fuse_stem)) else 0)   # stem + body.1 run as one launch
         bytes_step = sum(m["bytes"] for m in conv_meta)
         flops_step = sum(m["flops"] for m in conv_meta)
         bound_s = sum(max(m["flops"] / MFMA_PEAK, m["bytes"] / HBM_PEAK) for m in conv_meta)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 3
+#define YMI_ABI_VERSION 4
 
 /* error codes */
 #define YMI_OK 0
@@ -249,6 +249,10 @@ int ymi_conv_stem_planar(const ymi_conv_desc* d, const void* const* imgs, int n_
  * activation of the network, never reaches memory.  Output is bit-identical to ymi_conv_stem_planar + ymi_conv2d. */
 int ymi_stem_body1_planar(const ymi_conv_desc* stem, const ymi_conv_desc* body1, const void* const* imgs, int n_imgs, void* stream);
 
+/* The same pair fed from the letterboxed canvas (dynamic-shape streams: transform.py:53-97 resizes and pads first): `stem` exactly as
+ * for ymi_conv2d on the NHWC4 canvas (x = ymi_letterbox's output, x_cstride 8), `body1` as above.  Bit-identical to two ymi_conv2d calls. */
+int ymi_stem_body1(const ymi_conv_desc* stem, const ymi_conv_desc* body1, void* stream);
+
 /* Measurement aid (bench.py): one wave spins for `spin_us` microseconds of the constant 100 MHz clock and writes
  * {shader-clock cycles, 100 MHz ticks} to out[0..1] (device memory) -- the shader clock the chip runs at while whatever else
  * is in flight on other streams executes.  Asynchronous on `stream`. */
@@ -308,6 +312,9 @@ int ymi_plan_add_head_decode(ymi_plan* p, const ymi_conv_desc* conv, const ymi_p
 int ymi_plan_add_head_decode_group(ymi_plan* p, const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* d);
 int ymi_plan_add_post_finish(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_num_ops(const ymi_plan* p);
+/* on != 0: ops 0 and 1 (the stem over the letterboxed canvas and body.1 reading its output, see ymi_stem_body1) run as ONE launch whenever a
+ * run covers both; op indices are unchanged, the stem's output buffer is then not written.  Fails unless ops 0 and 1 are such a pair. */
+int ymi_plan_set_fuse_stem(ymi_plan* p, int on);
 /* runs ops [first, last) on stream (last < 0 = all); use_graph != 0 replays a captured hipGraph */
 int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream);
 /* per-op timing with HIP events on `stream`: ms_out[num_ops], averaged over iters */

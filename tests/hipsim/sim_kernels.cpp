@@ -61,6 +61,13 @@ extern "C" int sim_stem_body1_planar(const ymi_conv_desc* stem, const ymi_conv_d
     if (n_imgs != stem->n || n_imgs != body1->n) { ymi::set_error("sim_stem_body1_planar: %d images for batches of %d / %d", n_imgs, stem->n, body1->n); return YMI_EINVAL; }
     return ymi::stem_body1_planar_launch(a1, a2, imgs, stem->dtype, nullptr);
 }
+// the same from the letterboxed NHWC4 canvas (stem->x)
+extern "C" int sim_stem_body1(const ymi_conv_desc* stem, const ymi_conv_desc* body1) {
+    ymi::ConvArgs a1, a2;
+    sim_fill(stem, a1);
+    sim_fill(body1, a2);
+    return ymi::stem_body1_launch(a1, a2, stem->dtype, nullptr);
+}
 extern "C" const char* sim_last_error(void) { return ymi::g_err; }
 extern "C" int sim_max_lds(void) { return hipsim::g_max_lds; }
 extern "C" long sim_launches(void) { return hipsim::g_launches; }

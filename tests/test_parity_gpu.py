@@ -207,13 +207,26 @@ def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size
         print("   %.2e  %s  tile %s  %s" % w)
     n_ref_convs = sum(1 for k in known if ".head." not in k)
     assert checked >= n_ref_convs, f"only {checked} of the reference's {n_ref_convs} conv layers were exercised"
-    # the first layers as the benchmark runs them -- straight from the planar images, the stem alone (ymi_conv_stem_planar) or stem + body.1 as one
-    # launch (ymi_stem_body1_planar, when the plan offers it) -- equal ops 0 (and 1) on the letterboxed batch bit for bit
-    if not dynamic and plan.stem_planar_ok(imgs, (size, size)):
-        _fill(plan.io[0]["x"], torch.stack(imgs_cpu).to(dtype).float(), dtype)
+    # the first layers as the benchmark runs them equal ops 0 (and 1) on the letterboxed batch bit for bit:
+    #   fixed-size streams   straight from the planar images, the stem alone (ymi_conv_stem_planar) or stem + body.1 as one launch (ymi_stem_body1_planar)
+    #   dynamic-shape ones   stem + body.1 as one launch from the canvas (ymi_plan_set_fuse_stem), when the plan offers it
+    canvas_fused = plan.fuse_stem
+    plan.set_fuse_stem(False)
+    batch_q, _ = O.letterbox(imgs_cpu, size, size, kw.get("size_divisible", 32))
+    _fill(plan.io[0]["x"], batch_q.to(dtype).float(), dtype)
+    plan.run(0, 2)
+    torch.cuda.synchronize()
+    y0, y1 = plan.io[0]["y"].as_tensor().clone(), plan.io[1]["y"].as_tensor().clone()
+    if plan.set_fuse_stem(True):
+        plan.io[0]["y"].as_tensor().zero_()
+        plan.io[1]["y"].as_tensor().zero_()
         plan.run(0, 2)
         torch.cuda.synchronize()
-        y0, y1 = plan.io[0]["y"].as_tensor().clone(), plan.io[1]["y"].as_tensor().clone()
+        assert torch.equal(y1, plan.io[1]["y"].as_tensor()), "fused stem + body.1 (canvas) differs from the two launches"
+        assert float(plan.io[0]["y"].as_tensor().abs().max()) == 0.0     # the stem's output never reaches memory
+        print("fused stem + body.1 from the canvas: bit-identical to the two launches")
+    plan.set_fuse_stem(canvas_fused)
+    if not dynamic and plan.stem_planar_ok(imgs, (size, size)):
         os.environ["YOLORT_AMD_FUSE_STEM"] = "0"
         try:
             plan.io[0]["y"].as_tensor().zero_()

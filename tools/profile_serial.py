@@ -43,7 +43,7 @@ def main():
     e = next(iter(m.model._entries.values()))
     if a.ops:
         ops = [{"name": n, **meta} for n, meta in zip(e.plan.names, e.plan.meta)]
-        if c["shapes"] != "dynamic" and e.plan.stem_body1_fusable():   # ops 0 and 1 run as ONE launch (ymi_stem_body1_planar): one table row, both layers' algorithmic work
+        if e.plan.stem_body1_fusable() and (c["shapes"] != "dynamic" or e.plan.fuse_stem):   # ops 0 and 1 run as ONE launch (ymi_stem_body1_planar / ymi_plan_set_fuse_stem): one table row, both layers' algorithmic work
             o0, o1 = ops[0], ops[1]
             ops = [{**o0, "name": o0["name"] + "+" + o1["name"].split(".")[-1], "flops": o0["flops"] + o1["flops"], "bytes": o0["bytes"] + o1["bytes"],
                     "ref_convs": 2, "tile": -2, "shape": "stem 3->32 k6 s2 + 32->64 k3 s2 (one launch)"}] + ops[2:]

@@ -52,7 +52,7 @@ class C3Desc(C.Structure):
     ]
 
 
-ABI_VERSION = 3   # include/yolort_amd.h YMI_ABI_VERSION
+ABI_VERSION = 4   # include/yolort_amd.h YMI_ABI_VERSION
 POST_EXACT_FULL = 1
 
 
@@ -86,6 +86,7 @@ _SIGS = {
     "ymi_plan_add_c3_fused": (C.c_int, [C.c_void_p, C.POINTER(C3Desc)]),
     "ymi_conv_stem_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "ymi_stem_body1_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "ymi_stem_body1": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
     "ymi_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ymi_conv_build_ktab": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "ymi_spp_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -111,6 +112,7 @@ _SIGS = {
     "ymi_plan_add_head_decode_group": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_int, C.POINTER(PostDesc)]),
     "ymi_plan_add_post_finish": (C.c_int, [C.c_void_p, C.POINTER(PostDesc)]),
     "ymi_plan_num_ops": (C.c_int, [C.c_void_p]),
+    "ymi_plan_set_fuse_stem": (C.c_int, [C.c_void_p, C.c_int]),
     "ymi_plan_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ymi_plan_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }

@@ -53,6 +53,7 @@ bool head_anchor_split() {
 
 int conv2d_launch(const ymi_conv_desc* d, hipStream_t s);
 int c3_fused_launch(const ymi_c3_desc* d, hipStream_t s);
+int stem_body1_desc_launch(const ymi_conv_desc* stem, const ymi_conv_desc* body1, hipStream_t s);
 int postprocess_launch(const ymi_post_desc* d, hipStream_t s);
 int post_begin_launch(const ymi_post_desc* d, hipStream_t s);
 int post_finish_launch(const ymi_post_desc* d, hipStream_t s);
@@ -94,6 +95,7 @@ static int run_op(const Op& op, hipStream_t s) {
 
 struct ymi_plan {
     std::vector<ymi::Op> ops;
+    bool fuse_stem = false;   // ops 0 + 1 (stem, body.1) run as ONE launch whenever a run covers both (ymi_plan_set_fuse_stem)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int graph_first = -1, graph_last = -1;
@@ -266,6 +268,26 @@ extern "C" int ymi_plan_add_post_finish(ymi_plan* p, const ymi_post_desc* d) {
 
 extern "C" int ymi_plan_num_ops(const ymi_plan* p) { return p ? (int)p->ops.size() : 0; }
 
+extern "C" int ymi_plan_set_fuse_stem(ymi_plan* p, int on) {
+    YMI_REQUIRE(p != nullptr, "ymi_plan_set_fuse_stem: null plan");
+    if (on) {
+        YMI_REQUIRE(p->ops.size() >= 2 && p->ops[0].kind == OP_CONV && p->ops[1].kind == OP_CONV, "ymi_plan_set_fuse_stem: ops 0 and 1 must be convolutions");
+        YMI_REQUIRE(p->ops[1].conv.x == p->ops[0].conv.y && p->ops[1].conv.x_cstride == p->ops[0].conv.y_cstride, "ymi_plan_set_fuse_stem: op 1 must read op 0's output");
+    }
+    if (p->fuse_stem != (on != 0)) drop_graph(p);
+    p->fuse_stem = on != 0;
+    return YMI_OK;
+}
+
+// ops [first, last) in order; with fuse_stem, ops 0 + 1 together when the range holds both (i advances past op 1)
+static int run_range_op(const ymi_plan* p, int& i, int last, hipStream_t s) {
+    if (i == 0 && p->fuse_stem && last >= 2) {
+        i = 1;
+        return stem_body1_desc_launch(&p->ops[0].conv, &p->ops[1].conv, s);
+    }
+    return run_op(p->ops[i], s);
+}
+
 extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream) {
     YMI_REQUIRE(p != nullptr, "ymi_plan_run: null plan");
     hipStream_t s = (hipStream_t)stream;
@@ -274,7 +296,7 @@ extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, voi
     if (first < 0) first = 0;
     if (!use_graph) {
         for (int i = first; i < last; ++i) {
-            int rc = run_op(p->ops[i], s);
+            int rc = run_range_op(p, i, last, s);
             if (rc != YMI_OK) return rc;
         }
         return YMI_OK;
@@ -284,7 +306,7 @@ extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, voi
         YMI_REQUIRE(s != nullptr, "ymi_plan_run: graph capture needs a non-default stream");
         YMI_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = YMI_OK;
-        for (int i = first; i < last && rc == YMI_OK; ++i) rc = run_op(p->ops[i], s);
+        for (int i = first; i < last && rc == YMI_OK; ++i) rc = run_range_op(p, i, last, s);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(s, &g);
         if (rc != YMI_OK) {
@@ -315,8 +337,9 @@ extern "C" int ymi_plan_profile(ymi_plan* p, int iters, float* ms_out, void* str
     for (int it = 0; it < iters && rc == YMI_OK; ++it) {
         YMI_CHECK_HIP(hipEventRecord(ev[0], s));
         for (int i = 0; i < nops && rc == YMI_OK; ++i) {
-            rc = run_op(p->ops[i], s);
-            YMI_CHECK_HIP(hipEventRecord(ev[i + 1], s));
+            const int i0 = i;
+            rc = run_range_op(p, i, nops, s);   // a fused stem: its time lands on op 0, op 1 reads 0
+            for (int k = i0; k <= i; ++k) YMI_CHECK_HIP(hipEventRecord(ev[k + 1], s));
         }
         YMI_CHECK_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < nops && rc == YMI_OK; ++i) {

@@ -630,5 +630,6 @@ int conv_stem_launch(const ConvArgs& a, int dtype, int out_dtype, hipStream_t s)
 // the same stem fed from planar (3, H, W) images of the compute dtype, identity-size batches (no letterbox pass)
 int conv_stem_planar_launch(const ConvArgs& a, const void* const* imgs, int dtype, int out_dtype, hipStream_t s);
 int stem_body1_planar_launch(const ConvArgs& a1, const ConvArgs& a2, const void* const* imgs, int dtype, hipStream_t s);   // stem_body1_fused.hip
+int stem_body1_launch(const ConvArgs& a1, const ConvArgs& a2, int dtype, hipStream_t s);                                    // stem_body1_fused.hip (NHWC4 canvas)
 
 }  // namespace ymi

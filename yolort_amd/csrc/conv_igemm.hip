@@ -327,6 +327,31 @@ extern "C" int ymi_stem_body1_planar(const ymi_conv_desc* stem, const ymi_conv_d
     return stem_body1_planar_launch(a1, a2, imgs, stem->dtype, (hipStream_t)stream);
 }
 
+namespace ymi {
+// ops 0 + 1 of a plan (the stem reading the letterboxed canvas, body.1 reading the stem's output) as one launch; the stem's y is not written
+int stem_body1_desc_launch(const ymi_conv_desc* stem, const ymi_conv_desc* body1, hipStream_t s) {
+    YMI_REQUIRE(stem != nullptr && body1 != nullptr, "ymi_stem_body1: null argument");
+    YMI_REQUIRE(stem->x && stem->w && stem->bias && stem->zeros && body1->w && body1->bias && body1->y, "ymi_stem_body1: null buffer (stem.x, both weights / biases, the zero page and body1.y are required)");
+    YMI_REQUIRE(stem->n == body1->n && stem->n >= 1, "ymi_stem_body1: descriptors of batch %d / %d", stem->n, body1->n);
+    YMI_REQUIRE((stem->dtype == YMI_F16 || stem->dtype == YMI_BF16) && body1->dtype == stem->dtype && stem->out_dtype == stem->dtype && body1->out_dtype == stem->dtype,
+                "ymi_stem_body1: both convolutions must compute and store F16 or BF16");
+    YMI_REQUIRE(stem->ho == (stem->h + 2 * stem->ph - stem->kh) / stem->sh + 1 && stem->wo == (stem->w_in + 2 * stem->pw - stem->kw) / stem->sw + 1, "ymi_stem_body1: inconsistent stem output size");
+    YMI_REQUIRE(body1->y_cstride % 8 == 0, "ymi_stem_body1: y_cstride must be a multiple of 8");
+    ymi_conv_desc d1 = *stem, d2 = *body1;
+    d1.y = body1->y;                                 // the stem's output is not written
+    d2.x = body1->zeros ? body1->zeros : stem->zeros;   // not read: keep the zero-page offset check of the shared argument builder trivially true
+    d2.zeros = d2.x;
+    ConvArgs a1, a2;
+    { const int rc_args = fill_conv_args(&d1, a1); if (rc_args != YMI_OK) return rc_args; }
+    { const int rc_args = fill_conv_args(&d2, a2); if (rc_args != YMI_OK) return rc_args; }
+    return stem_body1_launch(a1, a2, stem->dtype, s);
+}
+}  // namespace ymi
+
+extern "C" int ymi_stem_body1(const ymi_conv_desc* stem, const ymi_conv_desc* body1, void* stream) {
+    return ymi::stem_body1_desc_launch(stem, body1, (hipStream_t)stream);
+}
+
 extern "C" int ymi_conv_head_decode_group(const ymi_conv_desc* convs, int n_levels, const ymi_post_desc* post, void* stream) {
     return ymi::conv_head_decode_group_launch(convs, n_levels, post, (hipStream_t)stream);
 }

@@ -1,4 +1,5 @@
-// The first two layers of the r6.0 backbone in ONE launch (gfx950), fed from the planar input images:
+// The first two layers of the r6.0 backbone in ONE launch (gfx950), fed from the planar input images (fixed-size streams) or from
+// the letterboxed NHWC4 canvas (dynamic-shape streams):
 //     body.0  Conv(3, 32, k=6, s=2, p=2) + BN + SiLU      (reference yolort/models/darknetv6.py:81, v5/models/common.py:69-70)
 //     body.1  Conv(32, 64, k=3, s=2, p=1) + BN + SiLU     (darknetv6.py:85-86)
 //
@@ -26,6 +27,10 @@ constexpr int SB_GROUPS = (SB_PPIX + 31) / 32;           // 18 groups of 32 stem
 constexpr int SB_IR = 2 * SB_PH + 4, SB_IC = 80;         // planar patch: 38 rows x 80 pixels (needed: columns 4 .. 73) per plane
 constexpr int SB_ENTRIES = 3 * SB_IR * (SB_IC / 8);      // 1140 16-byte row segments
 constexpr int SB_PIECES = (SB_ENTRIES + 63) / 64;        // 18 DMA pieces of 1 KiB
+// NHWC4 form (the letterboxed canvas of a dynamic-shape stream, 8 halves per super-pixel = 2 pixels x RGB0): 38 rows x 35 super-pixels per tile
+constexpr int SB_SW = SB_PW + 2;                         // 35 super-pixel columns: stem pixel sx reads super-pixels sx - 1 .. sx + 1
+constexpr int SB_SENTRIES = SB_IR * SB_SW;               // 1330 16-byte super-pixels
+constexpr int SB_SPIECES = (SB_SENTRIES + 63) / 64;      // 21 DMA pieces of 1 KiB
 constexpr int SB_MAX_IMGS = 32;
 #ifndef YMI_SB_PK
 #define YMI_SB_PK 0
@@ -36,10 +41,11 @@ struct SbImgs {
     const uint16_t* img[SB_MAX_IMGS];
 };
 
-constexpr int SB_W1 = 0, SB_W2 = 36 * 1024, SB_B2 = 256, SB_PLANAR = SB_PIECES * 1024, SB_PATCH = ((SB_PPIX + 15) / 16) * 1024;
-constexpr int SB_LDS = SB_W1 + SB_W2 + SB_B2 + SB_PLANAR + SB_PATCH;   // 36 + 0.25 + 18 + 36 KiB (the stem weights live in registers)
+constexpr int SB_W1 = 0, SB_W2 = 36 * 1024, SB_B2 = 256, SB_PLANAR = SB_SPIECES * 1024, SB_PATCH = ((SB_PPIX + 15) / 16) * 1024;   // (input patch sized for the larger, NHWC4 form)
+constexpr int SB_LDS = SB_W1 + SB_W2 + SB_B2 + SB_PLANAR + SB_PATCH;   // 36 + 0.25 + 21 + 36 KiB (the stem weights live in registers)
 
-template <int DT>
+// PLANAR: the input is one (3, H, W) planar image per batch element (pl.img; fixed-size streams); else a1.x is the NHWC4 canvas (n, H, W/2, 8) the letterbox wrote
+template <int DT, bool PLANAR>
 __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs a1, const ConvArgs a2, const SbImgs pl, int tiles_x, int tiles_y, int ntiles) {
     typedef typename Mfma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_sm[];
@@ -75,18 +81,26 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
         for (int s = 0; s < 9; ++s) wf1[s] = *reinterpret_cast<const frag*>(wr + 16 * s);
     }
 
-    // ---- planar patch DMA geometry (fixed per lane): entry e = (plane, row, segment of 8 pixels) ----
+    // ---- input patch DMA geometry (fixed per lane).  PLANAR: entry e = (plane, row, segment of 8 pixels); NHWC4: entry e = (row, super-pixel column) ----
     int e_plane[3], e_row[3], e_col[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int e = (wave * 3 + j) * 64 + lane;
-        const int ec = e < SB_ENTRIES ? e : SB_ENTRIES - 1;
-        const int plane = ec / (SB_IR * (SB_IC / 8));
-        const int rem = ec - plane * (SB_IR * (SB_IC / 8));
-        const int pr = rem / (SB_IC / 8), seg = rem - pr * (SB_IC / 8);
-        e_plane[j] = e < SB_ENTRIES ? plane : -1;
-        e_row[j] = pr - 4;
-        e_col[j] = 8 * seg - 8;
+        if constexpr (PLANAR) {
+            const int ec = e < SB_ENTRIES ? e : SB_ENTRIES - 1;
+            const int plane = ec / (SB_IR * (SB_IC / 8));
+            const int rem = ec - plane * (SB_IR * (SB_IC / 8));
+            const int pr = rem / (SB_IC / 8), seg = rem - pr * (SB_IC / 8);
+            e_plane[j] = e < SB_ENTRIES ? plane : -1;
+            e_row[j] = pr - 4;
+            e_col[j] = 8 * seg - 8;
+        } else {
+            const int ec = e < SB_SENTRIES ? e : SB_SENTRIES - 1;
+            const int pr = ec / SB_SW, sc = ec - pr * SB_SW;
+            e_plane[j] = e < SB_SENTRIES ? 0 : -1;
+            e_row[j] = pr - 4;
+            e_col[j] = sc - 2;     // super-pixel column relative to 2 * ox0
+        }
     }
     auto tile_origin = [&](int idx, int& img, int& oy0, int& ox0) {
         int t = xcd_remap(idx, ntiles);
@@ -100,15 +114,28 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
     auto issue_planar = [&](int idx) {
         int img, oy0, ox0;
         tile_origin(idx, img, oy0, ox0);
-        const uint16_t* base = pl.img[img];
+        if constexpr (PLANAR) {
+            const uint16_t* base = pl.img[img];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int pi = wave * 3 + j;
-            if (pi < SB_PIECES) {   // wave-uniform
-                const int iy = 4 * oy0 + e_row[j], ix = 4 * ox0 + e_col[j];
-                const bool ok = (e_plane[j] >= 0) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);   // W % 8 == 0: a segment is in or out as a whole
-                const uint16_t* src = ok ? base + ((int64_t)e_plane[j] * H + iy) * W + ix : a1.zeros;
-                glds16(src, planar + pi * 512);
+            for (int j = 0; j < 3; ++j) {
+                const int pi = wave * 3 + j;
+                if (pi < SB_PIECES) {   // wave-uniform
+                    const int iy = 4 * oy0 + e_row[j], ix = 4 * ox0 + e_col[j];
+                    const bool ok = (e_plane[j] >= 0) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);   // W % 8 == 0: a segment is in or out as a whole
+                    const uint16_t* src = ok ? base + ((int64_t)e_plane[j] * H + iy) * W + ix : a1.zeros;
+                    glds16(src, planar + pi * 512);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int pi = wave * 3 + j;
+                if (pi < SB_SPIECES) {   // wave-uniform
+                    const int iy = 4 * oy0 + e_row[j], isp = 2 * ox0 + e_col[j];
+                    const bool ok = (e_plane[j] >= 0) && ((unsigned)iy < (unsigned)H) && ((unsigned)isp < (unsigned)a1.w_in);
+                    const uint16_t* src = ok ? a1.x + ((int64_t)(img * H + iy) * a1.w_in + isp) * a1.x_cs : a1.zeros;
+                    glds16(src, planar + pi * 512);
+                }
             }
         }
     };
@@ -123,7 +150,8 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
         const int pr = qc / SB_PW, rem = qc - pr * SB_PW;
         const int pc = rem < SB_NE ? 2 * rem : 2 * (rem - SB_NE) + 1;
         s1_rc[j] = q < SB_PPIX ? ((pr << 16) | pc) : -1;
-        s1_off[j] = (2 * pr) * SB_IC + 2 * pc + 4;                     // planar patch element of tap (ky, kx') = (0, 0)
+        s1_off[j] = PLANAR ? (2 * pr) * SB_IC + 2 * pc + 4              // planar patch element of tap (ky, kx') = (0, 0)
+                           : ((2 * pr) * SB_SW + pc) * 8;                // NHWC4: super-pixel (row 2 pr, column pc) in halves
         s1_dst[j] = qc * 64 + ((hi ^ ((qc >> 2) & 3)) * 16);            // byte address of chunk `hi` of the slot (chunk hi + 2: ^ 32)
     }
     // ---- stage-2 geometry (fixed per lane): wave -> (32-pixel group, cout tile) ----
@@ -157,31 +185,45 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
             if (wave + 8 * j < SB_GROUPS) {   // wave-uniform
                 f32x16 acc[1][1];
                 init_acc<1, 1>(acc, bias1);
-                // all 27 planar reads of the group first, then the 9 MFMAs: left to itself the compiler reads, waits and multiplies step by step
-                // (one LDS round trip per MFMA, two waves per SIMD to hide it -- measured 5.4 us per tile)
-                uint32_t rr[9], gg[9], bb[9];
+                if constexpr (PLANAR) {
+                    // all 27 planar reads of the group first, then the 9 MFMAs: left to itself the compiler reads, waits and multiplies step by step
+                    // (one LDS round trip per MFMA, two waves per SIMD to hide it -- measured 5.4 us per tile)
+                    uint32_t rr[9], gg[9], bb[9];
 #pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    // tap = 2s + hi -> (ky, kx') = (tap / 3, tap % 3): compile-time per half
-                    const int tap0 = 2 * s, tap1 = 2 * s + 1;
-                    const int o0 = (tap0 / 3) * SB_IC + 2 * (tap0 % 3), o1 = (tap1 / 3) * SB_IC + 2 * (tap1 % 3);
-                    const uint16_t* p0 = planar + s1_off[j] + (hi ? o1 : o0);
-                    rr[s] = *reinterpret_cast<const uint32_t*>(p0);
-                    gg[s] = *reinterpret_cast<const uint32_t*>(p0 + PLANE_HALFS);
-                    bb[s] = *reinterpret_cast<const uint32_t*>(p0 + 2 * PLANE_HALFS);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int s = 0; s < 9; ++s) {
+                        // tap = 2s + hi -> (ky, kx') = (tap / 3, tap % 3): compile-time per half
+                        const int tap0 = 2 * s, tap1 = 2 * s + 1;
+                        const int o0 = (tap0 / 3) * SB_IC + 2 * (tap0 % 3), o1 = (tap1 / 3) * SB_IC + 2 * (tap1 % 3);
+                        const uint16_t* p0 = planar + s1_off[j] + (hi ? o1 : o0);
+                        rr[s] = *reinterpret_cast<const uint32_t*>(p0);
+                        gg[s] = *reinterpret_cast<const uint32_t*>(p0 + PLANE_HALFS);
+                        bb[s] = *reinterpret_cast<const uint32_t*>(p0 + 2 * PLANE_HALFS);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    const uint32_t r = rr[s], g = gg[s], b = bb[s];
-                    u32x4 q;
-                    q[0] = (r & 0xffffu) | (g << 16);        // R0 G0
-                    q[1] = b & 0xffffu;                      // B0 0
-                    q[2] = (r >> 16) | (g & 0xffff0000u);    // R1 G1
-                    q[3] = b >> 16;                          // B1 0
-                    frag af;
-                    __builtin_memcpy(&af, &q, 16);
-                    acc[0][0] = Mfma<DT>::run(wf1[s], af, acc[0][0]);
+                    for (int s = 0; s < 9; ++s) {
+                        const uint32_t r = rr[s], g = gg[s], b = bb[s];
+                        u32x4 q;
+                        q[0] = (r & 0xffffu) | (g << 16);        // R0 G0
+                        q[1] = b & 0xffffu;                      // B0 0
+                        q[2] = (r >> 16) | (g & 0xffff0000u);    // R1 G1
+                        q[3] = b >> 16;                          // B1 0
+                        frag af;
+                        __builtin_memcpy(&af, &q, 16);
+                        acc[0][0] = Mfma<DT>::run(wf1[s], af, acc[0][0]);
+                    }
+                } else {
+                    // NHWC4 canvas: a super-pixel IS the fragment of its tap (conv_stem_kernel's reads): nine 16-byte reads, then the nine MFMAs
+                    frag af[9];
+#pragma unroll
+                    for (int s = 0; s < 9; ++s) {
+                        const int tap0 = 2 * s, tap1 = 2 * s + 1;
+                        const int o0 = ((tap0 / 3) * SB_SW + (tap0 % 3)) * 8, o1 = ((tap1 / 3) * SB_SW + (tap1 % 3)) * 8;
+                        af[s] = *reinterpret_cast<const frag*>(planar + s1_off[j] + (hi ? o1 : o0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 9; ++s) acc[0][0] = Mfma<DT>::run(wf1[s], af[s], acc[0][0]);
                 }
                 const u32x2 norv[4] = {};
                 u32x4 o[2];
@@ -231,41 +273,55 @@ __global__ __launch_bounds__(512, 1) void stem_body1_fused_kernel(const ConvArgs
     }
 }
 
-template <int DT>
+template <int DT, bool PLANAR>
 static int stem_body1_launch_t(const ConvArgs& s0, const ConvArgs& b0, const void* const* imgs, hipStream_t st) {
     const int tiles_x = cdiv(b0.wo, SB_TW), tiles_y = cdiv(b0.ho, SB_TH);
-    auto kfn = stem_body1_fused_kernel<DT>;
+    auto kfn = stem_body1_fused_kernel<DT, PLANAR>;
     { const int rc_lds = allow_big_lds((const void*)kfn, SB_LDS); if (rc_lds != YMI_OK) return rc_lds; }
-    for (int base = 0; base < b0.n; base += SB_MAX_IMGS) {
+    const int per_launch = PLANAR ? SB_MAX_IMGS : b0.n;   // planar image pointers travel as kernel arguments, 32 at a time; the canvas is one tensor
+    for (int base = 0; base < b0.n; base += per_launch) {
         ConvArgs a1 = s0, a2 = b0;
-        const int n = b0.n - base < SB_MAX_IMGS ? b0.n - base : SB_MAX_IMGS;
+        const int n = b0.n - base < per_launch ? b0.n - base : per_launch;
         a1.n = a2.n = n;
         SbImgs pl;
-        for (int i = 0; i < SB_MAX_IMGS; ++i) pl.img[i] = (const uint16_t*)imgs[base + (i < n ? i : 0)];
+        for (int i = 0; i < SB_MAX_IMGS; ++i) pl.img[i] = PLANAR ? (const uint16_t*)imgs[base + (i < n ? i : 0)] : nullptr;
         a2.y = (void*)((uint16_t*)b0.y + (int64_t)base * b0.ho * b0.wo * b0.y_cs);
         a2.M = n * a2.ho * a2.wo;
         const int ntiles = n * tiles_x * tiles_y;
         a2.nblk_m = ntiles;
         a2.nblk_n = 1;
-        const int resident = 256;   // one 8-wave block per CU (99 KiB of LDS)
+        const int resident = 256;   // one 8-wave block per CU (102 KiB of LDS)
         hipLaunchKernelGGL(kfn, dim3(ntiles < resident ? ntiles : resident), dim3(512), SB_LDS, st, a1, a2, pl, tiles_x, tiles_y, ntiles);
     }
     return check_launch("stem_body1_fused_kernel");
 }
 
-// a1: the stem in its super-pixel form (as for conv_stem_planar_launch; y is not written); a2: Conv(32, 64, 3, 2, 1) over the stem's output (x is not read)
-int stem_body1_planar_launch(const ConvArgs& a1, const ConvArgs& a2, const void* const* imgs, int dtype, hipStream_t s) {
+static int stem_body1_check(const ConvArgs& a1, const ConvArgs& a2, const char* who) {
     YMI_REQUIRE(a1.cin == 8 && a1.kh == 6 && a1.kw == 3 && a1.sh == 2 && a1.sw == 1 && a1.ph == 2 && a1.pw == 1 && a1.k_pad >= 144 && a1.cout == 32 && a1.cout_pad >= 32 &&
                     a1.zeros != nullptr && a1.split == 0 && a1.res == nullptr && a1.act == YMI_ACT_SILU && a1.chain_w == nullptr && a1.up2 == 0,
-                "ymi_stem_body1_planar: the first descriptor must be the 32-channel stem in its 6x3 s(2,1) p(2,1) super-pixel form (SiLU, no residual / split / chain)");
-    YMI_REQUIRE((2 * a1.w_in) % 8 == 0, "ymi_stem_body1_planar: the image width must be a multiple of 8");
+                "%s: the first descriptor must be the 32-channel stem in its 6x3 s(2,1) p(2,1) super-pixel form (SiLU, no residual / split / chain)", who);
     YMI_REQUIRE(a2.kh == 3 && a2.kw == 3 && a2.sh == 2 && a2.sw == 2 && a2.ph == 1 && a2.pw == 1 && a2.cin == 32 && a2.k_pad == 288 && a2.cout == 64 && a2.cout_pad >= 64 &&
                     a2.up2 == 0 && a2.chain_w == nullptr && a2.split == 0 && a2.res == nullptr && a2.act == YMI_ACT_SILU,
-                "ymi_stem_body1_planar: the second descriptor must be Conv(32, 64, k=3, s=2, p=1) with SiLU (no residual / split / chain)");
+                "%s: the second descriptor must be Conv(32, 64, k=3, s=2, p=1) with SiLU (no residual / split / chain)", who);
     YMI_REQUIRE(a2.n == a1.n && a2.h == a1.ho && a2.w_in == a1.wo && a2.ho == (a2.h - 1) / 2 + 1 && a2.wo == (a2.w_in - 1) / 2 + 1,
-                "ymi_stem_body1_planar: the second convolution must read the first one's output (%dx%d), got %dx%d", a1.ho, a1.wo, a2.h, a2.w_in);
-    YMI_REQUIRE(((int64_t)a2.M + 1) * a2.y_cs < ((int64_t)1 << 31), "ymi_stem_body1_planar: output tensor too large for 32-bit offsets");
-    return dtype == YMI_F16 ? stem_body1_launch_t<YMI_F16>(a1, a2, imgs, s) : stem_body1_launch_t<YMI_BF16>(a1, a2, imgs, s);
+                "%s: the second convolution must read the first one's output (%dx%d), got %dx%d", who, a1.ho, a1.wo, a2.h, a2.w_in);
+    YMI_REQUIRE(((int64_t)a2.M + 1) * a2.y_cs < ((int64_t)1 << 31), "%s: output tensor too large for 32-bit offsets", who);
+    return YMI_OK;
+}
+
+// a1: the stem in its super-pixel form (as for conv_stem_planar_launch; y is not written); a2: Conv(32, 64, 3, 2, 1) over the stem's output (x is not read)
+int stem_body1_planar_launch(const ConvArgs& a1, const ConvArgs& a2, const void* const* imgs, int dtype, hipStream_t s) {
+    { const int rc = stem_body1_check(a1, a2, "ymi_stem_body1_planar"); if (rc != YMI_OK) return rc; }
+    YMI_REQUIRE((2 * a1.w_in) % 8 == 0, "ymi_stem_body1_planar: the image width must be a multiple of 8");
+    return dtype == YMI_F16 ? stem_body1_launch_t<YMI_F16, true>(a1, a2, imgs, s) : stem_body1_launch_t<YMI_BF16, true>(a1, a2, imgs, s);
+}
+
+// The same pair fed from the NHWC4 canvas a1.x (n, H, W / 2, 8) the letterbox wrote (dynamic-shape streams)
+int stem_body1_launch(const ConvArgs& a1, const ConvArgs& a2, int dtype, hipStream_t s) {
+    { const int rc = stem_body1_check(a1, a2, "ymi_stem_body1"); if (rc != YMI_OK) return rc; }
+    YMI_REQUIRE(a1.x != nullptr && a1.x_cs == 8, "ymi_stem_body1: the stem must read the NHWC4 canvas (8 halves per super-pixel)");
+    YMI_REQUIRE((int64_t)a1.n * a1.h * a1.w_in * 8 < ((int64_t)1 << 31), "ymi_stem_body1: input canvas too large for 32-bit offsets");
+    return dtype == YMI_F16 ? stem_body1_launch_t<YMI_F16, false>(a1, a2, nullptr, s) : stem_body1_launch_t<YMI_BF16, false>(a1, a2, nullptr, s);
 }
 
 }  // namespace ymi

@@ -190,6 +190,7 @@ class Plan:
         # reference conv -- no fused pairs / chained convs / folded upsample / fused head, no tile choice.  This is the mode
         # in which the HIP path meets the north-star tolerance against the fp32 CPU reference end to end.
         self.fp32 = dtype == torch.float32
+        self.fuse_stem = False   # set_fuse_stem()
         if self.fp32:
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
@@ -558,6 +559,14 @@ class Plan:
         return (d0.cout == 32 and d0.out_dtype == d0.dtype and d0.act == ACT_SILU and self.io[1]["x"].ptr == self.io[0]["y"].ptr and self.io[1]["x"].cs == 32
                 and d1.cin == 32 and d1.cout == 64 and (d1.kh, d1.kw, d1.sh, d1.sw, d1.ph, d1.pw) == (3, 3, 2, 2, 1, 1) and d1.k_pad == 288 and d1.act == ACT_SILU
                 and not d1.res and not d1.chain_w and d1.cout_split == 0 and d1.y2_mode == 0 and d1.out_dtype == d1.dtype == d0.dtype and d1.y_cstride % 8 == 0)
+
+    def set_fuse_stem(self, on: bool) -> bool:
+        """Dynamic-shape streams (ops 0 and 1 read the letterboxed canvas): run the two as ONE launch whenever a run covers both
+        (ymi_plan_set_fuse_stem; op indices stay, the stem's output buffer is then not written).  Returns what is in effect."""
+        on = bool(on) and self.stem_body1_fusable() and self.conv_descs[0].x_cstride == 8 and bool(self.conv_descs[0].x)
+        check(self.lib.ymi_plan_set_fuse_stem(self.handle, 1 if on else 0), "ymi_plan_set_fuse_stem")
+        self.fuse_stem = on
+        return on
 
     def stem_planar_ok(self, images: Sequence[Tensor], canvas_hw: Tuple[int, int]) -> bool:
         d = self.conv_descs.get(0)

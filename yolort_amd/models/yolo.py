@@ -276,6 +276,7 @@ class YOLO(nn.Module):
         x = plan.alloc(n, h, w, 4, zero=True)
         feats = self.backbone.emit(plan, x)
         n_backbone = plan.num_ops
+        plan.set_fuse_stem(os.environ.get("YOLORT_AMD_FUSE_STEM_CANVAS", "1") != "0")   # stem + body.1 as one launch on the letterboxed canvas too
         logits = post = rescale = None
         if self.fused():
             rescale = torch.zeros(n, 3, device=device, dtype=torch.float32)
