@@ -333,6 +333,81 @@ def test_halo8_with_a_chained_1x1_equals_the_two_launches(sim, tile, c_, residua
     assert (t_ch.view().float() - ref1).abs().max().item() <= 4e-3 * max(1.0, ref1.abs().max().item())
 
 
+@pytest.mark.parametrize("cin,cout,xcs", [(64, 64, 64), (64, 48, 64), (48, 48, 48), (64, 32, 96), (48, 64, 64)])
+def test_resident_weights_3x3_c64_kernel_logic(sim, cin, cout, xcs, monkeypatch):
+    """conv3x3_res.hip (tile 132): 48 / 64 input channels, resident weights, persistent blocks with the next tile's patch in flight -- against
+    torch, and BIT-IDENTICAL to the 8-wave implicit GEMM (tiles 113 / 114: the same K order -- tap-major, channel-minor; the halo kernel it replaces
+    walks 32-channel chunks outermost and rounds differently in the last bit); maps that are ragged against the 16 x 16 tiles, several
+    tiles per block (the double-buffered patch), the shortcut, a channel-slice input view (pixel stride > cin)"""
+    from yolort_amd import engine
+    cpu = torch.device("cpu")
+    monkeypatch.setenv("YOLORT_AMD_RES3X3_BLOCKS", "3")   # 12 / 1 / 4 tiles on 3 blocks: the persistent loop, both patch buffers, the deferred stores
+    for dtype, (n, h, w), residual in [(torch.float16, (2, 21, 37), True), (torch.bfloat16, (1, 16, 16), False), (torch.float16, (1, 5, 50), False)]:
+        g = torch.Generator().manual_seed(cin + cout + h)
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        pc = engine.PackedConv(wt, bias, None, dtype, cpu)
+        xw = Buf(n, h, w, xcs, dtype)
+        xw.view()[..., :cin] = x.permute(0, 2, 3, 1).to(dtype)
+        if xcs > cin:
+            xw.view()[..., cin:] = 7.0     # the neighbouring channels of the slice must not leak in
+        xb = xw.slice_c(0, cin)
+        rb = Buf(n, h, w, cout, dtype, fill=torch.randn(n, h, w, cout, generator=g)) if residual else None
+        ref = F.silu(F.conv2d(x, wt, bias, 1, 1))
+        if residual:
+            ref = ref + rb.view().float().permute(0, 3, 1, 2)
+        outs = []
+        for tile in (132, 113 if cout > 32 else 114) if cin % 32 == 0 else (132,):
+            wide = Buf(n, h, w, cout + 32, dtype)
+            yv = wide.slice_c(16, cout)
+            d = _conv_desc(xb, pc, yv, tile, k=3, pad=1, res=rb)
+            d.ktab = pc.ktab(w, xcs).data_ptr()
+            _check(sim, sim.sim_conv2d(C.byref(d)))
+            got = yv.view().float().permute(0, 3, 1, 2)
+            tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+            assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (tile, cin, cout)
+            w_all = wide.view().float()
+            assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + cout:].abs().max().item() == 0
+            outs.append(yv.view().clone())
+        if len(outs) == 2:
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "tile 132 differs from the implicit GEMM"
+
+
+def test_resident_weights_3x3_c64_with_a_chained_1x1_equals_the_two_launches(sim):
+    """tile 132 with the next Bottleneck's 1x1 riding in the epilogue (a wave owns all couts of its pixels, as in conv_halo8's 8 x 1 forms)"""
+    from yolort_amd import engine
+    dtype, cpu, c_ = torch.float16, torch.device("cpu"), 64
+    os.environ["YOLORT_AMD_RES3X3_BLOCKS"] = "5"
+    g = torch.Generator().manual_seed(132)
+    n, h, w = 2, 19, 23
+    x = torch.randn(n, c_, h, w, generator=g).to(dtype).float()
+    w3 = (torch.randn(c_, c_, 3, 3, generator=g) / np.sqrt(9 * c_)).to(dtype).float()
+    b3 = torch.randn(c_, generator=g) * 0.1
+    w1 = (torch.randn(c_, c_, 1, 1, generator=g) / np.sqrt(c_)).to(dtype).float()
+    b1 = torch.randn(c_, generator=g) * 0.1
+    pc3, pc1 = engine.PackedConv(w3, b3, None, dtype, cpu), engine.PackedConv(w1, b1, None, dtype, cpu)
+    xb = Buf(n, h, w, c_, dtype, fill=x.permute(0, 2, 3, 1))
+    rb = Buf(n, h, w, c_, dtype, fill=torch.randn(n, h, w, c_, generator=g))
+    kt = pc3.ktab(w, c_)
+
+    def d3(y, tile, chain=None):
+        d = _conv_desc(xb, pc3, y, tile, k=3, pad=1, res=rb, chain=chain)
+        d.ktab = kt.data_ptr()
+        return d
+
+    y_sep, t_sep = Buf(n, h, w, c_, dtype), Buf(n, h, w, c_, dtype)
+    _check(sim, sim.sim_conv2d(C.byref(d3(y_sep, 113))))
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(y_sep, pc1, t_sep, 27))))
+    y_ch, t_ch = Buf(n, h, w, c_, dtype), Buf(n, h, w, c_, dtype)
+    try:
+        _check(sim, sim.sim_conv2d(C.byref(d3(y_ch, 132, chain=(pc1, t_ch)))))
+    finally:
+        del os.environ["YOLORT_AMD_RES3X3_BLOCKS"]
+    assert torch.equal(y_ch.view().view(torch.int16), y_sep.view().view(torch.int16))
+    assert torch.equal(t_ch.view().view(torch.int16), t_sep.view().view(torch.int16)), (t_ch.view().float() - t_sep.view().float()).abs().max().item()
+
+
 @pytest.mark.parametrize("tile,cout", [(31, 128), (32, 64), (33, 32), (35, 64), (37, 128)])
 def test_halo4_3x3_kernel_logic(sim, tile, cout):
     """conv3x3_halo.hip (4-wave LDS-halo kernel)"""

@@ -191,7 +191,9 @@ class Plan:
         # in which the HIP path meets the north-star tolerance against the fp32 CPU reference end to end.
         self.fp32 = dtype == torch.float32
         self.fuse_stem = False   # set_fuse_stem()
+        self.res3x3 = os.environ.get("YOLORT_AMD_RES3X3", "1") != "0"   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
         if self.fp32:
+            self.res3x3 = False
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
             self.chain_next = False
@@ -316,6 +318,8 @@ class Plan:
                     0 if chain is None else (1 if len(chain) < 3 or chain[2] is None else 2 + chain[2].c))
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
+            elif self.res3x3 and self._res3x3_ok(d):
+                d.tile = 132   # resident-weights persistent 3x3 (conv3x3_res.hip): ahead of the table on every layer it fits (same-box A/B)
             elif self.use_tile_table:
                 d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
         esz = 2
@@ -333,6 +337,12 @@ class Plan:
                      ref_convs=ref_reads + (1 if chain is not None else 0), tile=int(d.tile),
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
+
+    @staticmethod
+    def _res3x3_ok(d: ConvDesc) -> bool:
+        chain_ok = (not d.chain_w) or (not d.chain_x2 and d.cout_pad == d.cout and d.cout in (32, 64))
+        return (d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin in (48, 64) and d.k_pad >= 9 * d.cin and d.cout <= 64
+                and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and chain_ok)
 
     _TUNE_CACHE: Dict[Tuple, int] = {}
     _TUNE_TIMES: Dict[str, Dict[str, float]] = {}
@@ -383,6 +393,8 @@ class Plan:
         if d.kh == 3 and d.kw == 3 and d.sh == d.sw and d.sh in (1, 2) and d.ph == 1 and d.pw == 1 and d.cin == 32 and d.cout in (32, 64) and d.k_pad == 288 and \
                 d.out_dtype == d.dtype and d.y2_mode != 2 and chain is None:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
+        if self._res3x3_ok(d):
+            cands = cands + [132]   # ... cin = 48 / 64, stride 1, cross-tile patch prefetch (conv3x3_res.hip)
         if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
             cands = cands + [41]   # dedicated stem kernel
         best, best_ms = 0, float("inf")
