@@ -592,11 +592,12 @@ def test_batched_nms_bit_exact_vs_oracle(sim, n, ncls, ties):
     np.testing.assert_array_equal(keep[: int(count[0])].astype(np.int64), ref)
 
 
-@pytest.mark.parametrize("thr,k,saturated", [(0.3, 300, False), (0.05, 50, False), (0.3, 300, True)])
-def test_postprocess_vs_oracle(sim, thr, k, saturated):
+@pytest.mark.parametrize("thr,k,saturated,cap0", [(0.3, 300, False, 4096), (0.05, 50, False, 4096), (0.3, 300, True, 4096), (0.02, 300, False, 131072), (0.3, 300, True, 131072)])
+def test_postprocess_vs_oracle(sim, thr, k, saturated, cap0):
     """ymi_postprocess on the simulator from the reference's own head-output layout: sigmoid / anchor decode, multi-label threshold, the
     per-image ranking sort, class-aware NMS, top-k and the in-kernel rescale (box_head.py:328-360, 414-427; transform.py:354-367) --
-    counts, labels and order exact, scores / boxes to the rounding of expf"""
+    counts, labels and order exact, scores / boxes to the rounding of expf.  cap0 = 131072: per-image regions of 65536 records, the MULTI-BLOCK form of the
+    score-prefix selection (sel_hist / sel_compact / sel_copyback over four slices; the saturated image still takes the one-block refinement)"""
     from oracle import yolov5_oracle as O
     from yolort_amd._lib import PostDesc
     g = torch.Generator().manual_seed(11)
@@ -620,7 +621,7 @@ def test_postprocess_vs_oracle(sim, thr, k, saturated):
         t[..., : 3 * kk] = ho.permute(0, 2, 3, 1, 4).reshape(n, ho.shape[2], ho.shape[3], 3 * kk)
         logits.append(t)
     total_anchors = sum(3 * h * w for h, w in shapes)
-    cap, flags = 4096, 0
+    cap, flags = cap0, 0
     while True:   # the host protocol of yolort_amd/ops.py: nothing is truncated silently, a too small candidate capacity is grown and the batch redone
         boxes, scores = torch.zeros(n, k, 4), torch.zeros(n, k)
         labels, count, status = torch.zeros(n, k, dtype=torch.int64), torch.zeros(n, dtype=torch.int32), torch.zeros(4, dtype=torch.int32)
@@ -639,6 +640,8 @@ def test_postprocess_vs_oracle(sim, thr, k, saturated):
         _check(sim, sim.ymi_postprocess(C.byref(d), None))
         st = status.tolist()
         if st[1] == 0:
+            if cap0 > 4096 and not saturated:
+                assert 2 * 4096 <= st[0] <= 2 * 6144, st   # both images were cut to just above sel_t = 4096 records: the selection ran -- with 65536-record regions, in its multi-block form
             if saturated:
                 assert flags == 0 and st[0] <= 6144 + 4096, st   # the prefix path held: image 0 was cut to <= RANK_MAX records, no exact-full redo
             break

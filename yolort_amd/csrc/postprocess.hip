@@ -13,6 +13,7 @@
 // with ties in candidate order (anchor asc, class asc) == a stable descending sort of the
 // reference's torch.where order (box_head.py:418).
 #include "post_common.hpp"
+#include <cstdlib>
 
 namespace ymi {
 
@@ -408,8 +409,108 @@ __device__ __forceinline__ void hist_add(int* hist, int bin, bool valid) {
     }
 }
 
+// Multi-block form of the selection's two streaming passes (round 3).  ONE block per image streams the image twice -- histogram, then the
+// in-place compaction -- and at 8 images of 218 k records (yolov5l6 at 1280 x 1280) that is 8 CUs moving 35 MB: 0.39 ms of a 0.52 ms post-process.
+// For images with regions of >= 2 * SEL_SLICE records the passes are split over slices of SEL_SLICE records:
+//   sel_hist_kernel      (slices x images)  LDS histogram of a slice, non-empty bins added to the image's global histogram
+//   select_prefix_kernel (images)           the cut from that histogram; unless the boundary bin is fat (refinement: the one-block path above stays
+//                                           in charge of the whole image) it only PUBLISHES the cut: mode 1, b*, and the count it implies
+//   sel_compact_kernel   (slices x images)  records of bins <= b* appended to the image's staging region (arrays [1], free until scatter_ranks)
+//                                           at positions handed out by one atomic per wave -- their order does not matter: every consumer ranks
+//                                           by the records' unique keys
+//   sel_copyback_kernel                     staging -> the front of the image's own region (<= RANK_MAX records)
+// An in-place multi-block compaction would overwrite records of slice 0 that its block may not have read yet.
+// What this does NOT yet split is the refinement of a fat boundary bin: the saturated synthetic scores of the benchmark configurations put most images there, so
+// the measured gain is small (C5: 0.51 -> 0.47 ms); a multi-block refinement is a fixed ladder of (histogram, pick) launch pairs, one per 11-bit level.
+constexpr int SEL_SLICE = 16384;
+
+__global__ __launch_bounds__(1024) void sel_hist_kernel(const uint64_t* in_hi, const int* img_count, int cap_img, int sel_t, int* ghist) {
+    __shared__ int hist[SEL_BINS];
+    const int img = blockIdx.y;
+    const int raw = img_count[img];
+    const int n_i = raw < cap_img ? raw : cap_img;
+    if (sel_t <= 0 || n_i <= sel_t + sel_t / 2) return;
+    const int i0 = blockIdx.x * SEL_SLICE;
+    const int i1 = i0 + SEL_SLICE < n_i ? i0 + SEL_SLICE : n_i;
+    if (i0 >= i1) return;
+    const uint64_t* hi = in_hi + (int64_t)img * cap_img;
+    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int c0 = i0; c0 < i1; c0 += 4 * blockDim.x) {   // (whole waves enter hist_add: its ballots need every lane)
+        uint64_t hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+            hv[u] = i < i1 ? hi[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool v = c0 + u * (int)blockDim.x + (int)threadIdx.x < i1;
+            hist_add(hist, v ? score_bin(hv[u]) : 0, v);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < SEL_BINS; b += blockDim.x)
+        if (hist[b] != 0) atomicAdd(&ghist[(int64_t)img * SEL_BINS + b], hist[b]);
+}
+
+__global__ __launch_bounds__(1024) void sel_compact_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* img_count, int cap_img, const int* sel_mode, int* gfill,
+                                                           uint64_t* st_hi, uint32_t* st_lo) {
+    const int img = blockIdx.y;
+    if (sel_mode[2 * img] != 1) return;
+    const int bstar = sel_mode[2 * img + 1];
+    const int raw = img_count[img];
+    const int n_i = raw < cap_img ? raw : cap_img;
+    const int i0 = blockIdx.x * SEL_SLICE;
+    const int i1 = i0 + SEL_SLICE < n_i ? i0 + SEL_SLICE : n_i;
+    if (i0 >= i1) return;
+    const uint64_t* hi = in_hi + (int64_t)img * cap_img;
+    const uint32_t* lo = in_lo + (int64_t)img * cap_img;
+    uint64_t* sh = st_hi + (int64_t)img * cap_img;
+    uint32_t* sl = st_lo + (int64_t)img * cap_img;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int c0 = i0; c0 < i1; c0 += 4 * blockDim.x) {
+        uint64_t h[4];
+        uint32_t l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+            h[u] = i < i1 ? hi[i] : 0ull;
+            l[u] = i < i1 ? lo[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool take = c0 + u * (int)blockDim.x + (int)threadIdx.x < i1 && score_bin(h[u]) <= bstar;
+            const uint64_t m = __ballot(take);
+            if (m == 0ull) continue;   // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&gfill[img], __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (take) {
+                const int pos = base + __popcll(m & lt);
+                sh[pos] = h[u];
+                sl[pos] = l[u];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sel_copyback_kernel(uint64_t* hi0, uint32_t* lo0, const uint64_t* st_hi, const uint32_t* st_lo, const int* sel_mode, const int* sel_count,
+                                                           int cap_img) {
+    const int img = blockIdx.y;
+    if (sel_mode[2 * img] != 1) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < sel_count[img]) {
+        hi0[(int64_t)img * cap_img + i] = st_hi[(int64_t)img * cap_img + i];
+        lo0[(int64_t)img * cap_img + i] = st_lo[(int64_t)img * cap_img + i];
+    }
+}
+
+// ghist / sel_mode non-null: the multi-block form (see above) -- the image's level-0 histogram is already in ghist, and an image whose cut needs no refinement is
+// left to sel_compact_kernel
 __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, uint32_t* in_lo, const int* img_count, int cap_img, int n_img, int sel_t,
-                                                             int* sel_count, uint32_t* rank_g, uint32_t* rank_p) {
+                                                             int* sel_count, uint32_t* rank_g, uint32_t* rank_p, const int* ghist, int* sel_mode) {
     __shared__ int hist[SEL_BINS];
     __shared__ int s_bstar, s_nsel, s_fill;
     const int img = blockIdx.x;
@@ -425,21 +526,25 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
     }
     uint64_t* hi = in_hi + (int64_t)img * cap_img;
     uint32_t* lo = in_lo + (int64_t)img * cap_img;
-    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    // One block streams a whole image (up to cap_img records: 2.6 MB at 218 k): four loads in flight per thread, or the pass is bound by one
-    // CU's load latency (a single 8-byte load per thread and iteration streamed ~60 GB/s)
-    for (int c0 = 0; c0 < n_i; c0 += 4 * blockDim.x) {   // (whole waves enter hist_add: its ballots need every lane)
-        uint64_t hv[4];
+    if (ghist != nullptr) {   // wave-uniform: sel_hist_kernel has counted the bins
+        for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = ghist[(int64_t)img * SEL_BINS + i];
+    } else {
+        for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        // One block streams a whole image (up to cap_img records: 2.6 MB at 218 k): four loads in flight per thread, or the pass is bound by one
+        // CU's load latency (a single 8-byte load per thread and iteration streamed ~60 GB/s)
+        for (int c0 = 0; c0 < n_i; c0 += 4 * blockDim.x) {   // (whole waves enter hist_add: its ballots need every lane)
+            uint64_t hv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
-            hv[u] = i < n_i ? hi[i] : 0ull;
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+                hv[u] = i < n_i ? hi[i] : 0ull;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool v = c0 + u * (int)blockDim.x + (int)threadIdx.x < n_i;
-            hist_add(hist, v ? score_bin(hv[u]) : 0, v);
+            for (int u = 0; u < 4; ++u) {
+                const bool v = c0 + u * (int)blockDim.x + (int)threadIdx.x < n_i;
+                hist_add(hist, v ? score_bin(hv[u]) : 0, v);
+            }
         }
     }
     __syncthreads();
@@ -469,6 +574,10 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
     const int bstar = s_bstar, nsel = s_nsel;
     if (nsel >= n_i) {   // the best bins hold everything: nothing to cut
         if (threadIdx.x == 0) { sel_count[img] = n_i; sel_count[n_img + img] = 0; }
+        return;
+    }
+    if (sel_mode != nullptr && nsel <= RANK_MAX) {   // multi-block form, plain cut: publish it, sel_compact_kernel moves the records
+        if (threadIdx.x == 0) { sel_mode[2 * img] = 1; sel_mode[2 * img + 1] = bstar; sel_count[img] = nsel; sel_count[n_img + img] = 1; }
         return;
     }
     // Round 3: a FAT boundary bin (saturated scores: thousands of records within 1/4096 of each other, or exactly equal) used to push the
@@ -1084,7 +1193,25 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
         // rank counters live in seg_start / kept_box, which are not in use before find_segments
         uint32_t* rank_g = w.seg_start;
         uint32_t* rank_p = reinterpret_cast<uint32_t*>(w.kept_box);
-        hipLaunchKernelGGL(select_prefix_kernel, dim3(d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, sel_t, w.sel_count, rank_g, rank_p);
+        // multi-block selection for large per-image regions; its scratch -- (n, 4096) histograms, then n fill counters and n {mode, b*} pairs -- lives in the P arrays,
+        // which nothing uses before scatter_ranks_kernel (cap_img * 8 bytes per image against 16 KiB + 12)
+        // (few images only: with 32 or more the one-block-per-image form already spreads over enough CUs and the three extra launches cost more than
+        // they save -- C3, 64 images: 0.89 -> 0.99 ms; C5, 8 images: 0.51 -> 0.47 ms, profiles/r03z5_sel_multi_ab.txt)
+        const bool multi = sel_t > 0 && cap_img >= 2 * SEL_SLICE && d->n < 32 && getenv("YOLORT_AMD_SEL_SINGLE") == nullptr;
+        int* ghist = reinterpret_cast<int*>(w.p_hi);
+        int* gfill = ghist + (int64_t)d->n * SEL_BINS;
+        int* sel_mode = gfill + d->n;
+        const int nslices = cdiv(cap_img, SEL_SLICE);
+        if (multi) {
+            YMI_CHECK_HIP(hipMemsetAsync(ghist, 0, ((size_t)d->n * SEL_BINS + 3 * (size_t)d->n) * sizeof(int), s));
+            hipLaunchKernelGGL(sel_hist_kernel, dim3(nslices, d->n), dim3(1024), 0, s, w.hi[0], w.img_count, cap_img, sel_t, ghist);
+        }
+        hipLaunchKernelGGL(select_prefix_kernel, dim3(d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, sel_t, w.sel_count, rank_g, rank_p,
+                           multi ? ghist : nullptr, multi ? sel_mode : nullptr);
+        if (multi) {
+            hipLaunchKernelGGL(sel_compact_kernel, dim3(nslices, d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, sel_mode, gfill, w.hi[1], w.lo[1]);
+            hipLaunchKernelGGL(sel_copyback_kernel, dim3(cdiv(RANK_MAX, 256), d->n), dim3(256), 0, s, w.hi[0], w.lo[0], w.hi[1], w.lo[1], sel_mode, w.sel_count, cap_img);
+        }
         const int rank_cap = cap_img < RANK_MAX ? cap_img : RANK_MAX;   // no image holds more than cap_img records
         hipLaunchKernelGGL(rank_image_kernel, dim3(cdiv(rank_cap, RANK_IT), cdiv(rank_cap, RANK_JT), d->n), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.sel_count, cap_img,
                            L.label_bits, rank_g, rank_p);
