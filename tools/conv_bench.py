@@ -34,8 +34,11 @@ def run(case, tiles, iters=20):
             x = plan.alloc(n, h, w, cin); x.base.normal_()
             wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
             pc = engine.PackedConv(wt, None, None, torch.float16, dev)
+            short = None
+            if os.environ.get("RES", "0") == "1" and s == 1:   # a shortcut operand (Bottleneck.add)
+                short = plan.alloc(n, h, w, cout); short.base.normal_()
             try:
-                plan.conv(x, pc, s, p, tile=tile, act=int(os.environ.get('ACT', '1')))
+                plan.conv(x, pc, s, p, tile=tile, act=int(os.environ.get('ACT', '1')), res=short)
             except Exception as e:
                 res.append((tile, None, str(e)[:60])); continue
         try:

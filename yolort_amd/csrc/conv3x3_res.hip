@@ -25,6 +25,16 @@
 
 namespace ymi {
 
+#ifdef YMI_STAMPS   // tuning aid (never in the shipped build): s_memtime timeline of wave 0 of each block, 8 slots per tile (tools/stamp_r3.py)
+__device__ unsigned long long ymi_stamps_r3[256 * 128];
+#define R3_STAMP(tile, slot)                                                                                                                        \
+    do {                                                                                                                                            \
+        if (threadIdx.x == 0 && (tile) < 16) ymi_stamps_r3[blockIdx.x * 128 + (tile) * 8 + (slot)] = __builtin_readcyclecounter();                   \
+    } while (0)
+#else
+#define R3_STAMP(tile, slot) ((void)0)
+#endif
+
 constexpr int R3_T = 16;                                  // output tile 16 x 16
 constexpr int R3_PH = R3_T + 2, R3_PITCH = R3_T + 2;      // patch rows / row pitch in slots
 constexpr int R3_SLOTS = R3_PH * R3_PITCH;                // 324 pixel slots of 128 B
@@ -61,8 +71,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_res_kernel(const ConvArgs a, i
     }
 
     // ---- patch DMA geometry (fixed per lane): entry e = piece*64 + lane -> slot e >> 3 = (pr, pc), position e & 7 holds chunk pos ^ v(pr, pc) ----
-    int p_rc[R3_PPW];     // pr << 16 | pc, or -1: nothing to fetch (past the patch, or one of the two unused chunks of a 48-channel pixel)
-    int p_kc[R3_PPW];
+    int p_rc[R3_PPW];     // pr << 16 | chunk << 8 | pc, or -1: nothing to fetch (past the patch, or one of the two unused chunks of a 48-channel pixel)
+    int p_off[R3_PPW];
 #pragma unroll
     for (int j = 0; j < R3_PPW; ++j) {
         int pi = wave * R3_PPW + j;
@@ -72,8 +82,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_res_kernel(const ConvArgs a, i
         const int qc = q < R3_SLOTS ? q : R3_SLOTS - 1;
         const int pr = qc / R3_PITCH, pc = qc - pr * R3_PITCH;
         const int chunk = (e & 7) ^ (((pr * R3_T + pc) >> 1) & 7);
-        p_rc[j] = (q < R3_SLOTS && chunk < NCH) ? ((pr << 16) | pc) : -1;
-        p_kc[j] = chunk * 8;
+        p_rc[j] = (q < R3_SLOTS && chunk < NCH) ? ((pr << 16) | (chunk << 8) | pc) : -1;
+        p_off[j] = (pr * a.w_in + pc) * a.x_cs + chunk * 8;   // relative to the patch origin: all an interior tile needs
     }
     // ---- fragment geometry (fixed per lane): output pixel p = wave*32 + frow -> (r, c); tap (dy, dx) reads slot (r + dy) * 18 + c + dx ----
     const int pr_o = (wave * 32 + frow) / R3_T, pc_o = (wave * 32 + frow) % R3_T;
@@ -94,79 +104,103 @@ __global__ __launch_bounds__(512, 1) void conv3x3_res_kernel(const ConvArgs a, i
         oy0 = ty * R3_T;
         ox0 = tx * R3_T;
     };
+    // one DMA piece of the patch of the tile at (img, oy0, ox0).  Interior tiles (the patch lies inside the image: most of them) take the offsets precomputed above
+    auto issue_piece = [&](auto jt, int img, int oy0, int ox0, unsigned char* dst) {
+        constexpr int j = decltype(jt)::value;
+        int pi = wave * R3_PPW + j;
+        pi = pi < R3_PIECES ? pi : R3_PIECES - 1;
+        int off;
+        if (oy0 >= 1 && ox0 >= 1 && oy0 + R3_T + 1 <= a.h && ox0 + R3_T + 1 <= a.w_in) {   // wave-uniform
+            off = p_rc[j] >= 0 ? ((img * a.h + oy0 - 1) * a.w_in + ox0 - 1) * a.x_cs + p_off[j] : a.x_zero_off;
+        } else {
+            const int iy = oy0 - 1 + (p_rc[j] >> 16), ix = ox0 - 1 + (p_rc[j] & 0xff);
+            const bool ok = p_rc[j] >= 0 && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w_in);
+            off = ok ? ((img * a.h + iy) * a.w_in + ix) * a.x_cs + ((p_rc[j] >> 8) & 0xff) * 8 : a.x_zero_off;
+        }
+        glds16(a.x + off, reinterpret_cast<uint16_t*>(dst + pi * 1024));
+    };
     auto issue_patch = [&](int idx, unsigned char* dst) {
         int img, oy0, ox0;
         tile_origin(idx, img, oy0, ox0);
-#pragma unroll
-        for (int j = 0; j < R3_PPW; ++j) {
-            int pi = wave * R3_PPW + j;
-            pi = pi < R3_PIECES ? pi : R3_PIECES - 1;
-            const int iy = oy0 - 1 + (p_rc[j] >> 16), ix = ox0 - 1 + (p_rc[j] & 0xffff);
-            const bool ok = p_rc[j] >= 0 && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w_in);
-            const int off = ok ? ((img * a.h + iy) * a.w_in + ix) * a.x_cs + p_kc[j] : a.x_zero_off;
-            glds16(a.x + off, reinterpret_cast<uint16_t*>(dst + pi * 1024));
-        }
+        static_for<0, R3_PPW>([&](auto jt) { issue_piece(jt, img, oy0, ox0, dst); });
     };
 
-    // Epilogue in two halves around the tile boundary (lean case: SiLU, no chained conv): the packets of tile i stay in registers across the barrier and are
-    // stored right after the DMA of tile i+1's patch is issued, at the top of tile i+1 -- they have a whole tile to be acknowledged before the next vmcnt(0) --
-    // and the shortcut of tile i is fetched at the top of tile i, a whole MFMA phase before it is added.  (Measured: neither round trip was what bounds a tile.
-    // Ablation on 64 -> 64 at 320^2, bs 8, 12.5 tiles per block, profiles/r03z4_res3x3_ablation.txt: whole kernel 92 us; without the MFMA loop 49; without the
-    // epilogue 67; without either 29 -- the bare DMA pipeline, one 41 KiB patch in flight per CU: 3.6 TB/s; weight / activation fragments read once instead of per
-    // step 90 / 88, both 82 -- so the LDS reads cost 11 us, NOT the 1.5 KiB-per-MFMA wall they were suspected to be.  The phases of a tile simply ADD: 8 waves meet at
-    // the barrier, run their 72 MFMAs together (2.6 us against 1.9 at the matrix pipe's rate), then their 32 SiLUs per lane together (2.0 us of vector ALU), and the
-    // pipe of the other kind idles meanwhile.  What would overlap them is the previous tile's SiLUs issued BETWEEN this tile's MFMAs, or two desynchronised
-    // blocks per CU -- neither fits 256 registers / 160 KiB as the kernel stands.)
+    // Lean case (SiLU, no chained conv): the epilogue of a tile is DEFERRED into the next tile's MFMA loop.  Ablation of the first version of this kernel, whose
+    // waves ran their 72 MFMAs and then their 32 SiLUs per lane (64 -> 64 at 320^2, bs 8, 12.5 tiles per block, profiles/r03z4_res3x3_ablation.txt): whole kernel 92 us;
+    // without the MFMA loop 49; without the epilogue 67; without either 29 (the bare DMA pipeline, one 41 KiB patch in flight per CU: 3.6 TB/s); weight / activation
+    // fragments read once instead of per step 90 / 88, both 82 -- the phases of a tile simply ADD (MFMAs 2.6 us, SiLUs 2.0 us, sync + exposed DMA 1.2 - 2.3 us), because the
+    // 8 waves meet at the barrier and are then all in the same phase, using the same pipe; LDS fragment traffic costs 11 us of the 92.  Deferring the stores alone (past the
+    // next patch's DMA issue) and prefetching the shortcut changed nothing: the round trips were not what bounds a tile.
     // (cout may end 16 channels short of the last 32-wide group -- yolov5m's 48: its second packet pair is then neither fetched nor stored)
     const int64_t cs_max = a.y_cs > a.res_cs ? a.y_cs : a.res_cs;
     const bool lean = !CHAIN && a.act == YMI_ACT_SILU && (a.cout & 15) == 0 && a.cout > 32 * (TN - 1) && ((int64_t)a.M + 1) * cs_max < ((int64_t)1 << 31);
     const bool has_res = a.res != nullptr;
-    auto store_prev = [&](const LeanPix& p, const u32x4 (&o)[TN][2]) {
-        if (!p.ok) return;
-        char* const yb = reinterpret_cast<char*>(a.y);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (i * 32 + q * 16 < a.cout) st16(yb + (size_t)(i * 32 + q * 16) * 2 + (size_t)p.yo, o[i][q]);
-    };
-    auto load_res = [&](const LeanPix& p, u32x2 (&rv)[TN][4]) {
+    // the shortcut in packet form (conv_common.hpp, lean_load_residual): two 16-byte loads per 32-channel group, unswapped where they are used
+    auto load_res = [&](const LeanPix& p, u32x4 (&rw)[TN][2]) {
         const char* const rb = reinterpret_cast<const char*>(a.res);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (i * 32 + g * 8 < a.cout) rv[i][g] = *reinterpret_cast<const u32x2*>(rb + (size_t)p.ro + (i * 32 + g * 8) * 2);
+            for (int q = 0; q < 2; ++q)
+                if (i * 32 + q * 16 < a.cout) rw[i][q] = *reinterpret_cast<const u32x4*>(rb + (size_t)p.ro + (size_t)(8 * hi) + (i * 32 + q * 16) * 2);
     };
-    u32x4 o_prev[TN][2];
+    // The epilogue of tile i-1 runs INSIDE the MFMA loop of tile i, one pair of outputs per step: step s = (sub-tile i, octet pair g, half h, pair p) rounds two
+    // accumulators of the previous tile exactly like silu_pack_subtile (same helper, same order of operations); every fourth step completes a 16-byte packet
+    // (the lane swap) and stores it.  A wave's vector-ALU work then sits between its own MFMAs instead of after them.
+    constexpr int NS = 8 * TN;
+    f32x16 acc_prev[TN];
+    u32x4 rw[TN][2] = {};
+    u32x2 rv[4] = {};   // the current packet's four 4-channel pieces (rows g, g + 1 of the group)
+    uint32_t pk[2][2] = {};
     LeanPix p_prev;
     p_prev.ok = false;
     bool have_prev = false;
+    auto epi_step = [&](auto st) {
+        constexpr int s = decltype(st)::value;
+        constexpr int i = s >> 3, g = ((s >> 2) & 1) * 2, h = (s >> 1) & 1, p = s & 1;
+        if constexpr ((s & 3) == 0) {
+            if (has_res) unswap_residual_packet(rw[i][g >> 1], rv, g);
+        }
+        f32x2 v = {acc_prev[i][(g + h) * 4 + 2 * p], acc_prev[i][(g + h) * 4 + 2 * p + 1]};
+        v = silu_pair(v);
+        if (has_res) v = v + unpack16<DT>(rv[g + h][p]);
+        pk[h][p] = cvt_pk16<DT>(v);
+        if constexpr ((s & 3) == 3) {
+            const auto rx = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const u32x4 q = {rx[0], ry[0], rx[1], ry[1]};
+            constexpr int co = i * 32 + (g >> 1) * 16;
+            if (p_prev.ok && co < a.cout) st16(reinterpret_cast<char*>(a.y) + (size_t)co * 2 + (size_t)p_prev.yo, q);
+        }
+    };
 
     int idx = blockIdx.x;
     int buf = 0;
     if (idx < ntiles) issue_patch(idx, patch0);
-    for (; idx < ntiles; idx += gridDim.x) {
+    int tile_no = 0;
+    (void)tile_no;
+    for (; idx < ntiles; idx += gridDim.x, ++tile_no) {
         int img, oy0, ox0;
         tile_origin(idx, img, oy0, ox0);
+        R3_STAMP(tile_no, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        R3_STAMP(tile_no, 1);
         __syncthreads();   // patch i has landed; everyone is done reading patch i-1 (first pass: the weights are written)
+        R3_STAMP(tile_no, 2);
         const unsigned char* pb = patch0 + buf * R3_PATCH_BYTES;
+        // The previous tile's shortcut FIRST: vmcnt retires in order, so a load issued behind the next patch's DMA is only known to have landed when that whole patch
+        // has (timeline of the first version, 64 -> 64 at 320^2 with a shortcut: 2035 cycles of a 14 100-cycle tile waiting right here, profiles/r03z9_res3x3_timeline.txt)
+        if (lean && have_prev && has_res) load_res(p_prev, rw);
+        // (issuing the DMA of the next patch piece by piece between the MFMAs below moved its 1300 cycles per tile into the loop, one for one: a wave stalls at a
+        // vector-memory instruction until the texture path accepts it, and nothing behind it issues -- profiles/r03z9_res3x3_timeline.txt)
         if (idx + (int)gridDim.x < ntiles) issue_patch(idx + gridDim.x, patch0 + (buf ^ 1) * R3_PATCH_BYTES);
         buf ^= 1;
+        R3_STAMP(tile_no, 3);
         auto pix = [&](int, int64_t& m, bool& ok) {
             const int oy = oy0 + pr_o, ox = ox0 + pc_o;
             ok = oy < a.ho && ox < a.wo;
             m = ((int64_t)img * a.ho + oy) * a.wo + ox;
         };
-        LeanPix p_cur;
-        u32x2 rv[TN][4] = {};
-        if (lean) {
-            if (have_prev) store_prev(p_prev, o_prev);
-            p_cur = lean_pix(a, 0, hi, pix);
-            if (has_res) load_res(p_cur, rv);
-        }
-
         f32x16 acc[TN][1];
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -179,43 +213,64 @@ __global__ __launch_bounds__(512, 1) void conv3x3_res_kernel(const ConvArgs a, i
         // unit = U k16 steps of one tap (half a tap at CIN = 64, a whole one at 48): its U activation and U * TN weight fragments are fetched
         // under the previous unit's MFMAs (a whole tap in flight twice over did not fit the 256 registers of a wave: 84 spilled)
         constexpr int U = KC == 4 ? 2 : KC, NU = 9 * KC / U;
+        // epilogue steps run in the last two thirds of the loop: the shortcut fetched at the top of this tile is a memory round trip away (with the steps starting at
+        // unit 1 the loop waited 2000 cycles for it at its head)
+        constexpr int E0 = NU / 3, SPU = (NS + (NU - E0) - 1) / (NU - E0);
         frag fa[2][U], fw[2][U][TN];
+        // (the 9 * KC fragment addresses are invariant across tiles: left alone, the compiler hoists all of them out of the tile loop -- 36 registers at CIN = 64,
+        // and the kernel spills; laundering the tap's base address inside the loop keeps the one-instruction XORs where they are used)
         auto read_unit = [&](auto ut, auto bt) {
             constexpr int u = decltype(ut)::value, b = decltype(bt)::value;
             constexpr int t = (u * U) / KC, kc0 = (u * U) % KC;
+            int eb = ea[t];
+            asm volatile("" : "+v"(eb));
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                fa[b][k] = *reinterpret_cast<const frag*>(pb + (ea[t] ^ ((kc0 + k) << 5)));
+                fa[b][k] = *reinterpret_cast<const frag*>(pb + (eb ^ ((kc0 + k) << 5)));
 #pragma unroll
                 for (int i = 0; i < TN; ++i) fw[b][k][i] = wl[((t * KC + kc0 + k) * TN + i) * 64 + lane];
             }
         };
-        read_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        static_for<0, NU>([&](auto ut) {
-            constexpr int u = decltype(ut)::value;
-            if constexpr (u + 1 < NU) read_unit(std::integral_constant<int, u + 1>{}, std::integral_constant<int, (u + 1) & 1>{});
+        auto run_tile = [&](auto with_epi) {
+            constexpr bool EPI = decltype(with_epi)::value;
+            read_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            static_for<0, NU>([&](auto ut) {
+                constexpr int u = decltype(ut)::value;
+                if constexpr (u + 1 < NU) read_unit(std::integral_constant<int, u + 1>{}, std::integral_constant<int, (u + 1) & 1>{});
 #pragma unroll
-            for (int k = 0; k < U; ++k)
+                for (int k = 0; k < U; ++k)
 #pragma unroll
-                for (int i = 0; i < TN; ++i) acc[i][0] = Mfma<DT>::run(fw[u & 1][k][i], fa[u & 1][k], acc[i][0]);
-        });
+                    for (int i = 0; i < TN; ++i) acc[i][0] = Mfma<DT>::run(fw[u & 1][k][i], fa[u & 1][k], acc[i][0]);
+                if constexpr (EPI && u >= E0) {
+                    static_for<0, SPU>([&](auto jt) {
+                        constexpr int s = (u - E0) * SPU + decltype(jt)::value;
+                        if constexpr (s < NS) epi_step(std::integral_constant<int, s>{});
+                    });
+                }
+            });
+        };
+        R3_STAMP(tile_no, 4);
+        if (lean && have_prev) run_tile(std::true_type{});
+        else run_tile(std::false_type{});
+        R3_STAMP(tile_no, 5);
         if constexpr (CHAIN) {
             finish_wave_tile_chain<DT, TN, 1>(a, acc, hi, lane, pix);   // a wave owns ALL couts of its 32 pixels: a chained 1x1 runs from registers
         } else {
-            if (lean) {   // the arithmetic of finish_wave_tile_lean; the stores follow at the top of the next tile
+            if (lean) {   // handed to the next tile's loop (or to the tail below)
 #pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    if (has_res) silu_pack_subtile<DT, true>(acc[i][0], rv[i], o_prev[i]);
-                    else silu_pack_subtile<DT, false>(acc[i][0], rv[i], o_prev[i]);
-                }
-                p_prev = p_cur;
+                for (int i = 0; i < TN; ++i) acc_prev[i] = acc[i][0];
+                p_prev = lean_pix(a, 0, hi, pix);
                 have_prev = true;
             } else {
                 finish_wave_tile<DT, DT, TN, 1>(a, acc, 0, hi, pix);
             }
         }
+        R3_STAMP(tile_no, 6);
     }
-    if (have_prev) store_prev(p_prev, o_prev);
+    if (have_prev) {   // the last tile's epilogue, in one piece
+        if (has_res) load_res(p_prev, rw);
+        static_for<0, NS>([&](auto st) { epi_step(st); });
+    }
 }
 
 template <int DT, int CIN, int TN, bool CHAIN>
@@ -261,3 +316,9 @@ int conv3x3_res_launch(const ConvArgs& a, int dtype, int out_dtype, int variant,
 }
 
 }  // namespace ymi
+
+#ifdef YMI_STAMPS
+extern "C" int ymi_debug_stamps_r3(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ymi::ymi_stamps_r3), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -259,9 +259,19 @@ __device__ __forceinline__ f32x2 unpack16(uint32_t u) {
 // -- also exactly the activation fragments of v_mfma_f32_32x32x16 for a chained 1x1 convolution
 // PK = false: the same arithmetic with scalar fp32 instructions instead of v_pk_mul_f32 / v_pk_add_f32 (identical results; MI355X_MICROARCH.md prices a packed
 // fp32 instruction above two scalar ones when it sits beside MFMAs -- an A/B knob of the fused stem kernel's stage 1)
+// SiLU of two fp32 values with packed instructions: x * rcp(1 + exp2(-x * log2 e)) -- THE arithmetic of every 16-bit epilogue (one definition: kernels that
+// spread a tile's epilogue over the next tile's MFMAs, conv3x3_res.hip, must round exactly like the ones that run it in one piece)
+__device__ __forceinline__ f32x2 silu_pair(f32x2 v) {
+    const f32x2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.0f, 1.0f};
+    const f32x2 t = v * nl2e;
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = e + one;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return v * r;
+}
+
 template <int DT, bool RES, bool ACT = true, bool PK = true>
 __device__ __forceinline__ void silu_pack_subtile(const f32x16& acc, const u32x2 (&rv)[4], u32x4 (&o)[2]) {
-    const f32x2 nl2e = {-1.44269504088896341f, -1.44269504088896341f}, one = {1.0f, 1.0f};
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
         uint32_t pk[2][2];
@@ -284,11 +294,7 @@ __device__ __forceinline__ void silu_pack_subtile(const f32x16& acc, const u32x2
                     v[0] = a0;
                     v[1] = a1;
                 } else if constexpr (ACT) {
-                    const f32x2 t = v * nl2e;
-                    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                    e = e + one;
-                    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
-                    v = v * r;
+                    v = silu_pair(v);
                 }
                 if constexpr (RES) v = v + unpack16<DT>(rv[g + h][p]);
                 pk[h][p] = cvt_pk16<DT>(v);
@@ -335,13 +341,31 @@ __device__ __forceinline__ LeanPix lean_pix(const ConvArgs& a, int j, int hi, Pi
     }
     return p;
 }
+// The shortcut arrives in the PACKET form the outputs leave in: lane (pixel, hi) loads the two 16-byte packets of channel octets (0 + hi) and (2 + hi) of each
+// 32-channel group -- 32 bytes of 32 pixels per instruction, like a lean store -- and the lane swap of silu_pack_subtile, run backwards, hands every lane the four
+// 4-channel pieces of its accumulator rows.  (Round 3: loaded as four 8-byte pieces per group it cost the texture path twice the cache-line look-ups per wave, 256
+// instead of 128 for a 64-channel tile, and the persistent 3x3 kernel's timeline showed its waves stalled at exactly these instructions:
+// profiles/r03z9_res3x3_timeline.txt.)
+__device__ __forceinline__ void unswap_residual_packet(const u32x4& w, u32x2 (&rv)[4], int g) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+    rv[g][0] = s0[0];
+    rv[g + 1][0] = s0[1];
+    rv[g][1] = s1[0];
+    rv[g + 1][1] = s1[1];
+}
 template <int TN>
-__device__ __forceinline__ void lean_load_residual(const ConvArgs& a, int cbase0, const LeanPix& p, u32x2 (&rv)[TN][4]) {
+__device__ __forceinline__ void lean_load_residual(const ConvArgs& a, int cbase0, const LeanPix& p, u32x2 (&rv)[TN][4], int hi) {
     const char* const rb = reinterpret_cast<const char*>(a.res + cbase0);
+    u32x4 w[TN][2];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rv[i][g] = *reinterpret_cast<const u32x2*>(rb + (size_t)p.ro + (i * 32 + g * 8) * 2);
+        for (int q = 0; q < 2; ++q) w[i][q] = *reinterpret_cast<const u32x4*>(rb + (size_t)p.ro + (size_t)(8 * hi) + (i * 32 + q * 16) * 2);   // p.ro carries 4 * hi channels: + 4 more
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) unswap_residual_packet(w[i][q], rv[i], 2 * q);
 }
 // stores the two packets of sub-tile `cb` (first channel, wave-uniform, a multiple of 32) of one pixel group
 __device__ __forceinline__ void lean_store(const ConvArgs& a, const LeanPix& p, int cb, const u32x4 (&o)[2]) {
@@ -370,7 +394,7 @@ __device__ __forceinline__ void finish_wave_tile_lean(const ConvArgs& a, const f
     for (int j = 0; j < TM; ++j) {
         const LeanPix p = lean_pix(a, j, hi, pix);
         u32x2 rv[TN][4] = {};
-        if constexpr (RES) lean_load_residual<TN>(a, cbase0, p, rv);
+        if constexpr (RES) lean_load_residual<TN>(a, cbase0, p, rv, hi);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             u32x4 o[2];
@@ -419,7 +443,7 @@ __device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, cons
         u32x2 rv[TN][4] = {};
         if constexpr (RES) {
             const LeanPix p = lean_pix(a, j, hi, pix);
-            lean_load_residual<TN>(a, cbase0, p, rv);
+            lean_load_residual<TN>(a, cbase0, p, rv, hi);
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
