@@ -305,6 +305,37 @@ def test_conv3x3_res_kernel(dev, cin, cout, shape):
     _run_conv(dev, torch.bfloat16, cin=cin, cout=cout, k=3, s=1, p=1, tile=132, seed=133 + cin + cout, **shape)
 
 
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("cout", [64, 32])
+def test_conv3x3_res_equals_the_implicit_gemm_bit_for_bit(dev, cout, residual):
+    """tile 132 accumulates in the implicit GEMM's K order (tap-major, channel-minor) and rounds through the same silu_pair / lane-swap code, its epilogue
+    spread over the next tile's MFMA loop and its shortcut fetched in packet form: the outputs equal tile 113 / 114's bit for bit (300 tiles on 256 blocks:
+    deferred epilogues, the tail, partial tiles)"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(7 + cout)
+    n, h, w, cin = 12, 80, 77, 64
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(n, cout, h, w, generator=g)
+    outs = []
+    for tile in (132, 113 if cout > 32 else 114):
+        plan = engine.Plan(dev, torch.float16)
+        xv = plan.alloc(n, h, w, cin)
+        xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+        pc = engine.PackedConv(wt.half().float(), bias, None, torch.float16, dev)
+        yv = plan.alloc(n, h, w, cout, zero=True)
+        rv = None
+        if residual:
+            rv = plan.alloc(n, h, w, cout)
+            rv.as_tensor().copy_(_nhwc(r).to(dev, torch.float16))
+        plan.conv(xv, pc, 1, 1, out=yv, res=rv, tile=tile)
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append(yv.as_tensor().clone())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), f"max difference {(outs[0].float() - outs[1].float()).abs().max().item()}"
+
+
 @pytest.mark.parametrize("tile", [121, 122, 123, 124])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv1x1_stream_kernel(dev, dtype, tile):
