@@ -420,8 +420,10 @@ __device__ __forceinline__ void hist_add(int* hist, int bin, bool valid) {
 //                                           by the records' unique keys
 //   sel_copyback_kernel                     staging -> the front of the image's own region (<= RANK_MAX records)
 // An in-place multi-block compaction would overwrite records of slice 0 that its block may not have read yet.
-// What this does NOT yet split is the refinement of a fat boundary bin: the saturated synthetic scores of the benchmark configurations put most images there, so
-// the measured gain is small (C5: 0.51 -> 0.47 ms); a multi-block refinement is a fixed ladder of (histogram, pick) launch pairs, one per 11-bit level.
+// A fat boundary bin (saturated scores: the benchmark configurations' synthetic weights put most images there) is refined by the same exact radix selection as
+// in the one-block kernel, as a fixed LADDER of six (sel_rhist_kernel, sel_rpick_kernel) pairs -- 11 key bits per level; the launch sequence does not depend on the
+// data, levels an image does not need return at once.  C5 (8 images of 218 k records): post-process 0.52 -> 0.23 ms; C3 (64 images): 0.90 -> 0.73 ms, but the extra
+// passes cost the pipelined throughput 1 %, so batches of 32 or more images keep the one-block form by default (profiles/r03z12_sel_ladder_ab.txt).
 constexpr int SEL_SLICE = 16384;
 
 __global__ __launch_bounds__(1024) void sel_hist_kernel(const uint64_t* in_hi, const int* img_count, int cap_img, int sel_t, int* ghist) {
@@ -454,11 +456,114 @@ __global__ __launch_bounds__(1024) void sel_hist_kernel(const uint64_t* in_hi, c
         if (hist[b] != 0) atomicAdd(&ghist[(int64_t)img * SEL_BINS + b], hist[b]);
 }
 
-__global__ __launch_bounds__(1024) void sel_compact_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* img_count, int cap_img, const int* sel_mode, int* gfill,
+// per-image state of the multi-block selection: {mode, b*, shift, need, have, prefix lo, prefix hi, -}.  mode 0: nothing to do here (no cut, or the one-block kernel did
+// it); 1: plain cut at bin b*; 2: the boundary bin is fat, refinement in progress; 3: refined -- records of b* are taken iff (g >> shift) <= prefix
+constexpr int SEL_STATE = 8;
+constexpr int SEL_RB = 11, SEL_RBINS = 1 << SEL_RB, SEL_LEVELS = (64 + SEL_RB - 1) / SEL_RB;   // 11 key bits per refinement level: six levels exhaust the 64-bit key
+
+// one refinement level, counting half: digit histogram of the records of bin b* that share the prefix chosen so far (slices x images)
+__global__ __launch_bounds__(1024) void sel_rhist_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* img_count, int cap_img, const int* sel_state, int* rhist) {
+    __shared__ int hist[SEL_RBINS];
+    const int img = blockIdx.y;
+    const int* st = sel_state + SEL_STATE * img;
+    if (st[0] != 2) return;
+    const int bstar = st[1], shift = st[2];
+    const uint64_t prefix = (uint64_t)(uint32_t)st[5] | ((uint64_t)(uint32_t)st[6] << 32);
+    const int width = shift >= SEL_RB ? SEL_RB : shift, nshift = shift - width;
+    const int raw = img_count[img];
+    const int n_i = raw < cap_img ? raw : cap_img;
+    const int i0 = blockIdx.x * SEL_SLICE;
+    const int i1 = i0 + SEL_SLICE < n_i ? i0 + SEL_SLICE : n_i;
+    if (i0 >= i1) return;
+    const uint64_t* hi = in_hi + (int64_t)img * cap_img;
+    const uint32_t* lo = in_lo + (int64_t)img * cap_img;
+    for (int i = threadIdx.x; i < SEL_RBINS; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int c0 = i0; c0 < i1; c0 += 4 * blockDim.x) {
+        uint64_t hv[4];
+        uint32_t lv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = c0 + u * (int)blockDim.x + (int)threadIdx.x;
+            hv[u] = i < i1 ? hi[i] : 0ull;
+            lv[u] = i < i1 ? lo[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bool v = c0 + u * (int)blockDim.x + (int)threadIdx.x < i1 && score_bin(hv[u]) == bstar;
+            const uint64_t g = ((uint64_t)(uint32_t)hv[u] << 32) | lv[u];
+            v = v && (shift >= 64 || (g >> shift) == prefix);
+            hist_add(hist, (int)((g >> nshift) & (uint64_t)((1 << width) - 1)), v);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < SEL_RBINS; b += blockDim.x)
+        if (hist[b] != 0) atomicAdd(&rhist[(int64_t)img * SEL_RBINS + b], hist[b]);
+}
+
+// ... deciding half (one wave per image): whole digit bins are kept in key order until the target is reached; descend into the bin that crosses it, or stop when the
+// selection fits RANK_MAX (the arithmetic of select_prefix_kernel's one-block refinement).  Leaves the image's digit histogram zeroed for the next level.
+__global__ __launch_bounds__(64) void sel_rpick_kernel(int* sel_state, int* rhist, int* sel_count) {
+    const int img = blockIdx.x, lane = threadIdx.x;
+    int* st = sel_state + SEL_STATE * img;
+    if (st[0] != 2) return;
+    int* h = rhist + (int64_t)img * SEL_RBINS;
+    const int shift = st[2], need = st[3], have = st[4];
+    const uint64_t prefix = (uint64_t)(uint32_t)st[5] | ((uint64_t)(uint32_t)st[6] << 32);
+    const int width = shift >= SEL_RB ? SEL_RB : shift, nshift = shift - width;
+    constexpr int PER = SEL_RBINS / 64;
+    int sum = 0;
+    for (int b = 0; b < PER; ++b) sum += h[lane * PER + b];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    const int excl = incl - sum;
+    int digit = 0, before = 0, inbin = 0;
+    const bool mine = excl < need && incl >= need;   // exactly one lane
+    if (mine) {
+        int c = excl, b = lane * PER;
+        for (; b < lane * PER + PER; ++b) {
+            if (c + h[b] >= need) break;
+            c += h[b];
+        }
+        digit = b;
+        before = c;
+        inbin = h[b];
+    }
+    const uint64_t owner = __ballot(mine);
+    const int src = owner ? __builtin_ctzll(owner) : 0;
+    digit = __shfl(digit, src, 64);
+    before = __shfl(before, src, 64);
+    inbin = __shfl(inbin, src, 64);
+    __builtin_amdgcn_wave_barrier();   // every lane has read its counts before they are cleared
+    for (int b = 0; b < PER; ++b) h[lane * PER + b] = 0;
+    if (lane == 0) {
+        const uint64_t np = (shift < 64 ? (prefix << width) : 0ull) | (uint64_t)digit;
+        st[2] = nshift;
+        st[5] = (int)(uint32_t)np;
+        st[6] = (int)(uint32_t)(np >> 32);
+        if (have + before + inbin <= RANK_MAX || nshift == 0) {   // keep the whole crossing digit bin: the selection fits (or the key is exhausted: unique keys)
+            st[0] = 3;
+            sel_count[img] = have + before + inbin;
+        } else {
+            st[4] = have + before;   // digit bins below the crossing one are taken whole
+            st[3] = need - before;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void sel_compact_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* img_count, int cap_img, const int* sel_state, int* gfill,
                                                            uint64_t* st_hi, uint32_t* st_lo) {
     const int img = blockIdx.y;
-    if (sel_mode[2 * img] != 1) return;
-    const int bstar = sel_mode[2 * img + 1];
+    const int* st = sel_state + SEL_STATE * img;
+    const int mode = st[0];
+    if (mode != 1 && mode != 3) return;
+    const int bstar = st[1];
+    const int sel_shift = mode == 3 ? st[2] : 64;
+    const uint64_t sel_prefix = (uint64_t)(uint32_t)st[5] | ((uint64_t)(uint32_t)st[6] << 32);
     const int raw = img_count[img];
     const int n_i = raw < cap_img ? raw : cap_img;
     const int i0 = blockIdx.x * SEL_SLICE;
@@ -481,7 +586,9 @@ __global__ __launch_bounds__(1024) void sel_compact_kernel(const uint64_t* in_hi
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool take = c0 + u * (int)blockDim.x + (int)threadIdx.x < i1 && score_bin(h[u]) <= bstar;
+            const int b = score_bin(h[u]);
+            const bool take = c0 + u * (int)blockDim.x + (int)threadIdx.x < i1 &&
+                              (b < bstar || (b == bstar && (sel_shift >= 64 || ((((uint64_t)(uint32_t)h[u] << 32) | l[u]) >> sel_shift) <= sel_prefix)));
             const uint64_t m = __ballot(take);
             if (m == 0ull) continue;   // wave-uniform
             int base = 0;
@@ -496,10 +603,11 @@ __global__ __launch_bounds__(1024) void sel_compact_kernel(const uint64_t* in_hi
     }
 }
 
-__global__ __launch_bounds__(256) void sel_copyback_kernel(uint64_t* hi0, uint32_t* lo0, const uint64_t* st_hi, const uint32_t* st_lo, const int* sel_mode, const int* sel_count,
+__global__ __launch_bounds__(256) void sel_copyback_kernel(uint64_t* hi0, uint32_t* lo0, const uint64_t* st_hi, const uint32_t* st_lo, const int* sel_state, const int* sel_count,
                                                            int cap_img) {
     const int img = blockIdx.y;
-    if (sel_mode[2 * img] != 1) return;
+    const int mode = sel_state[SEL_STATE * img];
+    if (mode != 1 && mode != 3) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < sel_count[img]) {
         hi0[(int64_t)img * cap_img + i] = st_hi[(int64_t)img * cap_img + i];
@@ -576,8 +684,23 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
         if (threadIdx.x == 0) { sel_count[img] = n_i; sel_count[n_img + img] = 0; }
         return;
     }
-    if (sel_mode != nullptr && nsel <= RANK_MAX) {   // multi-block form, plain cut: publish it, sel_compact_kernel moves the records
-        if (threadIdx.x == 0) { sel_mode[2 * img] = 1; sel_mode[2 * img + 1] = bstar; sel_count[img] = nsel; sel_count[n_img + img] = 1; }
+    if (sel_mode != nullptr) {   // multi-block form: publish the cut (plain), or hand the fat boundary bin to the refinement ladder; sel_compact_kernel moves the records
+        if (threadIdx.x == 0) {
+            int* st = sel_mode + SEL_STATE * img;
+            st[1] = bstar;
+            sel_count[n_img + img] = 1;
+            if (nsel <= RANK_MAX) {
+                st[0] = 1;
+                sel_count[img] = nsel;
+            } else {
+                const int before_bin = nsel - hist[bstar];   // records of the better bins
+                st[0] = 2;
+                st[2] = 64;
+                st[3] = sel_t - before_bin;   // still wanted from the boundary bin (>= 1)
+                st[4] = before_bin;           // taken for sure
+                st[5] = st[6] = 0;
+            }
+        }
         return;
     }
     // Round 3: a FAT boundary bin (saturated scores: thousands of records within 1/4096 of each other, or exactly equal) used to push the
@@ -1193,24 +1316,30 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
         // rank counters live in seg_start / kept_box, which are not in use before find_segments
         uint32_t* rank_g = w.seg_start;
         uint32_t* rank_p = reinterpret_cast<uint32_t*>(w.kept_box);
-        // multi-block selection for large per-image regions; its scratch -- (n, 4096) histograms, then n fill counters and n {mode, b*} pairs -- lives in the P arrays,
-        // which nothing uses before scatter_ranks_kernel (cap_img * 8 bytes per image against 16 KiB + 12)
-        // (few images only: with 32 or more the one-block-per-image form already spreads over enough CUs and the three extra launches cost more than
-        // they save -- C3, 64 images: 0.89 -> 0.99 ms; C5, 8 images: 0.51 -> 0.47 ms, profiles/r03z5_sel_multi_ab.txt)
-        const bool multi = sel_t > 0 && cap_img >= 2 * SEL_SLICE && d->n < 32 && getenv("YOLORT_AMD_SEL_SINGLE") == nullptr;
+        // multi-block selection for large per-image regions; its scratch -- (n, 4096) bin and (n, 2048) digit histograms, n fill counters, n states -- lives in the P
+        // arrays, which nothing uses before scatter_ranks_kernel (cap_img * 8 bytes per image against 24 KiB + 36)
+        // (few images only: with 32 or more the one-block-per-image form already spreads over enough CUs, and the ladder's extra passes cost throughput)
+        static const int multi_max_n = getenv("YOLORT_AMD_SEL_MULTI_MAXN") ? atoi(getenv("YOLORT_AMD_SEL_MULTI_MAXN")) : 32;   // tuning aid
+        const bool multi = sel_t > 0 && cap_img >= 2 * SEL_SLICE && d->n < multi_max_n && getenv("YOLORT_AMD_SEL_SINGLE") == nullptr;
         int* ghist = reinterpret_cast<int*>(w.p_hi);
-        int* gfill = ghist + (int64_t)d->n * SEL_BINS;
-        int* sel_mode = gfill + d->n;
+        int* rhist = ghist + (int64_t)d->n * SEL_BINS;
+        int* gfill = rhist + (int64_t)d->n * SEL_RBINS;
+        int* sel_state = gfill + d->n;
         const int nslices = cdiv(cap_img, SEL_SLICE);
         if (multi) {
-            YMI_CHECK_HIP(hipMemsetAsync(ghist, 0, ((size_t)d->n * SEL_BINS + 3 * (size_t)d->n) * sizeof(int), s));
+            YMI_CHECK_HIP(hipMemsetAsync(ghist, 0, (size_t)d->n * (SEL_BINS + SEL_RBINS + 1 + SEL_STATE) * sizeof(int), s));
             hipLaunchKernelGGL(sel_hist_kernel, dim3(nslices, d->n), dim3(1024), 0, s, w.hi[0], w.img_count, cap_img, sel_t, ghist);
         }
         hipLaunchKernelGGL(select_prefix_kernel, dim3(d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, d->n, sel_t, w.sel_count, rank_g, rank_p,
-                           multi ? ghist : nullptr, multi ? sel_mode : nullptr);
+                           multi ? ghist : nullptr, multi ? sel_state : nullptr);
         if (multi) {
-            hipLaunchKernelGGL(sel_compact_kernel, dim3(nslices, d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, sel_mode, gfill, w.hi[1], w.lo[1]);
-            hipLaunchKernelGGL(sel_copyback_kernel, dim3(cdiv(RANK_MAX, 256), d->n), dim3(256), 0, s, w.hi[0], w.lo[0], w.hi[1], w.lo[1], sel_mode, w.sel_count, cap_img);
+            // the refinement ladder: a fixed number of (count, decide) pairs -- the launch sequence must not depend on the data; levels an image does not need return at once
+            for (int l = 0; l < SEL_LEVELS; ++l) {
+                hipLaunchKernelGGL(sel_rhist_kernel, dim3(nslices, d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, sel_state, rhist);
+                hipLaunchKernelGGL(sel_rpick_kernel, dim3(d->n), dim3(64), 0, s, sel_state, rhist, w.sel_count);
+            }
+            hipLaunchKernelGGL(sel_compact_kernel, dim3(nslices, d->n), dim3(1024), 0, s, w.hi[0], w.lo[0], w.img_count, cap_img, sel_state, gfill, w.hi[1], w.lo[1]);
+            hipLaunchKernelGGL(sel_copyback_kernel, dim3(cdiv(RANK_MAX, 256), d->n), dim3(256), 0, s, w.hi[0], w.lo[0], w.hi[1], w.lo[1], sel_state, w.sel_count, cap_img);
         }
         const int rank_cap = cap_img < RANK_MAX ? cap_img : RANK_MAX;   // no image holds more than cap_img records
         hipLaunchKernelGGL(rank_image_kernel, dim3(cdiv(rank_cap, RANK_IT), cdiv(rank_cap, RANK_JT), d->n), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.sel_count, cap_img,
