@@ -592,7 +592,8 @@ def test_batched_nms_bit_exact_vs_oracle(sim, n, ncls, ties):
     np.testing.assert_array_equal(keep[: int(count[0])].astype(np.int64), ref)
 
 
-@pytest.mark.parametrize("thr,k,saturated,cap0", [(0.3, 300, False, 4096), (0.05, 50, False, 4096), (0.3, 300, True, 4096), (0.02, 300, False, 131072), (0.3, 300, True, 131072)])
+@pytest.mark.parametrize("thr,k,saturated,cap0", [(0.3, 300, False, 4096), (0.05, 50, False, 4096), (0.3, 300, True, 4096), (0.02, 300, False, 131072), (0.3, 300, True, 131072),
+                                                 (0.02, 300, "mixed", 131072)])
 def test_postprocess_vs_oracle(sim, thr, k, saturated, cap0):
     """ymi_postprocess on the simulator from the reference's own head-output layout: sigmoid / anchor decode, multi-label threshold, the
     per-image ranking sort, class-aware NMS, top-k and the in-kernel rescale (box_head.py:328-360, 414-427; transform.py:354-367) --
@@ -605,6 +606,13 @@ def test_postprocess_vs_oracle(sim, thr, k, saturated, cap0):
     kk = nc + 5
     shapes = [(10, 12), (5, 6), (3, 3)]
     heads = [torch.randn(n, 3, h, w, kk, generator=g) * 2.0 - 1.0 for h, w in shapes]
+    if saturated == "mixed":   # multi-block selection with one crowded image (cut) and one sparse image (left alone) in the same batch
+        for ho in heads:
+            ho[1, ..., 4] -= 4.0
+        saturated = False
+        mixed = True
+    else:
+        mixed = False
     if saturated:
         # thousands of (anchor, class) pairs with scores within 1/4096 of 1.0 -- many exactly equal -- in image 0: the score-prefix selection's boundary
         # bin is FAT (round 3: refined by an exact radix selection on the full sort key instead of sending the image to the one-block sort)
@@ -640,7 +648,9 @@ def test_postprocess_vs_oracle(sim, thr, k, saturated, cap0):
         _check(sim, sim.ymi_postprocess(C.byref(d), None))
         st = status.tolist()
         if st[1] == 0:
-            if cap0 > 4096 and not saturated:
+            if cap0 > 4096 and mixed:
+                assert 4096 <= st[0] <= 6144 + 6144 and len(ref[1]["scores"]) > 0, st   # image 0 cut to just above sel_t, image 1 (fewer than 1.5 sel_t records) untouched
+            elif cap0 > 4096 and not saturated:
                 assert 2 * 4096 <= st[0] <= 2 * 6144, st   # both images were cut to just above sel_t = 4096 records: the selection ran -- with 65536-record regions, in its multi-block form
             if saturated:
                 assert flags == 0 and st[0] <= 6144 + 4096, st   # the prefix path held: image 0 was cut to <= RANK_MAX records, no exact-full redo
