@@ -358,7 +358,7 @@ def test_resident_weights_3x3_c64_kernel_logic(sim, cin, cout, xcs, monkeypatch)
         if residual:
             ref = ref + rb.view().float().permute(0, 3, 1, 2)
         outs = []
-        for tile in (132, 113 if cout > 32 else 114) if cin % 32 == 0 else (132,):
+        for tile in ((132, 113 if cout > 32 else 114) if cin % 32 == 0 else (132,)) + ((133,) if cout == 64 else ()):
             wide = Buf(n, h, w, cout + 32, dtype)
             yv = wide.slice_c(16, cout)
             d = _conv_desc(xb, pc, yv, tile, k=3, pad=1, res=rb)
@@ -370,8 +370,8 @@ def test_resident_weights_3x3_c64_kernel_logic(sim, cin, cout, xcs, monkeypatch)
             w_all = wide.view().float()
             assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + cout:].abs().max().item() == 0
             outs.append(yv.view().clone())
-        if len(outs) == 2:
-            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "tile 132 differs from the implicit GEMM"
+        for o in outs[1:]:   # the implicit GEMM (cin % 32 == 0) and the register-weights variant (tile 133, cout = 64)
+            assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16)), "tile 132 differs from the implicit GEMM / tile 133"
 
 
 def test_resident_weights_3x3_c64_with_a_chained_1x1_equals_the_two_launches(sim):

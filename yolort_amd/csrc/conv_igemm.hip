@@ -98,6 +98,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile >= 121 && tile <= 124) return conv1x1_stream_launch(a, DT, ODT, tile - 120, s);   // streaming 1x1 (cin <= 128), no LDS
     if (tile == 131) return conv3x3_c32_launch(a, DT, ODT, 1, s);                              // resident-weights persistent 3x3, cin = 32
     if (tile == 132) return conv3x3_res_launch(a, DT, ODT, 1, s);                              // ... cin = 48 / 64, stride 1
+    if (tile == 133) return conv3x3_rw_launch(a, DT, ODT, 1, s);                               // ... weights in registers (opt-in)
     switch (tile_group_of(tile)) {
         case 0: return launch_tile_group<0, DT, ODT>(a, is1x1, tile, s);
         case 1: return launch_tile_group<1, DT, ODT>(a, is1x1, tile, s);

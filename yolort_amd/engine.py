@@ -191,9 +191,9 @@ class Plan:
         # in which the HIP path meets the north-star tolerance against the fp32 CPU reference end to end.
         self.fp32 = dtype == torch.float32
         self.fuse_stem = False   # set_fuse_stem()
-        self.res3x3 = os.environ.get("YOLORT_AMD_RES3X3", "1") != "0"   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
+        self.res3x3 = {"0": 0, "1": 1}.get(os.environ.get("YOLORT_AMD_RES3X3", "2"), 2)   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
         if self.fp32:
-            self.res3x3 = False
+            self.res3x3 = 0
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
             self.chain_next = False
@@ -319,7 +319,9 @@ class Plan:
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
             elif self.res3x3 and self._res3x3_ok(d):
-                d.tile = 132   # resident-weights persistent 3x3 (conv3x3_res.hip): ahead of the table on every layer it fits (same-box A/B)
+                # resident-weights persistent 3x3 (conv3x3_res.hip): ahead of the table on every layer it fits (same-box A/B); its
+                # register-weights variant (conv3x3_rw.hip, bit-identical, 9-10 % faster: profiles/r03z14_rw3x3.txt) where that one fits; YOLORT_AMD_RES3X3=1: tile 132 only
+                d.tile = 133 if (self.res3x3 == 2 and d.cout == 64 and d.act == ACT_SILU and not d.chain_w) else 132
             elif self.use_tile_table:
                 d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
         esz = 2
@@ -395,6 +397,8 @@ class Plan:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
         if self._res3x3_ok(d):
             cands = cands + [132]   # ... cin = 48 / 64, stride 1, cross-tile patch prefetch (conv3x3_res.hip)
+            if d.cout == 64 and d.act == ACT_SILU and not d.chain_w:
+                cands = cands + [133]   # ... weights in registers, two blocks per CU (conv3x3_rw.hip)
         if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
             cands = cands + [41]   # dedicated stem kernel
         best, best_ms = 0, float("inf")
