@@ -296,13 +296,14 @@ def test_conv3x3_c32_kernel(dev, stride, cout, shape):
     _run_conv(dev, torch.bfloat16, cin=32, cout=cout, k=3, s=stride, p=1, tile=131, seed=132 + stride + cout, **shape)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 48), (48, 48), (64, 32)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 48), (48, 48), (64, 32), (48, 64)])
 @pytest.mark.parametrize("shape", [dict(n=2, h=40, w=40), dict(n=1, h=33, w=21), dict(n=3, h=16, w=16), dict(n=2, h=5, w=7), dict(n=12, h=80, w=80), dict(n=2, h=160, w=160)])
 def test_conv3x3_res_kernel(dev, cin, cout, shape):
     """resident-weights persistent 3x3 kernel for cin = 48 / 64 (conv3x3_res.hip, tile 132): ragged sizes (partial 16 x 16 tiles), more tiles than
     resident blocks (12 x 25 = 300 tiles on 256 blocks: the persistent loop, its double-buffered patch and deferred stores), cout below the 64-wide wave tile, residual and channel-slice views"""
-    _run_conv(dev, torch.float16, cin=cin, cout=cout, k=3, s=1, p=1, tile=132, residual=True, x_cs_extra=32 if cin == 64 else 16, y_cs_extra=64, seed=132 + cin + cout, **shape)
-    _run_conv(dev, torch.bfloat16, cin=cin, cout=cout, k=3, s=1, p=1, tile=132, seed=133 + cin + cout, **shape)
+    for tile in (132, 133) if cout == 64 else (132,):   # 133 = the register-weights variant (conv3x3_rw.hip): cout = 64 only
+        _run_conv(dev, torch.float16, cin=cin, cout=cout, k=3, s=1, p=1, tile=tile, residual=True, x_cs_extra=32 if cin == 64 else 16, y_cs_extra=64, seed=132 + cin + cout, **shape)
+        _run_conv(dev, torch.bfloat16, cin=cin, cout=cout, k=3, s=1, p=1, tile=tile, seed=133 + cin + cout, **shape)
 
 
 @pytest.mark.parametrize("residual", [False, True])
