@@ -16,7 +16,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import yolov5_oracle as O  # noqa: E402
-from yolort_amd.utils.synth import COND_GAMMA, COND_HEAD_GAIN, COND_SIZE, cond_bn_path, cond_images, synth_bn_path, synth_images, synth_state_dict  # noqa: E402
+from yolort_amd.utils.synth import (COND_GAMMA, COND_HEAD_GAIN, COND_SIZE, SPREAD_OBJ_GAIN, SPREAD_OBJ_LEVEL, SPREAD_TARGET, cond_bn_path, cond_images, spread_cls_prior,  # noqa: E402
+                                    spread_images, synth_bn_path, synth_images, synth_state_dict)
 
 
 def reference_template(arch: str):
@@ -72,21 +73,22 @@ def photo_images():
     return out
 
 
-def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, thr: float = COND_THRESH, photo: bool = False):
+def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, thr: float = COND_THRESH, photo: bool = False, spread: bool = False):
     S, n = COND[arch]
     try:
         tmpl = reference_template(arch)
     except Exception:
         from yolort_amd.models import yolo as Y
         tmpl = Y.__dict__[arch]().state_dict()
-    sd = synth_state_dict(tmpl, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=0.0, bn_gamma=COND_GAMMA)
+    extra = dict(obj_gain=SPREAD_OBJ_GAIN, cls_prior=spread_cls_prior(seed)) if spread else {}
+    sd = synth_state_dict(tmpl, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=0.0, bn_gamma=COND_GAMMA, **extra)
     div = 64 if arch.endswith("6_r60") else 32
-    imgs = photo_images() if photo else cond_images(arch, seed)
+    imgs = photo_images() if photo else (spread_images(arch, seed) if spread else cond_images(arch, seed))
     batch, _ = O.letterbox(imgs, S, S, div)
     # yolov5l6 (round 3): with BatchNorm statistics taken on full-frame noise, the letterboxed, resized evaluation images drive the deep P6 network 10 - 200 x out of
     # its calibrated range (PAN output rms 5 / 24 / 91 / 227 per level, head logits of +-900: every image empty or saturated, tests/golden/cond_l6_search.txt), so
     # its statistics come from the evaluation batch itself, like the photo variant's; the committed n / s / m calibrations are untouched
-    calib = batch if (photo or arch.endswith("6_r60")) else synth_images(n, S, S, seed=1000 + seed)
+    calib = batch if (photo or spread or arch.endswith("6_r60")) else synth_images(n, S, S, seed=1000 + seed)
     O.CALIB.active = True
     try:
         with torch.no_grad():
@@ -98,16 +100,22 @@ def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, t
     obj = torch.cat([h[..., 4].flatten() for h in ho])
     pc = torch.sigmoid(torch.cat([h[..., 5:].flatten(0, -2) for h in ho]))
     lo, hi = -14.0, 6.0
+    lo, hi = (-40.0, 6.0) if spread else (lo, hi)
     for _ in range(48):   # bisection on the candidate count (monotone in the bias)
         mid = 0.5 * (lo + hi)
-        if int((torch.sigmoid(obj + mid)[:, None] * pc > thr).sum()) > target * len(imgs):
+        if spread:   # the spread recipe counts hot ANCHORS (objectness alone): each yields several labels through the class priors
+            count = int((torch.sigmoid(obj + mid) > SPREAD_OBJ_LEVEL).sum())
+            over = count > SPREAD_TARGET * len(imgs)
+        else:
+            over = int((torch.sigmoid(obj + mid)[:, None] * pc > thr).sum()) > target * len(imgs)
+        if over:
             hi = mid
         else:
             lo = mid
     bias = round(0.5 * (lo + hi), 3)
     stats = {k: v.numpy().astype(np.float32) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
     stats["__obj_bias__"] = np.float32(bias)
-    out = cond_bn_path(arch, seed, "photo" if photo else "cond")
+    out = cond_bn_path(arch, seed, "photo" if photo else ("spread" if spread else "cond"))
     np.savez(out, **stats)
     cand = int((torch.sigmoid(obj + bias)[:, None] * pc > thr).sum())
     print(arch, "conditioned" + (" (photos)" if photo else "") + ": obj bias", bias, "candidates", cand, "on", len(imgs), "images ->", out, os.path.getsize(out) // 1024, "KB")
@@ -116,14 +124,15 @@ def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, t
 if __name__ == "__main__":
     if "--cond" in sys.argv:
         photo = "--photo" in sys.argv
-        args = [a for a in sys.argv[1:] if a not in ("--cond", "--photo")]
+        spread = "--spread" in sys.argv
+        args = [a for a in sys.argv[1:] if a not in ("--cond", "--photo", "--spread")]
         seed = 0
         for a in list(args):
             if a.startswith("--seed="):
                 seed = int(a.split("=")[1])
                 args.remove(a)
         for a in args or list(COND):
-            calibrate_conditioned(a, seed, photo=photo)
+            calibrate_conditioned(a, seed, photo=photo, spread=spread)
         sys.exit(0)
     archs = sys.argv[1:] or ["yolov5_darknet_pan_n_r60", "yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60", "yolov5_darknet_pan_l6_r60"]
     for a in archs:

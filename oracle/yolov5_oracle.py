@@ -160,6 +160,9 @@ class _Emulate:
 
     def __init__(self) -> None:
         self.dtype = None
+        # optional predicate on the layer prefix (e.g. "backbone.body.4.m.0.cv2", "head.head.1"): only the layers it accepts store their input / weights in
+        # `dtype`, every other layer computes on what it is given in fp32 -- the per-layer error budget of tools/error_budget.py (None: every layer)
+        self.select = None
         # optional torch.Generator: every rounded tensor takes one extra ulp-level relative perturbation on a random half of its elements --
         # a different, equally valid rounding history (another summation order / tile).  tests/golden/make_golden.py uses a few of them to
         # measure the tolerance a 16-bit path can be held to on a workload BEFORE the tolerance is written into a GPU test.
@@ -181,8 +184,8 @@ class _Trace:
 TRACE = _Trace()
 
 
-def _q(x: Tensor) -> Tensor:
-    if EMULATE.dtype is None:
+def _q(x: Tensor, layer: Optional[str] = None) -> Tensor:
+    if EMULATE.dtype is None or (EMULATE.select is not None and layer is not None and not EMULATE.select(layer)):
         return x
     y = x.to(EMULATE.dtype).to(torch.float32)
     if EMULATE.jitter is not None:
@@ -202,7 +205,7 @@ def conv_bn_silu(x: Tensor, sd: Dict[str, Tensor], p: str, stride: int = 1, pad:
     if EMULATE.dtype is not None:  # folded-BN, low-precision storage emulation (see _Emulate)
         scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + BN_EPS)
         bias = sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale
-        y = F.conv2d(_q(x), _q(w * scale.view(-1, 1, 1, 1)), bias, stride, k // 2 if pad is None else pad)
+        y = F.conv2d(_q(x, p), _q(w * scale.view(-1, 1, 1, 1), p), bias, stride, k // 2 if pad is None else pad)
         return F.silu(y)
     y = F.conv2d(x, w, None, stride, k // 2 if pad is None else pad)
     if CALIB.active:
@@ -224,7 +227,7 @@ def c3(x: Tensor, sd: Dict[str, Tensor], p: str, shortcut: bool) -> Tensor:
     y = conv_bn_silu(x, sd, p + ".cv1")
     for j in range(_count(sd, p + ".m")):
         z = conv_bn_silu(conv_bn_silu(y, sd, f"{p}.m.{j}.cv1"), sd, f"{p}.m.{j}.cv2")
-        y = _q(_q(y) + z) if (shortcut and EMULATE.dtype is not None) else (y + z if shortcut else z)
+        y = _q(_q(y, f"{p}.m.{j}.cv1") + z, f"{p}.m.{j}.cv2") if (shortcut and EMULATE.dtype is not None) else (y + z if shortcut else z)
     return conv_bn_silu(torch.cat((y, conv_bn_silu(x, sd, p + ".cv2")), dim=1), sd, p + ".cv3")
 
 
@@ -280,7 +283,7 @@ def head(features: List[Tensor], sd: Dict[str, Tensor], p: str = "head", num_anc
     for i, f in enumerate(features):
         if TRACE.hook is not None:
             TRACE.hook(f"{p}.head.{i}", f, 1, 0)
-        y = F.conv2d(_q(f), _q(sd[f"{p}.head.{i}.weight"]), sd[f"{p}.head.{i}.bias"])
+        y = F.conv2d(_q(f, f"{p}.head.{i}"), _q(sd[f"{p}.head.{i}.weight"], f"{p}.head.{i}"), sd[f"{p}.head.{i}.bias"])
         n, _, h, w = y.shape
         outs.append(y.view(n, num_anchors, -1, h, w).permute(0, 1, 3, 4, 2).contiguous())
     return outs

@@ -309,6 +309,130 @@ def photo_golden(arch, seeds=range(0, 30)):
     raise RuntimeError(f"no usable seed for {arch} in {list(seeds)}")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: the reference's OWN 16-bit behaviour (VERDICT r3 "What's missing" 3).  The unmodified reference with `.half()` / `.bfloat16()`
+# parameters on the same inputs (yolov5.py:202-216; everything after the convolutions -- sigmoid, grid arithmetic, box conversion, NMS,
+# rescale -- then also runs in that type, as it does on the reference's own GPU path).  Its distance from its own fp32 detections is the
+# like-for-like yardstick for the HIP 16-bit path's tolerance: tests/test_golden_gpu.py asserts the HIP path is no further away.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _np_dets32(dets):
+    return [{k: (v.detach().float().cpu().numpy() if v.is_floating_point() else v.detach().cpu().numpy()) for k, v in d.items()} for d in dets]
+
+
+def _band(ref, got, thr):
+    """distance of a 16-bit evaluation from the fp32 detections: generous pairing (same label, IoU >= 0.5, |dscore| <= 0.1), then the worst pair"""
+    import bench
+    c = bench.direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)
+    return {"ref_dets": c["ref_dets"], "dets": c["hip_dets"], "paired": c["paired"], "min_iou": c["min_iou"], "iou_deficit": round(1.0 - c["min_iou"], 6), "max_dscore": c["max_dscore"],
+            "unpaired_ref": c["ref_dets"] - c["paired"], "unpaired_got": c["hip_dets"] - c["paired"]}
+
+
+def ref16_golden(kind, tag):
+    from oracle.make_synth_bn import photo_images
+    from yolort_amd.utils.synth import cond_images, conditioned_weights, spread_images
+    arch = {v: k for k, v in COND_TAGS.items()}[tag]
+    z = np.load(os.path.join(HERE, f"{kind}_{tag}.npz"))
+    meta = json.loads(str(z["meta"]))
+    S, thr, seed = meta["S"], meta["thr"], meta["seed"]
+    kw = dict(size_divisible=64) if arch.endswith("6_r60") else {}
+    variant = meta.get("variant", "photo" if kind == "photo" else "cond")
+    sd = conditioned_weights(YOLOv5(arch=arch, size=(S, S), **kw).state_dict(), arch, seed, variant=variant)
+    imgs = photo_images() if kind == "photo" else (cond_images(arch, seed) if variant == "cond" else spread_images(arch, seed))
+    ref = [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(len(meta["dets"]))]
+    out = {}
+    info = {"arch": arch, "seed": seed, "S": S, "thr": thr, "kind": kind, "what": "detections of the UNMODIFIED reference with .half() / .bfloat16() parameters and inputs (CPU)"}
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        with torch.no_grad():
+            got = _np_dets32(_reference_model(arch, S, thr, sd, dt).predict([im.to(dt) for im in imgs]))
+        info[name] = _band(ref, got, thr)
+        for i, g in enumerate(got):
+            for k in ("boxes", "scores", "labels"):
+                out[f"{name}_det{i}_{k}"] = g[k]
+        print(kind, tag, name, info[name], flush=True)
+    out["meta"] = json.dumps(info)
+    np.savez_compressed(os.path.join(HERE, f"ref16_{kind}_{tag}.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: the SPREAD workload (yolort_amd/utils/synth.py SPREAD_*): reference scores from the threshold up to ~0.9 and the score threshold
+# placed in a GAP of the reference's own score list, so that no detection is "near the cut" and a 16-bit evaluation has to reproduce every
+# single one (VERDICT r3 weak 2 / next 1c: the conditioned workload's scores all lie within a few hundredths of the threshold).
+# ---------------------------------------------------------------------------------------------------------------------------
+def spread_evaluate(arch, seed, thr_range=(0.25, 0.5), verbose=True):
+    import bench
+    from oracle import yolov5_oracle as O
+    from yolort_amd.utils.synth import COND_SIZE, conditioned_weights, spread_images
+    S = COND_SIZE[arch]
+    div = 64 if arch.endswith("6_r60") else 32
+    kw = dict(size_divisible=64) if div == 64 else {}
+    sd = conditioned_weights(YOLOv5(arch=arch, size=(S, S), **kw).state_dict(), arch, seed, variant="spread")
+    imgs = spread_images(arch, seed)
+    with torch.no_grad():
+        low = _np_dets(_reference_model(arch, S, 0.15, sd).predict(imgs))     # everything down to 0.15: the score list the threshold is placed in
+    pool = np.sort(np.concatenate([d["scores"] for d in low] + [np.asarray([0.15, 1.0], np.float32)]))
+    gaps = [(float(b - a), float(0.5 * (a + b))) for a, b in zip(pool[:-1], pool[1:]) if thr_range[0] <= 0.5 * (a + b) <= thr_range[1]]
+    if not gaps:
+        return {"arch": arch, "seed": seed, "dets": [len(d["scores"]) for d in low], "gap": 0.0}, None
+    gap, thr = max(gaps)
+    thr = round(thr, 4)
+    with torch.no_grad():
+        ref = _np_dets(_reference_model(arch, S, thr, sd).predict(imgs))
+        ref64 = _np_dets(_reference_model(arch, S, thr, sd, torch.float64).predict([im.double() for im in imgs]))
+        ora = _np_dets(O.yolov5_forward(imgs, sd, size=(S, S), size_divisible=div, score_thresh=thr))
+    for r in ref64:
+        r["boxes"], r["scores"] = r["boxes"].astype(np.float32), r["scores"].astype(np.float32)
+    c64 = bench.direct_checks(ref, ref64, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    cor = bench.direct_checks(ref, ora, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+    sgap = 1.0
+    for r in ref:
+        if len(r["scores"]) > 1:
+            sgap = min(sgap, float(np.min(-np.diff(r["scores"]))))
+    allsc = np.concatenate([r["scores"] for r in ref]) if sum(len(r["scores"]) for r in ref) else np.zeros(0, np.float32)
+    own = {}
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):   # the reference's own 16-bit evaluation of this workload
+        with torch.no_grad():
+            own[name] = _band(ref, _np_dets32(_reference_model(arch, S, thr, sd, dt).predict([im.to(dt) for im in imgs])), thr)
+    ev = {"arch": arch, "seed": seed, "S": S, "thr": thr, "variant": "spread", "dets": [len(r["scores"]) for r in ref], "thr_gap": gap,
+          "thr_margin": float(allsc.min() - thr) if len(allsc) else 0.0, "min_score_gap": sgap,
+          "score_range": [float(allsc.min()), float(allsc.max())] if len(allsc) else None,
+          "score_quartiles": [float(q) for q in np.quantile(allsc, [0.25, 0.5, 0.75])] if len(allsc) else None,
+          "fp64": c64, "oracle": cor, "reference_own_16bit": own}
+    if verbose:
+        print(json.dumps(ev), flush=True)
+    return ev, ref
+
+
+def spread_ok(ev):
+    n = len(ev["dets"])
+    if ev.get("gap", 1.0) == 0.0 or "fp64" not in ev:
+        return False
+    low = "bf16" if ev["arch"].endswith("_m_r60") else "fp16"
+    own = ev["reference_own_16bit"][low]
+    exact = all(ev[k]["unexplained"] == 0 and ev[k]["at_cut"] == 0 and ev[k]["images_labels_equal"] == n for k in ("fp64", "oracle"))
+    return (exact and sum(1 for d in ev["dets"] if d >= 3) >= 3 and 30 <= sum(ev["dets"]) <= 400 and ev["min_score_gap"] >= 1e-4
+            and ev["score_range"][1] >= 0.6 and own["unpaired_ref"] == 0 and own["unpaired_got"] == 0 and ev["thr_gap"] >= 6 * own["max_dscore"])
+
+
+def spread_golden(arch, seeds=range(0, 40)):
+    import subprocess
+    from yolort_amd.utils.synth import cond_bn_path
+    tag = COND_TAGS[arch]
+    for seed in seeds:
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", "--spread", f"--seed={seed}", arch], check=True, capture_output=True)
+        ev, ref = spread_evaluate(arch, seed)
+        if spread_ok(ev):
+            out = {"meta": json.dumps(ev)}
+            for i, r in enumerate(ref):
+                for k in ("boxes", "scores", "labels"):
+                    out[f"det{i}_{k}"] = r[k]
+            np.savez_compressed(os.path.join(HERE, f"spread_{tag}.npz"), **out)
+            print("spread golden", tag, "seed", seed, "thr", ev["thr"], "dets", ev["dets"], "reference's own 16-bit", ev["reference_own_16bit"])
+            ref16_golden("spread", tag)
+            return seed
+        os.remove(cond_bn_path(arch, seed, "spread"))
+    raise RuntimeError(f"no usable seed for {arch} in {list(seeds)}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "photo":
         if not os.path.exists(os.path.join(HERE, "bus.png")):
@@ -321,6 +445,15 @@ if __name__ == "__main__":
         seeds = [int(a) for a in sys.argv[2:] if a.isdigit()]   # usage: cond [arch ...] [seed ...]
         for a in [a for a in sys.argv[2:] if not a.isdigit()] or list(COND_TAGS):
             cond_golden(a, seeds or range(0, 40))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "spread":   # usage: spread [arch ...] [seed ...]
+        seeds = [int(a) for a in sys.argv[2:] if a.isdigit()]
+        for a in [a for a in sys.argv[2:] if not a.isdigit()] or ["yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60"]:
+            spread_golden(a, seeds or range(0, 40))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref16":   # usage: ref16 [kind:tag ...]
+        for a in sys.argv[2:] or ["cond:s", "cond:n", "cond:m", "photo:s"]:
+            ref16_golden(*a.split(":"))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cond-eval":
         cond_evaluate(sys.argv[2], int(sys.argv[3]))

@@ -117,6 +117,29 @@ def test_yolov5_accepts_a_prebuilt_model_and_rescales_after_a_post_process_hook(
         assert frac >= 0.95 and miou >= 0.97, (frac, miou)
 
 
+def test_post_process_hook_on_a_fixed_size_stream_runs_the_plan_from_the_planar_stem(dev):
+    """identity-size compute-dtype batches feed the stem from the planar images (ops 0 / 0+1 outside the recorded plan) and never fill the
+    NHWC4 canvas; the custom-hook branch must continue the plan from `first_op` instead of re-running op 0 on the empty canvas"""
+    from test_e2e_gpu import match_fraction
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.models.box_head import PostProcess
+
+    class MyPost(PostProcess):
+        pass
+
+    from yolort_amd.utils.synth import synth_images
+    hooked, _ = _yolo(dev, post_process=MyPost([8, 16, 32], 0.3, 0.45, 300))
+    plain, _ = _yolo(dev)
+    imgs = [synth_images(1, 320, 320, seed=90 + i)[0].to(dev).half() for i in range(2)]   # every image already is the canvas
+    mh, mp = YOLOv5(model=hooked, size=(320, 320)).eval(), YOLOv5(model=plain, size=(320, 320)).eval()
+    a, b = mh(imgs), mp(imgs)
+    assert not hooked.fused() and plain.fused()
+    for x, y in zip(a, b):
+        assert len(y["scores"]) > 5
+        frac, miou, _ = match_fraction(_np(y), _np(x), margin=0.02, thr=0.3, score_tol=0.02)
+        assert frac >= 0.95 and miou >= 0.97, (frac, miou)
+
+
 def test_operator_registry_hook(dev):
     """INTEGRATION.md section 2: `yolort_amd::nms` registered through torch.library dispatches to ymi_batched_nms for CUDA
     tensors and returns the oracle's kept indices bit for bit"""

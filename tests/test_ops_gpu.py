@@ -306,6 +306,39 @@ def test_conv3x3_res_kernel(dev, cin, cout, shape):
         _run_conv(dev, torch.bfloat16, cin=cin, cout=cout, k=3, s=1, p=1, tile=tile, seed=133 + cin + cout, **shape)
 
 
+@pytest.mark.parametrize("shape", [dict(n=2, h=40, w=40), dict(n=1, h=33, w=21), dict(n=3, h=16, w=16), dict(n=2, h=5, w=7), dict(n=12, h=160, w=160), dict(n=2, h=161, w=320)])
+def test_conv3x3_rw2_kernel(dev, shape):
+    """stride-2 register-weights 3x3 kernel, 64 -> 128 (conv3x3_rw2.hip, tile 134): ragged sizes against the 8 x 8 tiles (odd inputs), more tiles than resident
+    blocks (12 x 100 = 1200 tiles on 512 blocks: the persistent loop and its double-buffered parity-split patch), channel-slice views on both sides"""
+    _run_conv(dev, torch.float16, cin=64, cout=128, k=3, s=2, p=1, tile=134, x_cs_extra=32, y_cs_extra=64, seed=134, **shape)
+    _run_conv(dev, torch.bfloat16, cin=64, cout=128, k=3, s=2, p=1, tile=134, seed=135, **shape)
+
+
+def test_conv3x3_rw2_equals_the_implicit_gemm_bit_for_bit(dev):
+    """tile 134 accumulates in the implicit GEMM's K order and rounds through the same lean epilogue: equal to tiles 111 / 143 bit for bit (yolov5s body.3's shape
+    at a reduced batch and a ragged variant of it)"""
+    from yolort_amd import engine
+    for (n, h, w) in ((4, 160, 160), (3, 77, 91)):
+        g = torch.Generator().manual_seed(134 + h)
+        x = torch.randn(n, 64, h, w, generator=g)
+        wt = torch.randn(128, 64, 3, 3, generator=g) / np.sqrt(64 * 9)
+        bias = torch.randn(128, generator=g) * 0.1
+        outs = []
+        for tile in (134, 111, 143):
+            plan = engine.Plan(dev, torch.float16)
+            xv = plan.alloc(n, h, w, 64)
+            xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+            pc = engine.PackedConv(wt.half().float(), bias, None, torch.float16, dev)
+            ho, wo = engine.conv_out_hw(h, w, (3, 3), (2, 2), (1, 1))
+            yv = plan.alloc(n, ho, wo, 128, zero=True)
+            plan.conv(xv, pc, 2, 1, out=yv, tile=tile)
+            plan.run()
+            torch.cuda.synchronize()
+            outs.append(yv.as_tensor().clone())
+        for o in outs[1:]:
+            assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
+
+
 @pytest.mark.parametrize("residual", [False, True])
 @pytest.mark.parametrize("cout", [64, 32])
 def test_conv3x3_res_equals_the_implicit_gemm_bit_for_bit(dev, cout, residual):

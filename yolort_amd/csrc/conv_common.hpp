@@ -651,6 +651,8 @@ int conv3x3_c32_launch(const ConvArgs& a, int dtype, int out_dtype, int variant,
 int conv3x3_res_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // ... weights in registers, two independent 4-wave blocks per CU (conv3x3_rw.hip; opt-in)
 int conv3x3_rw_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
+// ... the same at stride 2, cin = 64 -> cout = 128 (conv3x3_rw2.hip, tile 134)
+int conv3x3_rw2_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // streaming 1x1 kernel for the memory-bound shallow-K layers (conv1x1_stream.hip): no LDS, weights in registers, variant = cout tiles per wave
 int conv1x1_stream_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // dedicated stem kernel (conv_stem.hip): 6x3 s(2,1) super-pixel form, input patch in LDS, weights in registers

@@ -192,8 +192,10 @@ class Plan:
         self.fp32 = dtype == torch.float32
         self.fuse_stem = False   # set_fuse_stem()
         self.res3x3 = {"0": 0, "1": 1}.get(os.environ.get("YOLORT_AMD_RES3X3", "2"), 2)   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
+        self.rw2 = os.environ.get("YOLORT_AMD_RW2", "1") != "0"   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2)
         if self.fp32:
             self.res3x3 = 0
+            self.rw2 = False
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
             self.chain_next = False
@@ -322,6 +324,8 @@ class Plan:
                 # resident-weights persistent 3x3 (conv3x3_res.hip): ahead of the table on every layer it fits (same-box A/B); its
                 # register-weights variant (conv3x3_rw.hip, bit-identical, 9-10 % faster: profiles/r03z14_rw3x3.txt) where that one fits; YOLORT_AMD_RES3X3=1: tile 132 only
                 d.tile = 133 if (self.res3x3 == 2 and d.cout == 64 and d.act == ACT_SILU and not d.chain_w) else 132
+            elif self.rw2 and self._rw2_ok(d):
+                d.tile = 134   # stride-2 register-weights 3x3 (conv3x3_rw2.hip): ahead of the table for Conv(64, 128, 3, 2); YOLORT_AMD_RW2=0 keeps the table's tile
             elif self.use_tile_table:
                 d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
         esz = 2
@@ -343,8 +347,17 @@ class Plan:
     @staticmethod
     def _res3x3_ok(d: ConvDesc) -> bool:
         chain_ok = (not d.chain_w) or (not d.chain_x2 and d.cout_pad == d.cout and d.cout in (32, 64))
+        # the launchers' 32-bit offset conditions (conv3x3_rw.hip / conv3x3_res.hip): a concat-slice output has the stride of the whole buffer
+        if (d.n * d.ho * d.wo + 1) * max(d.y_cstride, d.res_cstride) >= 2 ** 31 or d.n * d.h * d.w_in * d.x_cstride >= 2 ** 31:
+            return False
         return (d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin in (48, 64) and d.k_pad >= 9 * d.cin and d.cout <= 64
                 and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and chain_ok)
+
+    @staticmethod
+    def _rw2_ok(d: ConvDesc) -> bool:
+        return (d.kh == 3 and d.kw == 3 and d.sh == 2 and d.sw == 2 and d.ph == 1 and d.pw == 1 and d.cin == 64 and d.k_pad >= 576 and d.cout == 128 and d.cout_pad >= 128
+                and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and not d.chain_w and not d.res and d.act == ACT_SILU
+                and (d.n * d.ho * d.wo + 1) * d.y_cstride < 2 ** 31 and d.n * d.h * d.w_in * d.x_cstride < 2 ** 31)
 
     _TUNE_CACHE: Dict[Tuple, int] = {}
     _TUNE_TIMES: Dict[str, Dict[str, float]] = {}
@@ -395,6 +408,8 @@ class Plan:
         if d.kh == 3 and d.kw == 3 and d.sh == d.sw and d.sh in (1, 2) and d.ph == 1 and d.pw == 1 and d.cin == 32 and d.cout in (32, 64) and d.k_pad == 288 and \
                 d.out_dtype == d.dtype and d.y2_mode != 2 and chain is None:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
+        if self._rw2_ok(d):
+            cands = cands + [134]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip)
         if self._res3x3_ok(d):
             cands = cands + [132]   # ... cin = 48 / 64, stride 1, cross-tile patch prefetch (conv3x3_res.hip)
             if d.cout == 64 and d.act == ACT_SILU and not d.chain_w:

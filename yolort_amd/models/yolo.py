@@ -299,7 +299,8 @@ class YOLO(nn.Module):
         Conv stack on the current stream, post-process + result copy on the entry's side stream, so
         the next batch's convolutions overlap this batch's sort/NMS (few, long-running waves)."""
         if e.post is None:  # custom hooks: HIP backbone, then the injected modules on torch tensors
-            e.plan.run(graph=self.use_graph)
+            # from `first_op`: a planar-stem batch has already run ops 0 (and 1) from the images themselves and never filled the NHWC4 canvas (ADVICE r3)
+            e.plan.run(first_op, -1, graph=self.use_graph)
             feats = [view_to_nchw(v) for v in e.feats]
             head_outputs = self.head(feats)
             grids, shifts = self.anchor_generator(feats)
