@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(host cpus, 32))")
     ap.add_argument("--per-op", default="", help="write a per-op profile (json) to this path after the timed run")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region of --steps steps is run this many times back to back; value / ms_per_step are the MEDIAN repeat, all repeats are reported")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("YOLORT_AMD_GRAPH", "0")), help="replay the conv stack as a captured hipGraph")
     a = ap.parse_args()
     preset = CONFIGS[a.config]
@@ -82,9 +83,63 @@ def parse():
 # ----------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle = port of the reference's algorithm), stage split of SURVEY.md 8d
 # ----------------------------------------------------------------------------------------------------------------------
+def reference_cpu_baseline(args, sd, images_cpu, budget_s=14.0, cores=0):
+    """the UNMODIFIED reference `model.predict(batch)` (yolort/models/yolov5.py:202-216) timed on the host -- possible only where /root/reference
+    exists (the build container; tools/reference_cpu_baseline.py commits its figure under profiles/).  fp32 eager, torch.no_grad, 1 warm-up + timed passes; the
+    stage split comes from forward hooks on transform / backbone / head (post-process = the rest).  NMS runs through oracle/_tv_compat's stand-in for
+    torchvision.ops (torchvision is not installable here): reported separately inside `post_process`."""
+    from oracle.reference_loader import load_reference
+    load_reference()
+    from yolort.models import YOLOv5 as RefYOLOv5
+
+    host = os.cpu_count() or 1
+    cores = cores or args.cpu_threads or min(host, 32)
+    torch.set_num_threads(cores)
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    model = RefYOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, **kw)
+    model.load_state_dict({k: v.float() for k, v in sd.items()})
+    model.eval()
+    t = {"transform": 0.0, "backbone_pan": 0.0, "head": 0.0}
+    marks = {}
+
+    def pre(name):
+        return lambda m, i: marks.__setitem__(name, time.perf_counter())
+
+    def post(name):
+        return lambda m, i, o: t.__setitem__(name, t[name] + time.perf_counter() - marks[name])
+
+    for name, mod in (("transform", model.transform), ("backbone_pan", model.model.backbone), ("head", model.model.head)):
+        mod.register_forward_pre_hook(pre(name))
+        mod.register_forward_hook(post(name))
+    imgs = [im.float() for im in images_cpu]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        model.predict(imgs[:1])
+        warm = time.perf_counter() - t0
+        n_sample = int(max(1, min(len(imgs), budget_s / max(warm, 1e-3))))
+        for k in t:
+            t[k] = 0.0
+        passes, dt, n_det = 0, 0.0, 0
+        while passes < 3 and (passes == 0 or dt + dt / passes < 2 * budget_s):
+            t0 = time.perf_counter()
+            dets = model.predict(imgs[:n_sample])
+            dt += time.perf_counter() - t0
+            passes += 1
+            n_det = sum(len(d["scores"]) for d in dets)
+    stages = {k: round(v / (passes * n_sample) * 1e3, 2) for k, v in t.items()}
+    stages["post_process"] = round((dt - sum(t.values())) / (passes * n_sample) * 1e3, 2)
+    return {"value": round(passes * n_sample / dt, 3), "unit": "images/s", "cores": cores, "host_cpus": host, "kind": "reference",
+            "stages_ms_per_image": stages, "detections_per_image": round(n_det / n_sample, 1),
+            "sample": f"{passes} pass(es) of model.predict over {n_sample} image(s) of the workload, the UNMODIFIED reference (yolort.models.YOLOv5, fp32 eager, torch CPU, "
+                      f"{cores} threads); torchvision.ops.nms = oracle/_tv_compat stand-in (plain C)"}
+
+
 def cpu_baseline(args, sd, images_cpu, budget_s=14.0):
     from oracle import yolov5_oracle as O
+    from oracle.reference_loader import reference_available
 
+    if reference_available():   # build container: the reference itself is the baseline (kind "reference")
+        return reference_cpu_baseline(args, sd, images_cpu, budget_s)
     host = os.cpu_count() or 1
     cores = args.cpu_threads or min(host, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
@@ -131,11 +186,20 @@ def cpu_baseline(args, sd, images_cpu, budget_s=14.0):
         t0 = time.perf_counter()
         stages, n_c = staged(imgs[:n_sample])
         dt = time.perf_counter() - t0
-    return {"value": round(n_sample / dt, 3), "unit": "images/s", "cores": cores, "host_cpus": host, "kind": "port",
-            "stages_ms_per_image": {k: round(v / n_sample * 1e3, 2) for k, v in stages.items()},
-            "candidates_per_image": round(n_c / n_sample, 1),
-            "sample": f"one pass of {n_sample} image(s) of the workload through oracle/yolov5_oracle.py (fp32, torch CPU, {cores} threads), all stages; "
-                      "NMS is the oracle's plain-C restatement (single thread), not torchvision's kernel"}
+    out = {"value": round(n_sample / dt, 3), "unit": "images/s", "cores": cores, "host_cpus": host, "kind": "port",
+           "stages_ms_per_image": {k: round(v / n_sample * 1e3, 2) for k, v in stages.items()},
+           "candidates_per_image": round(n_c / n_sample, 1),
+           "sample": f"one pass of {n_sample} image(s) of the workload through oracle/yolov5_oracle.py (fp32, torch CPU, {cores} threads), all stages; "
+                     "NMS is the oracle's plain-C restatement (single thread), not torchvision's kernel"}
+    # /root/reference does not exist on this box: the UNMODIFIED reference's own timing was taken in the build container (tools/reference_cpu_baseline.py) and
+    # travels as a committed record -- another host, so it is quoted beside the live port figure, labelled, never merged into it
+    rpath = os.path.join(ROOT, "profiles", "reference_cpu_baseline.json")
+    if os.path.exists(rpath):
+        with open(rpath) as f:
+            rec = json.load(f).get(args.config)
+        if rec is not None:
+            out["reference_on_build_container"] = rec
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -206,37 +270,86 @@ def conditioned_parity(args, dev):
     from yolort_amd.models import YOLOv5
     from yolort_amd.utils.synth import cond_images, conditioned_weights
 
+    from yolort_amd.utils.synth import spread_images
+
     tag = {"yolov5_darknet_pan_n_r60": "n", "yolov5_darknet_pan_s_r60": "s", "yolov5_darknet_pan_m_r60": "m", "yolov5_darknet_pan_l6_r60": "l6"}.get(args.arch)
-    path = os.path.join(ROOT, "tests", "golden", f"cond_{tag}.npz")
-    if tag is None or not os.path.exists(path):
+    gold = os.path.join(ROOT, "tests", "golden")
+    if tag is None or not os.path.exists(os.path.join(gold, f"cond_{tag}.npz")):
         return None
-    z = np.load(path)
-    meta = json.loads(str(z["meta"]))
-    ref = [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(len(meta["dets"]))]
     tol = {"s": (0.98, 1e-2), "l6": (0.98, 1e-2), "n": (0.95, 3e-2), "m": (0.90, 6e-2)}[tag]
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
-    S, thr = meta["S"], meta["thr"]
-    imgs = cond_images(args.arch, meta["seed"])
     dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    out = {"workload": f"conditioned {args.arch} (BN gamma 0.3-0.6, head gain 1.0, tuned objectness bias; seed {meta['seed']}), 4 seeded images of mixed shapes at "
-                       f"{S}, thr {thr}; ground truth = detections of the UNMODIFIED reference (tests/golden/cond_{tag}.npz)",
-           "reference_self_reproducibility_fp64": meta["fp64"]}
-    for name, dtype in (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16)):
-        m = YOLOv5(arch=args.arch, size=(S, S), score_thresh=thr, nms_thresh=0.45, detections_per_img=300, **kw)
-        m.load_state_dict(conditioned_weights(m.state_dict(), args.arch, meta["seed"]))
-        m = m.to(dev).eval()
-        m = m.set_compute_dtype(torch.float32) if dtype == torch.float32 else m.to(dtype)
-        got = [_npd(d) for d in m.forward([im.to(dev) if dtype == torch.float32 else im.to(dev).to(dtype) for im in imgs])]
-        if dtype == torch.float32:
-            out[name] = direct_checks(ref, got, thr, score_eps=1e-4, iou_min=1 - 1e-3)
-        else:
-            c = direct_checks(ref, got, thr, score_eps=tol[1], iou_min=tol[0])
-            c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": tol[1]}
-            c["map_vs_ref_50_95"] = coco_ap(ref, got)
-            out[name] = c
-        del m
+    out = {}
+    # two reference-made goldens per architecture: `cond` (round 3: every score within a few hundredths of the threshold) and `spread` (round 4: scores from the threshold
+    # up to ~0.9, the threshold in a gap of the reference's score list -- nothing can be excused as "at the cut").  Each also carries the REFERENCE'S OWN 16-bit run
+    # (tests/golden/ref16_*.npz: the unmodified reference with .half() / .bfloat16()), the like-for-like yardstick for the production path's distance from fp32.
+    for kind, images_of in (("cond", cond_images), ("spread", spread_images)):
+        path = os.path.join(gold, f"{kind}_{tag}.npz")
+        if not os.path.exists(path):
+            continue
+        z = np.load(path)
+        meta = json.loads(str(z["meta"]))
+        ref = [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(len(meta["dets"]))]
+        S, thr = meta["S"], meta["thr"]
+        imgs = images_of(args.arch, meta["seed"])
+        blk = {"workload": f"{kind} {args.arch}, seed {meta['seed']}, 4 seeded images of mixed shapes at {S}, thr {thr}; ground truth = detections of the UNMODIFIED reference "
+                           f"(tests/golden/{kind}_{tag}.npz)", "reference_self_reproducibility_fp64": meta["fp64"]}
+        if kind == "spread":
+            blk["score_range"], blk["threshold_gap"] = meta["score_range"], meta["thr_gap"]
+        for name, dtype in (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16)):
+            m = YOLOv5(arch=args.arch, size=(S, S), score_thresh=thr, nms_thresh=0.45, detections_per_img=300, **kw)
+            m.load_state_dict(conditioned_weights(m.state_dict(), args.arch, meta["seed"], variant=kind))
+            m = m.to(dev).eval()
+            m = m.set_compute_dtype(torch.float32) if dtype == torch.float32 else m.to(dtype)
+            got = [_npd(d) for d in m.forward([im.to(dev) if dtype == torch.float32 else im.to(dev).to(dtype) for im in imgs])]
+            if dtype == torch.float32:
+                blk[name] = direct_checks(ref, got, thr, score_eps=1e-4, iou_min=1 - 1e-3)
+            else:
+                c = direct_checks(ref, got, thr, score_eps=tol[1], iou_min=tol[0])
+                c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": tol[1]}
+                c["map_vs_ref_50_95"] = coco_ap(ref, got)
+                g = direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)   # the generous pairing the reference's own 16-bit band was measured with
+                c["distance_from_fp32_reference"] = {"paired": g["paired"], "of": g["ref_dets"], "iou_deficit": round(1.0 - g["min_iou"], 6), "max_dscore": g["max_dscore"]}
+                r16 = os.path.join(gold, f"ref16_{kind}_{tag}.npz")
+                if os.path.exists(r16):
+                    own = json.loads(str(np.load(r16)["meta"]))[args.dtype]
+                    c["reference_own_" + args.dtype] = {"paired": own["paired"], "of": own["ref_dets"], "iou_deficit": own["iou_deficit"], "max_dscore": own["max_dscore"],
+                                                        "what": "the UNMODIFIED reference with ." + ("half()" if args.dtype == "fp16" else "bfloat16()") + " on the same inputs vs its own fp32 detections"}
+                    c["iou_deficit_vs_reference_own"] = round((1.0 - g["min_iou"]) / max(own["iou_deficit"], 1e-9), 3)
+                    c["dscore_vs_reference_own"] = round(g["max_dscore"] / max(own["max_dscore"], 1e-12), 3)
+                blk[name] = c
+            del m
+        out[kind] = blk
     torch.cuda.empty_cache()
+    if "cond" in out:   # the round-3 layout of the block stays readable: the conditioned workload's entries at the top level
+        for k, v in out["cond"].items():
+            out.setdefault(k, v)
     return out
+
+
+def fp32_mode_throughput(args, dev, images_cpu, steps=6):
+    """throughput of the mode that meets the north-star box tolerance (fp32 storage + exact fp32 MFMA arithmetic, csrc/conv_f32.hip) on the benchmark workload itself:
+    what the tolerance costs (`only the un-benchmarked fp32 parity mode meets 1 - 1e-3`)"""
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_weights
+
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    m = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300, **kw)
+    m.load_state_dict(synth_weights(m.state_dict(), args.arch, seed=0, head_gain=args.head_gain))
+    m = m.to(dev).eval().set_compute_dtype(torch.float32)
+    imgs = [im.to(dev) for im in images_cpu]
+    for _ in range(2):
+        m.forward_async(imgs).result()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pend = [m.forward_async(imgs) for _ in range(steps)]
+    for p in pend:
+        p.result()
+    torch.cuda.synchronize()
+    ips = len(imgs) * steps / (time.perf_counter() - t0)
+    del m
+    torch.cuda.empty_cache()
+    return round(ips, 1)
 
 
 def parity_sample(args, model, images_gpu, images_cpu, sd, k):
@@ -380,20 +493,31 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.barrier()
-    torch.cuda.synchronize()
-    host["enqueue"] = 0.0
-    t0 = time.perf_counter()
-    dets = run_steps(args.steps)
-    host_enqueue_ms = host["enqueue"] / args.steps * 1e3
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; the maximum over ranks"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        host["enqueue"] = 0.0
+        t0 = time.perf_counter()
+        d = run_steps(args.steps)
+        enq = host["enqueue"] / args.steps * 1e3
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, enq, d
+
+    # the region is run `repeats` times back to back (a 20-step region is 26 ms: one sample says little on a pool whose boxes and clocks wander by +-5 %);
+    # value / ms_per_step / host_enqueue are the MEDIAN repeat's, every repeat is in the line
+    reps = [timed_region() for _ in range(max(1, args.repeats))]
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    elapsed, host_enqueue_ms, dets = reps[order[len(order) // 2]]
+    rep_ips = [round(world * args.batch * args.steps / r[0], 1) for r in reps]
     region = {k: _elapsed(v) for k, v in yolo.bracket.items()}
     # the same launches with ONE batch in flight (no overlap with other batches' kernels), right after the timed region:
     # per-launch durations as rocprofv3 sees them.  The in-region brackets above include the time a batch's kernels share
@@ -410,8 +534,13 @@ def main():
     except Exception:
         probe = None
     for _ in range(n_excl):
-        collect(model.forward_async(images_gpu))
+        last = model.forward_async(images_gpu)
+        collect(last)
         torch.cuda.synchronize()
+    # candidate counts of the TIMED workload, read from the status words of its own last batch before anything else runs (status[4]: every (anchor, class) pair above
+    # the threshold; status[0]: the records that were sorted after the score-prefix selection -- round 3 reported the latter, of whatever batch ran last, as "candidates")
+    st_words = last.entry.post.status.tolist() if last.entry.post is not None else [0] * 8
+    n_cand_raw, n_cand_sorted = int(st_words[4]), int(st_words[0])
     if probe is not None:
         torch.cuda.synchronize()
         cyc, ticks = [int(v) for v in probe.tolist()]
@@ -435,6 +564,19 @@ def main():
             torch.cuda.synchronize()
         ex2 = {k: _elapsed(v) for k, v in yolo.bracket.items()}
         yolo.bracket = None
+        # ... and its throughput in the regime `value` is measured in (batches in flight, letterbox launch included)
+        dyn_steps = max(10, args.steps // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pend = []
+        for _ in range(dyn_steps):
+            pend.append(model.forward_async(dyn_gpu))
+            if len(pend) > depth:
+                collect(pend.pop(0))
+        while pend:
+            collect(pend.pop(0))
+        torch.cuda.synchronize()
+        dyn_ips = args.batch * dyn_steps / (time.perf_counter() - t0)
         in_b = sum(im.numel() * im.element_size() for im in dyn_gpu)
         hb, wb = e.x.h, e.x.w   # portrait and landscape shapes in one batch: the canvas is the full size x size square, the fixed stream's own plan
         if ex2["pre"]:
@@ -442,7 +584,7 @@ def main():
             lbb = in_b + args.batch * hb * wb * 4 * 2
             dyn = {"workload": f"{args.config}dyn: the same model, bs {args.batch}, the 8 cycled image sizes of SURVEY 8d scaled by {sc:g} -> canvas {hb}x{wb}",
                    "letterbox_tile2_kernel": {"ms": round(ms, 4), "algorithmic_bytes": lbb, "achieved_GBps": round(lbb / ms / 1e6, 1), "frac_of_hbm_peak": round(lbb / (ms * 1e-3) / HBM_PEAK, 4)},
-                   "conv_ms_per_step_serial": round(mean(ex2["conv"]), 4)}
+                   "conv_ms_per_step_serial": round(mean(ex2["conv"]), 4), "images_per_s": round(dyn_ips, 1), "steps": dyn_steps}
 
     if rank == 0:
         conv_meta = [m for m in e.plan.meta if m["kind"] == "conv"]
@@ -465,7 +607,7 @@ def main():
             traffic = {"bytes_per_launch": round((tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6 / max(n_conv, 1)),
                        "bytes_per_step": round((tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6), "source": tj["source"], "correction": tj["correction"]}
         # HBM-bound edge kernels: algorithmic bytes / exclusive event time
-        n_cand = int(e.post.status[0].item())
+        n_cand = n_cand_raw
         in_bytes = sum(im.numel() * im.element_size() for im in images_gpu)
         lb_bytes = in_bytes + args.batch * e.x.h * e.x.w * 4 * 2
         kernels = {}
@@ -475,9 +617,9 @@ def main():
                                            "frac_of_hbm_peak": round(lb_bytes / (ms * 1e-3) / HBM_PEAK, 4), "launches_per_step": (args.batch + 63) // 64}
         if excl["post"]:
             ms = mean(excl["post"])
-            pbytes = n_cand * 12 * 4 + args.batch * e.post.total_anchors * 16   # records read by select / sort (twice) / NMS + boxes of every anchor
+            pbytes = n_cand * 12 + n_cand_sorted * 12 * 3 + args.batch * e.post.total_anchors * 16   # every record read once by the selection, the selected ones by rank / scatter / NMS + the boxes of every anchor
             kernels["postprocess (select_prefix + sort_image + nms_segments + gather_topk)"] = {
-                "ms": round(ms, 4), "candidates_per_step": n_cand, "algorithmic_bytes": pbytes, "achieved_GBps": round(pbytes / ms / 1e6, 1),
+                "ms": round(ms, 4), "candidates_per_step": n_cand, "records_sorted_per_step": n_cand_sorted, "algorithmic_bytes": pbytes, "achieved_GBps": round(pbytes / ms / 1e6, 1),
                 "frac_of_hbm_peak": round(pbytes / (ms * 1e-3) / HBM_PEAK, 5), "note": "latency-bound (per-image sort + greedy NMS), not bandwidth-bound"}
         workload = (f"{args.arch} {args.dtype} bs={args.batch}/GPU {args.size}x{args.size} "
                     + ("dynamic-shape letterbox (8 cycled sizes, SURVEY 8d) -> " if args.shapes == "dynamic" else "fixed-size stream (letterbox = identity: the stem reads the planar images) -> ")
@@ -490,6 +632,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 4),
+            "repeats": {"n": len(reps), "images_per_s": rep_ips, "median": round(ips, 2), "min": min(rep_ips), "max": max(rep_ips),
+                        "spread_pct": round(100.0 * (max(rep_ips) - min(rep_ips)) / max(ips, 1e-9), 2),
+                        "note": "the timed region (exactly `steps` steps, barrier + synchronize on both sides) run back to back; value / ms_per_step are the median repeat"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -499,7 +644,7 @@ def main():
                        "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
                        "gather_second_rounds_rank0": second_rounds[0], "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
                        "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
-                       "candidates_per_step_rank0": n_cand, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
+                       "candidates_per_step_rank0": n_cand, "records_sorted_per_step_rank0": n_cand_sorted, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
             # `frac` is the PER-LAYER fraction SURVEY.md 8d prescribes (sum over the conv launches of max(flops / MFMA peak, bytes / HBM peak),
             # divided by the measured conv time) in the SERIAL regime; achieved / peak / frac_hbm are the plain bytes-over-time view of the
             # same measurement.  The two regimes are spelled out: `serial` = one batch in flight (what rocprofv3's kernel durations add up
@@ -529,13 +674,20 @@ def main():
         }
         if dyn is not None:
             out["roofline"]["other_kernels"]["dynamic_shape_stream"] = dyn
+            # secondary value: the same model on the dynamic-shape stream -- every batch runs the letterbox launch (the headline stream is letterbox-free: its
+            # images already are the canvas and the stem reads them directly)
+            out["secondary"] = {f"{args.config}dyn_images_per_s": dyn["images_per_s"], "workload": dyn["workload"]}
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.float().cpu() for k, v in model.state_dict().items()}
             k_par = 4 if args.size <= 640 else 2
             cp = conditioned_parity(args, dev)
             out["parity"] = {} if cp is None else dict(cp)
-            if cp is not None:   # the headline of the block: the fp32 parity mode's direct checks against the reference's detections
-                out["parity"]["unexplained"] = cp["fp32_parity_mode"]["unexplained"] + cp[f"production_{args.dtype}"]["unexplained"]
+            if cp is not None:   # the headline of the block: nothing unexplained on any golden, in either mode
+                out["parity"]["unexplained"] = sum(cp[k][m_]["unexplained"] for k in ("cond", "spread") if k in cp for m_ in ("fp32_parity_mode", f"production_{args.dtype}"))
+                out["parity"]["north_star_tolerance"] = ("boxes within 1e-3 IoU: met by the fp32 parity mode on every golden; the production 16-bit path is reported against the "
+                                                         "reference's OWN 16-bit run (reference_own_*): a per-layer budget (profiles/r04_error_budget_*.csv) shows no 16-bit-storage "
+                                                         "path can meet 1e-3 -- the roundings of ~60 layers add in quadrature and the first 30 would have to stay in fp32")
+                out["parity"]["fp32_parity_mode_images_per_s"] = fp32_mode_throughput(args, dev, images_cpu)
             out["parity"]["benchmark_workload"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
         if args.per_op and world == 1:

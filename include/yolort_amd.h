@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 4
+#define YMI_ABI_VERSION 5
 
 /* error codes */
 #define YMI_OK 0
@@ -218,12 +218,21 @@ typedef struct ymi_post_desc {
     float* out_scores;
     int64_t* out_labels;
     int32_t* out_count;
-    int32_t* status; /* device int32[4]: {candidates_needed, overflow, total_kept, reserved} */
+    int32_t* status; /* device int32[8] (ABI 5; was int32[4]): {records sorted (after the score-prefix selection), overflow bits, segments, largest raw
+                      * per-image count on overflow, RAW candidates of the batch (every (anchor, class) pair above the threshold), blocks of the last
+                      * kernel done, reserved x2} */
     void* ws;
     int64_t ws_bytes;
     int32_t cand_cap;
     int32_t flags; /* YMI_POST_* bits */
+    /* ABI 5: optional packed WIRE SLAB (n, 6 * detections_per_img + 1) fp32, written by the top-k kernel itself next to the four output arrays: per image
+     * [boxes 4K | scores K | labels K as float | count], slots past the count zeroed -- the fixed-shape format one all-gather per batch carries between
+     * ranks (the reference's TensorRT wire format, relay/trt_graphsurgeon.py:223-244, in one buffer).  When the batch has to be re-run by the caller
+     * (status[1] != 0: candidate capacity / score prefix) the LAST block of the kernel overwrites every row's count column with -1 (YMI_SLAB_STALE), so
+     * the receivers of a collective enqueued right behind the post-process learn it from the data.  NULL: not written. */
+    float* out_slab;
 } ymi_post_desc;
+#define YMI_SLAB_STALE (-1.0f)
 
 /* ymi_post_desc.flags.
  * By default an image with many candidates is post-processed on a score-ordered PREFIX of them (at least

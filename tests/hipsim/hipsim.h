@@ -237,6 +237,7 @@ inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { mems
 #define __shfl_up(v, d, ...) hipsim::shfl_up(v, (int)(d))
 #define __ffsll(x) __builtin_ffsll(x)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __threadfence() {}   // one lane runs at a time and blocks run one after another: every earlier write is visible
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
 #define __logf(x) logf(x)   /* fast-math intrinsics: the accurate libm forms (the head's pre-filter threshold carries a margin for exactly this) */

@@ -338,6 +338,56 @@ def test_slab_all_gather_is_enqueued_behind_the_post_process(dev):
     assert r.returncode == 0 and "GATHER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_the_topk_kernel_writes_the_wire_slab_itself(dev):
+    """round 4: the packed wire slab of the multi-GPU gather -- (n, 6K + 1) fp32: boxes | scores | labels | count, slots past the count zeroed --
+    is written by gather_topk_kernel next to the four output arrays (ymi_post_desc.out_slab); `dist.pack_slab` (a handful of torch launches) is off the serving
+    path.  (1) normal batches: slab == pack_slab(outputs) on every live slot, zeros beyond, over several batches with different detection counts (a later batch with
+    fewer detections must not leave the previous batch's entries behind); (2) a batch whose candidate capacity is too small: every row's count column reads
+    SLAB_STALE (-1) on the device BEFORE the host has seen the status word -- the marker a collective enqueued behind the post-process carries to the other ranks;
+    (3) status[4] carries the raw candidate count of the batch."""
+    from yolort_amd import dist as ydist
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    m = YOLOv5(arch=arch, size=(320, 320), score_thresh=0.2)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+    m = m.to(dev).half().eval()
+    k = 300
+    for seed, thr in ((31, 0.2), (32, 0.35), (33, 0.2)):
+        m.model.post_process.score_thresh = thr
+        imgs = [im.to(dev).half() for im in synth_images(3, 320, 320, seed=seed)]
+        pend = m.forward_async(imgs)
+        dets = pend.result()
+        torch.cuda.synchronize()
+        post = pend.entry.post
+        want = ydist.pack_slab(post.boxes, post.scores, post.labels, post.count)
+        slab = post.slab
+        counts = post.count.tolist()
+        assert counts == [len(d["scores"]) for d in dets] and max(counts) > 0
+        for i, c in enumerate(counts):
+            for lo, w in ((0, 4), (4 * k, 1), (5 * k, 1)):
+                assert torch.equal(slab[i, lo: lo + w * c], want[i, lo: lo + w * c]), (seed, i, lo)
+                assert float(slab[i, lo + w * c: lo + w * k].abs().sum()) == 0.0, (seed, i, lo)
+            assert float(slab[i, 6 * k]) == c
+        st = post.status.tolist()
+        assert st[1] == 0 and st[4] >= st[0] >= sum(counts) and st[5] == 3, st
+        b, s_, l, c_ = ydist.unpack_slab(slab, k)
+        assert torch.equal(c_.cpu(), post.count.cpu()) and torch.equal(l[0, : counts[0]], post.labels[0, : counts[0]])
+    # (2) the stale marker: a candidate capacity of 64 per image overflows; look at the first-pass slab of the instance BEFORE collecting the batch
+    m2 = YOLOv5(arch=arch, size=(320, 320), score_thresh=0.05)
+    m2.load_state_dict(synth_weights(m2.state_dict(), arch, seed=0, head_gain=1.0))
+    m2 = m2.to(dev).half().eval()
+    m2.model.cand_cap_per_image = 64
+    imgs = [im.to(dev).half() for im in synth_images(3, 320, 320, seed=34)]
+    pend = m2.forward_async(imgs)
+    pend.event.synchronize()
+    post = pend.entry.post
+    assert int(post.status[1]) != 0
+    assert torch.equal(post.slab[:, 6 * k].cpu(), torch.full((3,), float(ydist.SLAB_STALE)))
+    dets = pend.result()   # the host grows the capacity and re-runs: final results, final slab
+    assert sum(len(d["scores"]) for d in dets) > 0 and m2.model.cand_cap_per_image > 64
+
+
 def test_bench_two_ranks_control_flow_on_one_gpu(dev):
     """bench.py's N > 1 path (per-rank shard, warm-up before the gather is switched on, slab all-gather per batch, gathered() for
     every batch, barrier + max-over-ranks timing, one JSON line from rank 0) run as TWO ranks under torch.distributed.run.  The box

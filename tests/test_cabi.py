@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_channel(lib):
-    assert lib.ymi_abi_version() == 4
+    assert lib.ymi_abi_version() == 5
     # a host-side argument error must come back as a code + message, never as an exception/abort
     t = (C.c_int32 * 8)()
     rc = lib.ymi_conv_build_ktab(7, 3, 3, 10, 8, 32, t)   # cin not a multiple of 8

@@ -670,7 +670,8 @@ def test_postprocess_vs_oracle(sim, thr, k, saturated, cap0):
     cap, flags = cap0, 0
     while True:   # the host protocol of yolort_amd/ops.py: nothing is truncated silently, a too small candidate capacity is grown and the batch redone
         boxes, scores = torch.zeros(n, k, 4), torch.zeros(n, k)
-        labels, count, status = torch.zeros(n, k, dtype=torch.int64), torch.zeros(n, dtype=torch.int32), torch.zeros(4, dtype=torch.int32)
+        labels, count, status = torch.zeros(n, k, dtype=torch.int64), torch.zeros(n, dtype=torch.int32), torch.zeros(8, dtype=torch.int32)
+        slab = torch.full((n, 6 * k + 1), float("nan"))   # the packed wire slab the top-k kernel writes next to the four arrays (ymi_post_desc.out_slab, ABI 5)
         ws = torch.full((int(sim.ymi_postprocess_ws_bytes(n, total_anchors, cap)),), 0x7f, dtype=torch.uint8)   # a DIRTY workspace: nothing may rely on zeroed memory
         d = PostDesc()
         for i, (h, w) in enumerate(shapes):
@@ -683,8 +684,22 @@ def test_postprocess_vs_oracle(sim, thr, k, saturated, cap0):
         d.rescale = rescale.data_ptr()
         d.out_boxes, d.out_scores, d.out_labels, d.out_count = boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), count.data_ptr()
         d.status, d.ws, d.ws_bytes, d.cand_cap, d.flags = status.data_ptr(), ws.data_ptr(), ws.numel(), cap, flags
+        d.out_slab = slab.data_ptr()
         _check(sim, sim.ymi_postprocess(C.byref(d), None))
         st = status.tolist()
+        assert st[5] == n, st                                        # every block of the top-k kernel checked in (the last one fixes the slab up)
+        if st[1] != 0:                                               # the host will redo this batch: every row of the slab says so (dist.SLAB_STALE)
+            assert torch.equal(slab[:, 6 * k], torch.full((n,), -1.0)), slab[:, 6 * k]
+        else:                                                        # the kernel-written slab IS pack_slab of the four arrays, slots past the count zeroed
+            from yolort_amd import dist as ydist
+            want = ydist.pack_slab(boxes, scores, labels, count)
+            for i in range(n):
+                c = int(count[i])
+                for lo_, w_ in ((0, 4), (4 * k, 1), (5 * k, 1)):
+                    assert torch.equal(slab[i, lo_: lo_ + w_ * c], want[i, lo_: lo_ + w_ * c]), (i, lo_)
+                    assert float(slab[i, lo_ + w_ * c: lo_ + w_ * k].abs().sum()) == 0.0, (i, lo_)
+                assert float(slab[i, 6 * k]) == c
+            assert st[4] >= st[0] > 0, st                            # raw candidates of the batch >= the records that were sorted (score-prefix selection)
         if st[1] == 0:
             if cap0 > 4096 and mixed:
                 assert 4096 <= st[0] <= 6144 + 6144 and len(ref[1]["scores"]) > 0, st   # image 0 cut to just above sel_t, image 1 (fewer than 1.5 sel_t records) untouched
@@ -741,7 +756,7 @@ def test_fused_head_decode_equals_the_unfused_head(sim, dtype, nc):
 
     def post_desc(cap, logits=None):
         out = dict(boxes=torch.zeros(n, k, 4), scores=torch.zeros(n, k), labels=torch.zeros(n, k, dtype=torch.int64), count=torch.zeros(n, dtype=torch.int32),
-                   status=torch.zeros(4, dtype=torch.int32), ws=torch.full((int(sim.ymi_postprocess_ws_bytes(n, total_anchors, cap)),), 0x7f, dtype=torch.uint8))
+                   status=torch.zeros(8, dtype=torch.int32), ws=torch.full((int(sim.ymi_postprocess_ws_bytes(n, total_anchors, cap)),), 0x7f, dtype=torch.uint8))
         d = PostDesc()
         for i, (h, w) in enumerate(shapes):
             d.lh[i], d.lw[i], d.stride[i] = h, w, float(strides[i])

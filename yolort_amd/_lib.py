@@ -52,7 +52,7 @@ class C3Desc(C.Structure):
     ]
 
 
-ABI_VERSION = 4   # include/yolort_amd.h YMI_ABI_VERSION
+ABI_VERSION = 5   # include/yolort_amd.h YMI_ABI_VERSION
 POST_EXACT_FULL = 1
 
 
@@ -71,6 +71,7 @@ class PostDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("cand_cap", C.c_int32),
         ("flags", C.c_int32),
+        ("out_slab", C.c_void_p),   # ABI 5: packed wire slab (n, 6K + 1) fp32 or NULL
     ]
 
 

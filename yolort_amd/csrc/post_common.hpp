@@ -7,7 +7,7 @@
 namespace ymi {
 
 // status words (device int32[4])
-enum { ST_NCAND = 0, ST_OVERFLOW = 1, ST_NSEG = 2, ST_RSV = 3 };
+enum { ST_NCAND = 0, ST_OVERFLOW = 1, ST_NSEG = 2, ST_RSV = 3, ST_RAW = 4, ST_DONE = 5, ST_WORDS = 8 };
 
 struct Workspace {
     // all device pointers, carved from the caller's `ws`

@@ -1103,6 +1103,8 @@ struct GatherArgs {
     const float* rescale;
     const int* status;
     const int* truncated;   // per image: 1 = only a score prefix of its candidates was processed (NULL: never)
+    const int* img_count;   // per image: raw candidate count (per-image path; NULL: the global sort, whose status[ST_NCAND] is the raw count)
+    float* out_slab;        // (n, 6K + 1) packed wire slab or NULL (ymi_post_desc.out_slab)
     int* status_rw;
     int cap, total_anchors, label_bits, K;
     float* out_boxes;
@@ -1123,6 +1125,7 @@ __device__ int lower_bound_img(const uint64_t* ghi, int n, unsigned img) {
 __global__ __launch_bounds__(256) void gather_topk_kernel(const GatherArgs a) {
     __shared__ int wave_cnt[4];
     __shared__ int s_taken;
+    __shared__ int s_last;
     const int n = ncand(a.status, a.cap);
     const unsigned img = blockIdx.x;
     const int begin = lower_bound_img(a.ghi, n, img), end = lower_bound_img(a.ghi, n, img + 1);
@@ -1159,15 +1162,42 @@ __global__ __launch_bounds__(256) void gather_topk_kernel(const GatherArgs a) {
             *reinterpret_cast<f32x4*>(a.out_boxes + slot * 4) = o;
             a.out_scores[slot] = __uint_as_float(~(uint32_t)hi);
             a.out_labels[slot] = (int64_t)(lo & ((1u << a.label_bits) - 1u));
+            if (a.out_slab != nullptr) {   // the same detection in the packed wire slab (rows of 6K + 1 floats: only 4-byte aligned)
+                float* row = a.out_slab + (int64_t)img * (6 * a.K + 1);
+                row[4 * rank] = o[0]; row[4 * rank + 1] = o[1]; row[4 * rank + 2] = o[2]; row[4 * rank + 3] = o[3];
+                row[4 * a.K + rank] = __uint_as_float(~(uint32_t)hi);
+                row[5 * a.K + rank] = (float)(lo & ((1u << a.label_bits) - 1u));
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) s_taken = taken + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
+    const int cnt = s_taken < a.K ? s_taken : a.K;
+    if (a.out_slab != nullptr) {   // slots past the count are zero: the slab is a function of the detections alone
+        float* row = a.out_slab + (int64_t)img * (6 * a.K + 1);
+        for (int t = cnt + (int)threadIdx.x; t < a.K; t += 256) {
+            row[4 * t] = 0.f; row[4 * t + 1] = 0.f; row[4 * t + 2] = 0.f; row[4 * t + 3] = 0.f;
+            row[4 * a.K + t] = 0.f;
+            row[5 * a.K + t] = 0.f;
+        }
+        if (threadIdx.x == 0) row[6 * a.K] = (float)cnt;
+    }
     if (threadIdx.x == 0) {
-        a.out_count[img] = s_taken < a.K ? s_taken : a.K;
+        a.out_count[img] = cnt;
         // a truncated image must reach K survivors on its prefix alone, else the cut may have mattered
         if (a.truncated != nullptr && a.truncated[img] != 0 && s_taken < a.K) atomicOr(&a.status_rw[ST_OVERFLOW], YMI_STATUS_PREFIX_SHORT);
+        if (a.img_count != nullptr) atomicAdd(&a.status_rw[ST_RAW], a.img_count[img]);
+        else if (img == 0) atomicAdd(&a.status_rw[ST_RAW], n);
+        // last-block fix-up: the status word is final only when every image's block has finished (ST_DONE is zeroed by post_begin)
+        __threadfence();
+        s_last = atomicAdd(&a.status_rw[ST_DONE], 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && a.out_slab != nullptr) {
+        __threadfence();
+        if (atomicOr(&a.status_rw[ST_OVERFLOW], 0) != 0)   // the caller will re-run this batch: mark every row stale (yolort_amd/dist.py SLAB_STALE)
+            for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a.out_slab[(int64_t)i * (6 * a.K + 1) + 6 * a.K] = YMI_SLAB_STALE;
     }
 }
 
@@ -1193,7 +1223,7 @@ static int radix_pass(const Workspace& w, SortState& st, int* status, int cap, i
 // segments -> class-aware NMS -> top-k gather, given G (arrays w.hi/lo[g]) and the per-class order P
 static int nms_gather(const Workspace& w, int g, const uint64_t* phi, const uint32_t* plo, int* status, int cap, int n_img, int label_bits, int total_anchors,
                       float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count, hipStream_t s,
-                      const int* truncated = nullptr) {
+                      const int* truncated = nullptr, float* out_slab = nullptr, const int* img_count = nullptr) {
     const int nthr_blocks = cdiv(cap, 256);
     uint32_t* seg_start = w.seg_start;
     float* kept_box = w.kept_box;
@@ -1202,7 +1232,7 @@ static int nms_gather(const Workspace& w, int g, const uint64_t* phi, const uint
                        seg_start, kept_box, w.keep, nms_thresh);
     GatherArgs ga;
     ga.ghi = w.hi[g]; ga.glo = w.lo[g]; ga.keep = w.keep; ga.boxes_all = w.boxes_all; ga.rescale = rescale; ga.status = status;
-    ga.truncated = truncated; ga.status_rw = status;
+    ga.truncated = truncated; ga.status_rw = status; ga.out_slab = out_slab; ga.img_count = img_count;
     ga.cap = cap; ga.total_anchors = total_anchors; ga.label_bits = label_bits; ga.K = K;
     ga.out_boxes = out_boxes; ga.out_scores = out_scores; ga.out_labels = out_labels; ga.out_count = out_count;
     hipLaunchKernelGGL(gather_topk_kernel, dim3(n_img), dim3(256), 0, s, ga);
@@ -1212,7 +1242,7 @@ static int nms_gather(const Workspace& w, int g, const uint64_t* phi, const uint
 // sorts records in w.hi/lo[st.cur] by (img, score desc, cand asc), then runs NMS + gather.
 static int sort_nms_gather(const Workspace& w, SortState st, int* status, int cap, int n_img, int lo_bits, int label_bits, int total_anchors,
                            float nms_thresh, int K, const float* rescale, float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count,
-                           hipStream_t s) {
+                           hipStream_t s, float* out_slab = nullptr) {
     int rc;
     for (int sh = 0; sh < lo_bits; sh += 8) if ((rc = radix_pass(w, st, status, cap, sh, s)) != YMI_OK) return rc;
     for (int sh = 32; sh < 64; sh += 8) if ((rc = radix_pass(w, st, status, cap, sh, s)) != YMI_OK) return rc;
@@ -1247,7 +1277,7 @@ static int sort_nms_gather(const Workspace& w, SortState st, int* status, int ca
         plo = w.lo[p];
     }
     (void)label_passes;
-    return nms_gather(w, g, phi, plo, status, cap, n_img, label_bits, total_anchors, nms_thresh, K, rescale, out_boxes, out_scores, out_labels, out_count, s);
+    return nms_gather(w, g, phi, plo, status, cap, n_img, label_bits, total_anchors, nms_thresh, K, rescale, out_boxes, out_scores, out_labels, out_count, s, nullptr, out_slab);
 }
 
 static int post_validate(const ymi_post_desc* d, bool need_logits, PostLayout& L, Workspace& w) {
@@ -1277,7 +1307,7 @@ int post_begin_launch(const ymi_post_desc* d, hipStream_t s) {
     Workspace w;
     int rc = post_validate(d, false, L, w);
     if (rc != YMI_OK) return rc;
-    YMI_CHECK_HIP(hipMemsetAsync(d->status, 0, 4 * sizeof(int), s));
+    YMI_CHECK_HIP(hipMemsetAsync(d->status, 0, ST_WORDS * sizeof(int), s));
     YMI_CHECK_HIP(hipMemsetAsync(d->out_count, 0, (size_t)d->n * sizeof(int), s));
     if (L.per_image) YMI_CHECK_HIP(hipMemsetAsync(w.img_count, 0, (size_t)d->n * sizeof(int), s));
     return YMI_OK;
@@ -1358,13 +1388,13 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
                                RANK_MAX, w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);
         if ((rc = check_launch("select_prefix/sort_image")) != YMI_OK) return rc;
         return nms_gather(w, 1, w.p_hi, w.p_lo, d->status, d->cand_cap, d->n, L.label_bits, L.total_anchors, d->nms_thresh, d->detections_per_img, d->rescale,
-                          d->out_boxes, d->out_scores, d->out_labels, d->out_count, s, w.sel_count + d->n);
+                          d->out_boxes, d->out_scores, d->out_labels, d->out_count, s, w.sel_count + d->n, d->out_slab, w.img_count);
     }
     hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(64), 0, s, d->status, d->cand_cap);
     rc = check_launch("finalize_count");
     if (rc != YMI_OK) return rc;
     return sort_nms_gather(w, SortState{0}, d->status, d->cand_cap, d->n, L.label_bits + L.anchor_bits, L.label_bits, L.total_anchors, d->nms_thresh,
-                           d->detections_per_img, d->rescale, d->out_boxes, d->out_scores, d->out_labels, d->out_count, s);
+                           d->detections_per_img, d->rescale, d->out_boxes, d->out_scores, d->out_labels, d->out_count, s, d->out_slab);
 }
 
 int postprocess_launch(const ymi_post_desc* d, hipStream_t s) {

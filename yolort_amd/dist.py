@@ -29,6 +29,8 @@ SLAB_STALE = -1   # count column of a shard whose rank has to re-run the batch l
 
 def pack_slab(boxes: Tensor, scores: Tensor, labels: Tensor, count: Tensor, stale: Optional[Tensor] = None) -> Tensor:
     """(n,K,4)+(n,K)+(n,K)+(n) -> one fp32 buffer (n, K*6 + 1); labels/counts travel exactly (ints < 2^24).
+    HOST-SIDE form (second round of `resolve_stale`, tests): on the serving path the slab is written by the top-k kernel itself
+    (include/yolort_amd.h ymi_post_desc.out_slab, round 4) and the collective is enqueued straight behind the post-process.
     `stale`: optional 0-d / 1-element tensor on the same device (no host sync); when non-zero the shard's count column is
     SLAB_STALE -- the sender will re-run this batch (candidate capacity / score-prefix redo) and every rank learns it from the
     collective itself."""

@@ -512,6 +512,7 @@ class Plan:
         d.rescale = None if pb.rescale is None else pb.rescale.data_ptr()
         d.out_boxes, d.out_scores, d.out_labels, d.out_count = pb.boxes.data_ptr(), pb.scores.data_ptr(), pb.labels.data_ptr(), pb.count.data_ptr()
         d.status = pb.status.data_ptr()
+        d.out_slab = pb.slab.data_ptr()
         d.ws, d.ws_bytes, d.cand_cap = pb.ws.data_ptr(), pb.ws.numel(), cand_cap
         d.flags = flags
         pb.total_anchors = total_anchors
@@ -632,8 +633,11 @@ class PostBuffers:
         self.boxes = torch.zeros(n, k, 4, device=dev, dtype=torch.float32)
         self.scores = torch.zeros(n, k, device=dev, dtype=torch.float32)
         self.labels = torch.zeros(n, k, device=dev, dtype=torch.int64)
-        self.count = torch.zeros(n, device=dev, dtype=torch.int32)
-        self.status = torch.zeros(4, device=dev, dtype=torch.int32)
+        # status words and per-image counts share one buffer: ONE device-to-host copy per batch brings both (include/yolort_amd.h ymi_post_desc.status, ABI 5: 8 words)
+        self.status_count = torch.zeros(8 + n, device=dev, dtype=torch.int32)
+        self.status, self.count = self.status_count[:8], self.status_count[8:]
+        # the packed wire slab of yolort_amd/dist.py, written by the top-k kernel itself (ymi_post_desc.out_slab): [boxes 4K | scores K | labels K | count] per image
+        self.slab = torch.zeros(n, 6 * k + 1, device=dev, dtype=torch.float32)
         self.rescale = rescale
         nbytes = plan.lib.ymi_postprocess_ws_bytes(n, total_anchors, cand_cap)
         self.ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)

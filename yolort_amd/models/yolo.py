@@ -43,7 +43,9 @@ class _PlanEntry:
         n = x.n
         # pinned staging for the tiny per-batch host<->device traffic (rescale rows in, status+counts out)
         self.rescale_host = torch.zeros(n, 3, dtype=torch.float32).pin_memory() if post is not None else None
-        self.result_host = torch.zeros(4 + n, dtype=torch.int32).pin_memory() if post is not None else None
+        self.result_host = torch.zeros(8 + n, dtype=torch.int32).pin_memory() if post is not None else None
+        self.rescale_set = False
+        self.rescale_rows = None   # the rows last uploaded to `rescale` (a serving loop sends the same geometry again and again: uploaded once)
         self.done = None        # event recorded after the post-process + result copy of the last submit
         self.outstanding = None  # the PendingDetections of the last submit while the host has not collected it yet
         # stream priorities (tuning aid, default 0 / 0): YOLORT_AMD_POST_PRIORITY / YOLORT_AMD_CONV_PRIORITY, -1 = high
@@ -123,7 +125,7 @@ class PendingDetections:
                 print(f"[yolort_amd] candidate capacity {self.owner.cand_cap_per_image}/image exceeded (status {host[:4]}): growing", flush=True)
             return self.owner._redo_with_capacity(e, self.rows, per_image, self.planar)
         p = e.post
-        return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), host[4:])
+        return slab_to_list(p.boxes.clone(), p.scores.clone(), p.labels.clone(), host[8:])
 
 
 class YOLO(nn.Module):
@@ -306,11 +308,13 @@ class YOLO(nn.Module):
             grids, shifts = self.anchor_generator(feats)
             return PendingDetections(self, e, None, hook_result=self.post_process(head_outputs, grids, shifts))
         main = torch.cuda.current_stream()
-        if rescale_rows is None:
-            e.rescale_host.zero_()
-        else:
-            e.rescale_host.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
-        e.rescale.copy_(e.rescale_host, non_blocking=True)
+        if not e.rescale_set or e.rescale_rows is not rescale_rows:   # (the memoised geometry hands over the SAME list object for the same size list)
+            if rescale_rows is None:
+                e.rescale_host.zero_()
+            else:
+                e.rescale_host.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
+            e.rescale.copy_(e.rescale_host, non_blocking=True)
+            e.rescale_rows, e.rescale_set = rescale_rows, True
         br = self.bracket
         if br is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
@@ -336,13 +340,14 @@ class YOLO(nn.Module):
             else:
                 e.plan.run(e.n_conv_ops, -1, stream=side)
         with torch.cuda.stream(side):
-            e.result_host.copy_(torch.cat([e.post.status, e.post.count]), non_blocking=True)
+            e.result_host.copy_(e.post.status_count, non_blocking=True)
             gather = self._gather_on and not self._in_redo
             if gather:   # the collective waits for the post-process on `side`, and `side` then waits for it (no host sync)
                 import torch.distributed as dist
 
                 from .. import dist as ydist
-                packed = ydist.pack_slab(e.post.boxes, e.post.scores, e.post.labels, e.post.count, stale=e.post.status[1:2])
+                # the wire slab was written by the top-k kernel itself (ymi_post_desc.out_slab), stale marker included: nothing between the post-process and the collective
+                packed = e.post.slab
                 world = dist.get_world_size(self._gather_group)
                 if getattr(e, "gathered", None) is None or e.gathered.shape[0] != world * packed.shape[0]:
                     e.gathered = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
