@@ -418,14 +418,18 @@ def spread_ok(ev):
             and ev["score_range"][1] >= 0.75 and 0.5 * ev["thr_gap"] >= need)
 
 
-def spread_golden(arch, seeds=range(0, 40)):
+def spread_golden(arch, seeds=range(0, 40), force=False):
+    """`force`: commit the given seed whatever the margins are (they are recorded in the golden's meta and the GPU test states what it can assert): yolov5m in bf16
+    -- the reference's OWN bfloat16 run moves scores by 0.05-0.1 and re-decides a fifth to three quarters of the detections, no threshold gap of a hundred-detection
+    workload is that wide (tests/golden/spread_m_search.txt) -- and yolov5l6, whose evaluations cost minutes each (a bounded search, then the best seed)"""
     import subprocess
     from yolort_amd.utils.synth import cond_bn_path
     tag = COND_TAGS[arch]
     for seed in seeds:
         subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", "--spread", f"--seed={seed}", arch], check=True, capture_output=True)
         ev, ref = spread_evaluate(arch, seed)
-        if spread_ok(ev):
+        if spread_ok(ev) or (force and ref is not None):
+            ev["accepted_by"] = "criteria (spread_ok)" if spread_ok(ev) else "forced: best seed of a bounded search, margins as recorded"
             out = {"meta": json.dumps(ev)}
             for i, r in enumerate(ref):
                 for k in ("boxes", "scores", "labels"):
@@ -453,8 +457,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "spread":   # usage: spread [arch ...] [seed ...]
         seeds = [int(a) for a in sys.argv[2:] if a.isdigit()]
-        for a in [a for a in sys.argv[2:] if not a.isdigit()] or ["yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60"]:
-            spread_golden(a, seeds or range(0, 40))
+        force = "--force" in sys.argv
+        for a in [a for a in sys.argv[2:] if not a.isdigit() and a != "--force"] or ["yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60"]:
+            spread_golden(a, seeds or range(0, 40), force=force)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref16":   # usage: ref16 [kind:tag ...]
         for a in sys.argv[2:] or ["cond:s", "cond:n", "cond:m", "photo:s"]:

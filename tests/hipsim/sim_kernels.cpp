@@ -30,6 +30,7 @@ alignas(16) unsigned char sb_sm[SIM_LDS];
 alignas(16) unsigned char r3_sm[SIM_LDS];
 alignas(16) unsigned char rw_sm[SIM_LDS];
 alignas(16) unsigned char r2_sm[SIM_LDS];
+alignas(16) unsigned char r5_sm[SIM_LDS];
 alignas(16) uint16_t smem[SIM_LDS / 2];
 }  // namespace ymi
 
@@ -57,6 +58,7 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     if (d->tile == 132) return ymi::conv3x3_res_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 133) return ymi::conv3x3_rw_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 134) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 1, nullptr);
+    if (d->tile == 135) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 2, nullptr);
     if (d->tile == 41) return sim_conv2d_stem(a, d);
     if ((d->tile >= 11 && d->tile <= 119) || (d->tile >= 141 && d->tile <= 159)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
     ymi::set_error("sim_conv2d: tile %d is not part of the simulator build", d->tile);

@@ -356,10 +356,14 @@ def test_the_topk_kernel_writes_the_wire_slab_itself(dev):
     for seed, thr in ((31, 0.2), (32, 0.35), (33, 0.2)):
         m.model.post_process.score_thresh = thr
         imgs = [im.to(dev).half() for im in synth_images(3, 320, 320, seed=seed)]
-        pend = m.forward_async(imgs)
-        dets = pend.result()
-        torch.cuda.synchronize()
-        post = pend.entry.post
+        for _ in range(3):   # (a first pass may overflow the candidate capacity: the host grows it and re-runs on another instance -- look at a pass that went through)
+            pend = m.forward_async(imgs)
+            dets = pend.result()
+            torch.cuda.synchronize()
+            post = pend.entry.post
+            if int(post.status[1]) == 0:
+                break
+        assert int(post.status[1]) == 0
         want = ydist.pack_slab(post.boxes, post.scores, post.labels, post.count)
         slab = post.slab
         counts = post.count.tolist()

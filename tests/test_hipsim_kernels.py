@@ -412,6 +412,46 @@ def test_register_weights_3x3_stride2_kernel_logic(sim, monkeypatch):
             assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16)), "tile 134 differs from the implicit GEMM"
 
 
+@pytest.mark.parametrize("cout", [128, 256])
+def test_register_weights_3x3_stride2_ksplit_kernel_logic(sim, cout, monkeypatch):
+    """conv3x3_rw2.hip tile 135 (round 4): 128 -> 128 / 256 at stride 2, K split over two waves whose partial sums meet in the consumed patch buffer -- against torch
+    and against the 8-wave implicit GEMM (tile 111) within the fp32 summation-order noise (the split sum is another rounding order: not bit-identical by design);
+    ragged maps, several tiles per block, channel-slice views on both sides, both cout halves of the 256-wide form"""
+    from yolort_amd import engine
+    cpu = torch.device("cpu")
+    cin = 128
+    monkeypatch.setenv("YOLORT_AMD_RES3X3_BLOCKS", "2")
+    for dtype, (n, h, w), xcs in [(torch.float16, (2, 19, 34), 160), (torch.bfloat16, (1, 16, 16), 128)]:
+        g = torch.Generator().manual_seed(135 + h + cout)
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        pc = engine.PackedConv(wt, bias, None, dtype, cpu)
+        xw = Buf(n, h, w, xcs, dtype)
+        xw.view()[..., :cin] = x.permute(0, 2, 3, 1).to(dtype)
+        if xcs > cin:
+            xw.view()[..., cin:] = 7.0
+        xb = xw.slice_c(0, cin)
+        ref = F.silu(F.conv2d(x, wt, bias, 2, 1))
+        ho, wo = ref.shape[-2:]
+        outs = []
+        for tile in (135, 111):
+            wide = Buf(n, ho, wo, cout + 32, dtype)
+            yv = wide.slice_c(16, cout)
+            d = _conv_desc(xb, pc, yv, tile, k=3, pad=1, stride=2)
+            d.ktab = pc.ktab(w, xcs).data_ptr()
+            _check(sim, sim.sim_conv2d(C.byref(d)))
+            got = yv.view().float().permute(0, 3, 1, 2)
+            tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+            assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (tile, h, w)
+            w_all = wide.view().float()
+            assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + cout:].abs().max().item() == 0
+            outs.append(yv.view().float())
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+        assert (outs[0] - outs[1]).abs().max().item() <= ulp * max(1.0, ref.abs().max().item())   # one unit in the last place of the output type at most
+        assert (outs[0] != outs[1]).float().mean().item() < 0.05
+
+
 def test_resident_weights_3x3_c64_with_a_chained_1x1_equals_the_two_launches(sim):
     """tile 132 with the next Bottleneck's 1x1 riding in the epilogue (a wave owns all couts of its pixels, as in conv_halo8's 8 x 1 forms)"""
     from yolort_amd import engine

@@ -314,6 +314,16 @@ def test_conv3x3_rw2_kernel(dev, shape):
     _run_conv(dev, torch.bfloat16, cin=64, cout=128, k=3, s=2, p=1, tile=134, seed=135, **shape)
 
 
+@pytest.mark.parametrize("cout", [128, 256])
+@pytest.mark.parametrize("shape", [dict(n=2, h=40, w=40), dict(n=1, h=33, w=21), dict(n=2, h=5, w=7), dict(n=12, h=80, w=80), dict(n=3, h=81, w=160)])
+def test_conv3x3_rw3_ksplit_kernel(dev, cout, shape):
+    """tile 135 (conv3x3_rw2.hip, round 4): 128 -> 128 / 256 at stride 2, K split over two waves (partial sums through the consumed patch buffer), one 8-wave block
+    per CU walking the tiles; ragged maps, more tiles than resident blocks (12 x 25 = 300 tiles on 256 / 128 blocks), channel-slice views on both sides -- against the
+    fp32 convolution of the same rounded operands"""
+    _run_conv(dev, torch.float16, cin=128, cout=cout, k=3, s=2, p=1, tile=135, x_cs_extra=32, y_cs_extra=64, seed=135 + cout, **shape)
+    _run_conv(dev, torch.bfloat16, cin=128, cout=cout, k=3, s=2, p=1, tile=135, seed=136 + cout, **shape)
+
+
 def test_conv3x3_rw2_equals_the_implicit_gemm_bit_for_bit(dev):
     """tile 134 accumulates in the implicit GEMM's K order and rounds through the same lean epilogue: equal to tiles 111 / 143 bit for bit (yolov5s body.3's shape
     at a reduced batch and a ragged variant of it)"""

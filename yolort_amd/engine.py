@@ -193,9 +193,10 @@ class Plan:
         self.fuse_stem = False   # set_fuse_stem()
         self.res3x3 = {"0": 0, "1": 1}.get(os.environ.get("YOLORT_AMD_RES3X3", "2"), 2)   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
         self.rw2 = os.environ.get("YOLORT_AMD_RW2", "1") != "0"   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2)
+        self.rw3 = os.environ.get("YOLORT_AMD_RW3", "0") == "1"   # tile 135 (its K-split form, cin = 128): opt-in until measured
         if self.fp32:
             self.res3x3 = 0
-            self.rw2 = False
+            self.rw2 = self.rw3 = False
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
             self.chain_next = False
@@ -326,6 +327,8 @@ class Plan:
                 d.tile = 133 if (self.res3x3 == 2 and d.cout == 64 and d.act == ACT_SILU and not d.chain_w) else 132
             elif self.rw2 and self._rw2_ok(d):
                 d.tile = 134   # stride-2 register-weights 3x3 (conv3x3_rw2.hip): ahead of the table for Conv(64, 128, 3, 2); YOLORT_AMD_RW2=0 keeps the table's tile
+            elif self.rw3 and self._rw3_ok(d):
+                d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
                 d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
         esz = 2
@@ -356,6 +359,12 @@ class Plan:
     @staticmethod
     def _rw2_ok(d: ConvDesc) -> bool:
         return (d.kh == 3 and d.kw == 3 and d.sh == 2 and d.sw == 2 and d.ph == 1 and d.pw == 1 and d.cin == 64 and d.k_pad >= 576 and d.cout == 128 and d.cout_pad >= 128
+                and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and not d.chain_w and not d.res and d.act == ACT_SILU
+                and (d.n * d.ho * d.wo + 1) * d.y_cstride < 2 ** 31 and d.n * d.h * d.w_in * d.x_cstride < 2 ** 31)
+
+    @staticmethod
+    def _rw3_ok(d: ConvDesc) -> bool:
+        return (d.kh == 3 and d.kw == 3 and d.sh == 2 and d.sw == 2 and d.ph == 1 and d.pw == 1 and d.cin == 128 and d.k_pad >= 1152 and d.cout in (128, 256) and d.cout_pad >= d.cout
                 and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and not d.chain_w and not d.res and d.act == ACT_SILU
                 and (d.n * d.ho * d.wo + 1) * d.y_cstride < 2 ** 31 and d.n * d.h * d.w_in * d.x_cstride < 2 ** 31)
 
@@ -410,6 +419,8 @@ class Plan:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
         if self._rw2_ok(d):
             cands = cands + [134]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip)
+        if self._rw3_ok(d):
+            cands = cands + [135]   # ... K split over two waves, cin = 128
         if self._res3x3_ok(d):
             cands = cands + [132]   # ... cin = 48 / 64, stride 1, cross-tile patch prefetch (conv3x3_res.hip)
             if d.cout == 64 and d.act == ACT_SILU and not d.chain_w:
