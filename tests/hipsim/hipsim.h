@@ -261,3 +261,4 @@ inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return
 // after a keyword: legal only because every system header is included above.)
 #define volatile(...)
 #define asm
+#define YMI_HIPSIM 1   // kernels that issue LDS reads through inline assembly (explicitly scheduled loops) take their plain C++ form here

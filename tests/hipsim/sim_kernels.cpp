@@ -59,6 +59,7 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     if (d->tile == 133) return ymi::conv3x3_rw_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 134) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 135) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 2, nullptr);
+    if (d->tile == 136) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 3, nullptr);
     if (d->tile == 41) return sim_conv2d_stem(a, d);
     if ((d->tile >= 11 && d->tile <= 119) || (d->tile >= 141 && d->tile <= 159)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
     ymi::set_error("sim_conv2d: tile %d is not part of the simulator build", d->tile);

@@ -396,7 +396,7 @@ def test_register_weights_3x3_stride2_kernel_logic(sim, monkeypatch):
         ref = F.silu(F.conv2d(x, wt, bias, 2, 1))
         ho, wo = ref.shape[-2:]
         outs = []
-        for tile in (134, 111, 112):
+        for tile in (134, 111, 112, 136):   # 136: tile 134 with a DMA wave and three patch buffers (5 waves: every wave must meet the same number of barriers)
             wide = Buf(n, ho, wo, cout + 32, dtype)
             yv = wide.slice_c(16, cout)
             d = _conv_desc(xb, pc, yv, tile, k=3, pad=1, stride=2)

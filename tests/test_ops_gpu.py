@@ -310,8 +310,9 @@ def test_conv3x3_res_kernel(dev, cin, cout, shape):
 def test_conv3x3_rw2_kernel(dev, shape):
     """stride-2 register-weights 3x3 kernel, 64 -> 128 (conv3x3_rw2.hip, tile 134): ragged sizes against the 8 x 8 tiles (odd inputs), more tiles than resident
     blocks (12 x 100 = 1200 tiles on 512 blocks: the persistent loop and its double-buffered parity-split patch), channel-slice views on both sides"""
-    _run_conv(dev, torch.float16, cin=64, cout=128, k=3, s=2, p=1, tile=134, x_cs_extra=32, y_cs_extra=64, seed=134, **shape)
-    _run_conv(dev, torch.bfloat16, cin=64, cout=128, k=3, s=2, p=1, tile=134, seed=135, **shape)
+    for tile in (134, 136):   # 136: the same tile with a DMA wave and three patch buffers
+        _run_conv(dev, torch.float16, cin=64, cout=128, k=3, s=2, p=1, tile=tile, x_cs_extra=32, y_cs_extra=64, seed=134, **shape)
+        _run_conv(dev, torch.bfloat16, cin=64, cout=128, k=3, s=2, p=1, tile=tile, seed=135, **shape)
 
 
 @pytest.mark.parametrize("cout", [128, 256])
@@ -334,7 +335,7 @@ def test_conv3x3_rw2_equals_the_implicit_gemm_bit_for_bit(dev):
         wt = torch.randn(128, 64, 3, 3, generator=g) / np.sqrt(64 * 9)
         bias = torch.randn(128, generator=g) * 0.1
         outs = []
-        for tile in (134, 111, 143):
+        for tile in (134, 111, 143, 136):
             plan = engine.Plan(dev, torch.float16)
             xv = plan.alloc(n, h, w, 64)
             xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))

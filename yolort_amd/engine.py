@@ -192,11 +192,11 @@ class Plan:
         self.fp32 = dtype == torch.float32
         self.fuse_stem = False   # set_fuse_stem()
         self.res3x3 = {"0": 0, "1": 1}.get(os.environ.get("YOLORT_AMD_RES3X3", "2"), 2)   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
-        self.rw2 = os.environ.get("YOLORT_AMD_RW2", "1") != "0"   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2)
+        self.rw2 = {"0": 0, "2": 2}.get(os.environ.get("YOLORT_AMD_RW2", "1"), 1)   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2); 2: tile 136
         self.rw3 = os.environ.get("YOLORT_AMD_RW3", "0") == "1"   # tile 135 (its K-split form, cin = 128): opt-in until measured
         if self.fp32:
             self.res3x3 = 0
-            self.rw2 = self.rw3 = False
+            self.rw2, self.rw3 = 0, False
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
             self.chain_next = False
@@ -326,7 +326,7 @@ class Plan:
                 # register-weights variant (conv3x3_rw.hip, bit-identical, 9-10 % faster: profiles/r03z14_rw3x3.txt) where that one fits; YOLORT_AMD_RES3X3=1: tile 132 only
                 d.tile = 133 if (self.res3x3 == 2 and d.cout == 64 and d.act == ACT_SILU and not d.chain_w) else 132
             elif self.rw2 and self._rw2_ok(d):
-                d.tile = 134   # stride-2 register-weights 3x3 (conv3x3_rw2.hip): ahead of the table for Conv(64, 128, 3, 2); YOLORT_AMD_RW2=0 keeps the table's tile
+                d.tile = 136 if self.rw2 == 2 else 134   # stride-2 register-weights 3x3 (conv3x3_rw2.hip): ahead of the table for Conv(64, 128, 3, 2); YOLORT_AMD_RW2=0 keeps the table's tile, =2: its DMA-wave form (tile 136)
             elif self.rw3 and self._rw3_ok(d):
                 d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
@@ -336,13 +336,14 @@ class Plan:
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
         # output once; a fused cv1+cv2 launch stands for two reference convs, so its input counts twice.
         ref_reads = 2 if out2 is not None else 1
+        cin_real = pc.k_real // (pc.kh * pc.kw)   # the reference conv's input channels: zero-padded views (yolov5m's 48 -> 64 hidden width, the RGB0 super-pixels) do not count
         chain_flops = chain_bytes = 0.0
         if chain is not None:   # the chained conv is a reference conv of its own: reads its input once, writes its output once
             chain_flops = 2.0 * x.n * ho * wo * chain[0].cout * chain[0].k_real
-            chain_bytes = float(x.n * ho * wo * (chain[0].cin + chain[0].cout) * esz + chain[0].cout * chain[0].k * esz)
+            chain_bytes = float(x.n * ho * wo * (chain[0].k_real + chain[0].cout) * esz + chain[0].cout * chain[0].k_real * esz)
         self._record(self.lib.ymi_plan_add_conv(self.handle, C.byref(d)), name, kind="conv",
                      flops=flops + chain_flops,
-                     bytes=float(ref_reads * x.n * x.h * x.w * x.c * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k * esz) + chain_bytes,
+                     bytes=float(ref_reads * x.n * x.h * x.w * cin_real * esz + x.n * ho * wo * pc.cout * out.base.element_size() + pc.cout * pc.k_real * esz) + chain_bytes,
                      ref_convs=ref_reads + (1 if chain is not None else 0), tile=int(d.tile),
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
@@ -418,7 +419,7 @@ class Plan:
                 d.out_dtype == d.dtype and d.y2_mode != 2 and chain is None:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
         if self._rw2_ok(d):
-            cands = cands + [134]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip)
+            cands = cands + [134, 136]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip); 136: with a DMA wave
         if self._rw3_ok(d):
             cands = cands + [135]   # ... K split over two waves, cin = 128
         if self._res3x3_ok(d):

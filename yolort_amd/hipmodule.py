@@ -28,40 +28,43 @@ def compute_dtype_of(module: nn.Module) -> torch.dtype:
     return getattr(module, "compute_dtype", torch.float16)
 
 
+# Structure epoch: bumped whenever ANY nn.Module registers a parameter, a buffer or a sub-module (torch's global registration hooks fire for
+# `m.weight = nn.Parameter(...)`, `m.head = other_head`, `register_buffer`, `add_module`, ... -- every path through nn.Module.__setattr__).  While it stands still the
+# set of Parameter / buffer OBJECTS of a module tree cannot have changed, so `weights_signature` may keep the flat tensor list it collected (the previous
+# cache fingerprinted only modules that had children, and read only modules that already had parameters: a buffer registered later on a bare module, or a child
+# added to a former leaf, went unseen; the id() sum could also cancel out).
+_STRUCT_EPOCH = [0]
+
+
+def _bump_epoch(*_args):
+    _STRUCT_EPOCH[0] += 1
+    return None
+
+
+nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
+nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+
+
 def weights_signature(module: nn.Module) -> Tuple:
-    """changes when any parameter / buffer of the module tree is modified in place (`_version`), re-allocated or replaced (`data_ptr`): the plan
-    cache's key.  Called once per submitted batch, so it must be cheap: `module.parameters()` + `module.buffers()` walk the tree through two
-    recursive generators with name bookkeeping (0.4 ms per call on yolov5s -- most of the host's 0.76 ms per batch, tools/host_profile.py); here the
-    list of sub-MODULES is cached on first use, validated by a fingerprint of every module's direct children (a replaced sub-module rebuilds it), and
-    only the modules' own `_parameters` / `_buffers` dicts are read, so replaced Parameter objects are still seen."""
-    cache = module.__dict__.get("_ymi_modules")
-    if cache is not None:   # the cached module list is valid while no sub-module has been added, removed or REPLACED (e.g. `model.head = other_head`)
-        fp = 0
-        for m in cache[1]:
-            for c in m._modules.values():
-                fp += id(c)
-        if fp != cache[0]:
-            cache = None
-    if cache is None:
-        allm = list(module.modules())
-        fp = 0
-        for m in allm:
-            for c in m._modules.values():
-                fp += id(c)
-        cache = (fp, [m for m in allm if m._modules], [m for m in allm if m._parameters or m._buffers])
-        module.__dict__["_ymi_modules"] = cache
+    """changes when any parameter / buffer of the module tree is modified in place (`_version`), re-allocated (`data_ptr`: .to() / .half() swap the data of the
+    same Parameter object) or replaced (a new object is registered: the structure epoch moves and the tensor list is rebuilt): the plan cache's key.  Called once
+    per submitted batch, so it must be cheap: the flat list of tensor objects is cached per module tree and only `_version` / `data_ptr()` of each are read
+    (`module.parameters()` + `module.buffers()` walk the tree through two recursive generators with name bookkeeping: 0.4 ms per call on yolov5s, most of round 2's
+    0.76 ms per batch -- tools/host_profile.py).  The key holds the identity of the tensor objects, not the epoch: a registration somewhere else in the process (another
+    model being built) re-collects the list once and yields the same key.  (Direct pokes into a module's `_parameters` dict bypass nn.Module's registration and are not seen.)"""
+    cache = module.__dict__.get("_ymi_tensors")
+    if cache is None or cache[0] != _STRUCT_EPOCH[0]:
+        mods = list(module.modules())
+        tensors = [t for m in mods for t in m._parameters.values() if t is not None] + [t for m in mods for t in m._buffers.values() if t is not None]
+        cache = (_STRUCT_EPOCH[0], tensors, hash(tuple(id(t) for t in tensors)))
+        module.__dict__["_ymi_tensors"] = cache
     sig = 0
     ptr = 0
-    for m in cache[2]:
-        for t in m._parameters.values():
-            if t is not None:
-                sig += t._version
-                ptr ^= t.data_ptr()
-        for t in m._buffers.values():
-            if t is not None:
-                sig += t._version
-                ptr ^= t.data_ptr()
-    return (sig, ptr)
+    for t in cache[1]:
+        sig += t._version
+        ptr ^= t.data_ptr()
+    return (cache[2], sig, ptr)
 
 
 def nchw_to_view(plan_or_none: Optional[Plan], x: Tensor, c_pad: int, out: Optional[View] = None, dtype: Optional[torch.dtype] = None) -> View:
