@@ -31,6 +31,7 @@ alignas(16) unsigned char r3_sm[SIM_LDS];
 alignas(16) unsigned char rw_sm[SIM_LDS];
 alignas(16) unsigned char r2_sm[SIM_LDS];
 alignas(16) unsigned char r5_sm[SIM_LDS];
+alignas(16) unsigned char rs_sm[SIM_LDS];
 alignas(16) uint16_t smem[SIM_LDS / 2];
 }  // namespace ymi
 
@@ -40,6 +41,7 @@ alignas(16) uint16_t smem[SIM_LDS / 2];
 #include "../../yolort_amd/csrc/conv3x3_res.hip"
 #include "../../yolort_amd/csrc/conv3x3_rw.hip"
 #include "../../yolort_amd/csrc/conv3x3_rw2.hip"
+#include "../../yolort_amd/csrc/conv3x3_rs.hip"
 #include "../../yolort_amd/csrc/stem_body1_fused.hip"
 
 int sim_conv2d_gemm(const ymi::ConvArgs& a, const ymi_conv_desc* d);
@@ -60,6 +62,7 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     if (d->tile == 134) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 135) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 2, nullptr);
     if (d->tile == 136) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 3, nullptr);
+    if (d->tile == 137 || d->tile == 138) return ymi::conv3x3_rs_launch(a, d->dtype, d->out_dtype, d->tile - 136, nullptr);
     if (d->tile == 41) return sim_conv2d_stem(a, d);
     if ((d->tile >= 11 && d->tile <= 119) || (d->tile >= 141 && d->tile <= 159)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp
     ymi::set_error("sim_conv2d: tile %d is not part of the simulator build", d->tile);

@@ -412,6 +412,45 @@ def test_register_weights_3x3_stride2_kernel_logic(sim, monkeypatch):
             assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16)), "tile 134 differs from the implicit GEMM"
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_row_streaming_3x3_kernel_logic(sim, stride, monkeypatch):
+    """conv3x3_rs.hip (tiles 137 / 138, round 4): a block walks down a 16-column strip of the output with a ring of input rows in LDS, the images of a strip
+    concatenated into one stream (zero rows between them), row groups D steps ahead -- against torch and BIT-IDENTICAL to the implicit GEMM (tiles 113 / 111); several
+    images (the stream crosses image boundaries inside a block), maps ragged against the 16-column strips and the 2 / 4-row steps, heights that are / are not multiples
+    of four, few blocks (long chunks: the ring wraps many times) and many blocks (chunks shorter than the lookahead), channel-slice views on both sides"""
+    from yolort_amd import engine
+    cpu = torch.device("cpu")
+    cin, cout, tile, ref_tile = 64, (64 if stride == 1 else 128), (137 if stride == 1 else 138), (113 if stride == 1 else 111)
+    for blocks, dtype, (n, h, w), xcs in [("3", torch.float16, (3, 21, 37), 96), ("64", torch.bfloat16, (2, 16, 32), 64), ("5", torch.float16, (1, 9, 50), 64), ("2", torch.float16, (4, 8, 16), 64)]:
+        monkeypatch.setenv("YOLORT_AMD_RES3X3_BLOCKS", blocks)
+        g = torch.Generator().manual_seed(137 + h + stride)
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        pc = engine.PackedConv(wt, bias, None, dtype, cpu)
+        xw = Buf(n, h, w, xcs, dtype)
+        xw.view()[..., :cin] = x.permute(0, 2, 3, 1).to(dtype)
+        if xcs > cin:
+            xw.view()[..., cin:] = 7.0
+        xb = xw.slice_c(0, cin)
+        ref = F.silu(F.conv2d(x, wt, bias, stride, 1))
+        ho, wo = ref.shape[-2:]
+        outs = []
+        for t in (tile, ref_tile):
+            wide = Buf(n, ho, wo, cout + 32, dtype)
+            yv = wide.slice_c(16, cout)
+            d = _conv_desc(xb, pc, yv, t, k=3, pad=1, stride=stride)
+            d.ktab = pc.ktab(w, xcs).data_ptr()
+            _check(sim, sim.sim_conv2d(C.byref(d)))
+            got = yv.view().float().permute(0, 3, 1, 2)
+            tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+            assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (t, blocks, h, w)
+            w_all = wide.view().float()
+            assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + cout:].abs().max().item() == 0
+            outs.append(yv.view().clone())
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "the row-streaming kernel differs from the implicit GEMM"
+
+
 @pytest.mark.parametrize("cout", [128, 256])
 def test_register_weights_3x3_stride2_ksplit_kernel_logic(sim, cout, monkeypatch):
     """conv3x3_rw2.hip tile 135 (round 4): 128 -> 128 / 256 at stride 2, K split over two waves whose partial sums meet in the consumed patch buffer -- against torch

@@ -111,6 +111,7 @@ def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None, small_tiles=False):
     p.autotune, p.use_tile_table, p.fp32 = False, False, dtype == torch.float32
     p.res3x3, p.fuse_stem = (0 if p.fp32 else 2), False   # tiles 132 / 133 (conv3x3_res.hip / conv3x3_rw.hip) wherever they fit, as in production
     p.rw2 = not p.fp32                                    # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2), as in production
+    p.rs = False
     p.rw3 = not p.fp32                                    # tile 135 (its K-split form for cin = 128): executed inside the whole-model runs here
     if p.fp32:   # fp32 parity mode (engine.Plan.__init__): one launch per reference conv, no fused pairs / chains
         p.use_v1, p.chain_1x1, p.chain_cv3, p.fuse_c3 = True, False, False, False

@@ -325,6 +325,36 @@ def test_conv3x3_rw3_ksplit_kernel(dev, cout, shape):
     _run_conv(dev, torch.bfloat16, cin=128, cout=cout, k=3, s=2, p=1, tile=135, seed=136 + cout, **shape)
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("shape", [dict(n=2, h=40, w=40), dict(n=1, h=33, w=21), dict(n=3, h=16, w=16), dict(n=2, h=5, w=7), dict(n=12, h=80, w=80), dict(n=4, h=161, w=160)])
+def test_conv3x3_rs_kernel(dev, stride, shape, monkeypatch):
+    """row-streaming 3x3 (conv3x3_rs.hip, tiles 137 / 138): strips x chunks of steps over the concatenated images, ring of rows, counted waits (and the drain-everything form:
+    YOLORT_AMD_RS_COUNTED is read once per process, so the counted form is what runs here); ragged maps, channel-slice views; bit-identical to the implicit GEMM"""
+    from yolort_amd import engine
+    cout, tile, ref_tile = (64, 137, 113) if stride == 1 else (128, 138, 111)
+    _run_conv(dev, torch.float16, cin=64, cout=cout, k=3, s=stride, p=1, tile=tile, x_cs_extra=32, y_cs_extra=64, seed=137 + stride, **shape)
+    _run_conv(dev, torch.bfloat16, cin=64, cout=cout, k=3, s=stride, p=1, tile=tile, seed=138 + stride, **shape)
+    n, h, w = shape["n"], shape["h"], shape["w"]
+    g = torch.Generator().manual_seed(140 + h)
+    x = torch.randn(n, 64, h, w, generator=g)
+    wt = torch.randn(cout, 64, 3, 3, generator=g) / np.sqrt(64 * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    outs = []
+    for t in (tile, ref_tile):
+        plan = engine.Plan(dev, torch.float16)
+        xv = plan.alloc(n, h, w, 64)
+        xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
+        pc = engine.PackedConv(wt.half().float(), bias, None, torch.float16, dev)
+        ho, wo = engine.conv_out_hw(h, w, (3, 3), (stride, stride), (1, 1))
+        yv = plan.alloc(n, ho, wo, cout, zero=True)
+        plan.conv(xv, pc, stride, 1, out=yv, tile=t)
+        for _ in range(3):   # (repeated: a missed wait shows as a run-to-run difference)
+            plan.run()
+        torch.cuda.synchronize()
+        outs.append(yv.as_tensor().clone())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 def test_conv3x3_rw2_equals_the_implicit_gemm_bit_for_bit(dev):
     """tile 134 accumulates in the implicit GEMM's K order and rounds through the same lean epilogue: equal to tiles 111 / 143 bit for bit (yolov5s body.3's shape
     at a reduced batch and a ragged variant of it)"""

@@ -62,6 +62,8 @@ extern template int launch_head_decode<YMI_BF16, 4>(const ConvArgs&, const HeadD
 extern template int launch_head_group<YMI_BF16, 4>(const HeadGroupArgs&, hipStream_t);
 #endif
 
+int conv3x3_rs_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);   // conv3x3_rs.hip (declared here: conv_common.hpp is every unit's header)
+
 template <int DT, int ODT>
 static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s) {
     ConvArgs a = a0;
@@ -100,6 +102,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile == 132) return conv3x3_res_launch(a, DT, ODT, 1, s);                              // ... cin = 48 / 64, stride 1
     if (tile == 133) return conv3x3_rw_launch(a, DT, ODT, 1, s);                               // ... weights in registers (opt-in)
     if (tile == 135) return conv3x3_rw2_launch(a, DT, ODT, 2, s);                              // ... stride 2, cin = 128 -> cout = 128 / 256, K split over two waves (round 4)
+    if (tile == 137 || tile == 138) return conv3x3_rs_launch(a, DT, ODT, tile - 136, s);       // row-streaming 3x3, cin = 64: stride 1 -> 64 / stride 2 -> 128 (round 4)
     if (tile == 136) return conv3x3_rw2_launch(a, DT, ODT, 3, s);                              // ... tile 134 with a DMA wave and three patch buffers, one block per CU (round 4)
     if (tile == 134) return conv3x3_rw2_launch(a, DT, ODT, 1, s);                              // ... stride 2, cin = 64 -> cout = 128, weights in registers (round 4)
     switch (tile_group_of(tile)) {

@@ -194,9 +194,10 @@ class Plan:
         self.res3x3 = {"0": 0, "1": 1}.get(os.environ.get("YOLORT_AMD_RES3X3", "2"), 2)   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
         self.rw2 = {"0": 0, "2": 2}.get(os.environ.get("YOLORT_AMD_RW2", "1"), 1)   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2); 2: tile 136
         self.rw3 = os.environ.get("YOLORT_AMD_RW3", "0") == "1"   # tile 135 (its K-split form, cin = 128): opt-in until measured
+        self.rs = os.environ.get("YOLORT_AMD_RS", "0") == "1"     # tiles 137 / 138 (row-streaming 3x3, conv3x3_rs.hip): opt-in until measured
         if self.fp32:
             self.res3x3 = 0
-            self.rw2, self.rw3 = 0, False
+            self.rw2, self.rw3, self.rs = 0, False, False
             self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
             self.fuse_c3 = False
             self.chain_next = False
@@ -321,6 +322,8 @@ class Plan:
                     0 if chain is None else (1 if len(chain) < 3 or chain[2] is None else 2 + chain[2].c))
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
+            elif self.rs and self._rs_ok(d):
+                d.tile = 136 + d.sh   # row-streaming 3x3 (conv3x3_rs.hip): tile 137 (stride 1, 64 -> 64, no shortcut) / 138 (stride 2, 64 -> 128); YOLORT_AMD_RS=0 keeps tiles 133 / 134
             elif self.res3x3 and self._res3x3_ok(d):
                 # resident-weights persistent 3x3 (conv3x3_res.hip): ahead of the table on every layer it fits (same-box A/B); its
                 # register-weights variant (conv3x3_rw.hip, bit-identical, 9-10 % faster: profiles/r03z14_rw3x3.txt) where that one fits; YOLORT_AMD_RES3X3=1: tile 132 only
@@ -361,6 +364,12 @@ class Plan:
     def _rw2_ok(d: ConvDesc) -> bool:
         return (d.kh == 3 and d.kw == 3 and d.sh == 2 and d.sw == 2 and d.ph == 1 and d.pw == 1 and d.cin == 64 and d.k_pad >= 576 and d.cout == 128 and d.cout_pad >= 128
                 and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and not d.chain_w and not d.res and d.act == ACT_SILU
+                and (d.n * d.ho * d.wo + 1) * d.y_cstride < 2 ** 31 and d.n * d.h * d.w_in * d.x_cstride < 2 ** 31)
+
+    @staticmethod
+    def _rs_ok(d: ConvDesc) -> bool:
+        return (d.kh == 3 and d.kw == 3 and d.sh == d.sw and d.sh in (1, 2) and d.ph == 1 and d.pw == 1 and d.cin == 64 and d.k_pad >= 576 and d.cout == (64 if d.sh == 1 else 128)
+                and d.cout_pad >= d.cout and d.cout_split == 0 and d.y2_mode == 0 and d.out_dtype == d.dtype and bool(d.zeros) and not d.chain_w and not d.res and d.act == ACT_SILU
                 and (d.n * d.ho * d.wo + 1) * d.y_cstride < 2 ** 31 and d.n * d.h * d.w_in * d.x_cstride < 2 ** 31)
 
     @staticmethod
@@ -422,6 +431,8 @@ class Plan:
             cands = cands + [134, 136]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip); 136: with a DMA wave
         if self._rw3_ok(d):
             cands = cands + [135]   # ... K split over two waves, cin = 128
+        if self._rs_ok(d):
+            cands = cands + [136 + d.sh]   # row-streaming 3x3 (conv3x3_rs.hip)
         if self._res3x3_ok(d):
             cands = cands + [132]   # ... cin = 48 / 64, stride 1, cross-tile patch prefetch (conv3x3_res.hip)
             if d.cout == 64 and d.act == ACT_SILU and not d.chain_w:
