@@ -578,6 +578,34 @@ def test_row_transposed_store_tile_with_channel_split(sim):
     assert outs[1][1].float()[..., :64].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("tile,base", [(142, 21), (143, 66), (144, 61)])
+def test_row_transposed_store_tiles_write_the_upsampled_copy_as_whole_rows(sim, tile, base):
+    """round 4: y2_mode 1 (the PAN's nn.Upsample folded into its producer) through StoreEpilogueTP -- the 2 x 2 copies leave as whole 64 TN-byte rows instead of four scattered
+    32-byte pieces per packet; output and upsampled copy equal the base tile's bit for bit, the neighbouring channels of the concat buffer stay untouched, ragged pixel counts"""
+    from yolort_amd import engine
+    dtype, cpu = torch.float16, torch.device("cpu")
+    g = torch.Generator().manual_seed(tile)
+    n, cin, cout, h, w = 2, 64, 128, 7, 9
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / 8).to(dtype).float()
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = engine.PackedConv(wt, bias, None, dtype, cpu)
+    xb = Buf(n, h, w, cin, dtype, fill=x.permute(0, 2, 3, 1))
+    outs = []
+    for t in (base, tile):
+        y, cat = Buf(n, h, w, cout, dtype), Buf(n, 2 * h, 2 * w, cout + 64, dtype)
+        d = _conv_desc(xb, pc, y, t, y2=cat.slice_c(32, cout), split=0)
+        d.y2_mode = 1
+        _check(sim, sim.sim_conv2d(C.byref(d)))
+        outs.append((y.view().clone(), cat.view().clone()))
+    ref = F.silu(F.conv2d(x, wt, bias)).permute(0, 2, 3, 1)
+    assert (outs[1][0].float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    up = outs[1][1]
+    assert torch.equal(up[:, ::2, ::2, 32:32 + cout], outs[1][0]) and torch.equal(up[:, 1::2, 1::2, 32:32 + cout], outs[1][0])
+    assert up.float()[..., :32].abs().max().item() == 0 and up.float()[..., 32 + cout:].abs().max().item() == 0
+
+
 def _sim_letterbox(sim, imgs, size, out_dtype, c_out=4, div=32):
     """the product's host recipe (YOLOTransform.geometry: reference transform.py:53-97, 297-330) + ymi_letterbox on the simulator"""
     from yolort_amd._lib import YMI_U8_HWC, dtype_code

@@ -119,7 +119,7 @@ def test_conv_software_pipelined_tiles(dev, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 61, 75, 77, 111, 112, 117, 119])
+@pytest.mark.parametrize("tile", [0, 61, 75, 77, 111, 112, 117, 119, 141, 142, 143, 144, 145, 152])   # 14x / 15x: row-transposed stores, the upsampled copy as whole rows (round 4)
 def test_conv_upsampled_second_output(dev, dtype, tile):
     """y2_mode 1: one launch writes the conv output and its nearest x2 upsample (into a channel slice of a wider buffer):
     both must equal the plain conv followed by the upsample kernel, bit for bit"""

@@ -420,10 +420,12 @@ __device__ __forceinline__ bool lean_ok(const ConvArgs& a, int cbase0, int tn) {
 // at the end of round 2, executed on the CPU simulator (tests/test_hipsim_kernels.py), not yet timed.
 template <int TN> constexpr int LEAN_TP_PITCH = 64 * TN + 16;
 template <int TN> constexpr int LEAN_TP_BYTES = 32 * LEAN_TP_PITCH<TN>;
-// the wave's 32 TN couts go to ONE destination: no upsampled copy, the channel split not inside the wave's range
+// the wave's 32 TN couts go to ONE destination: the channel split not inside the wave's range.  (Round 4: the x2-upsampled copy -- the PAN's nn.Upsample folded into its
+// producer -- is written from here too, as whole 64 TN-byte rows to the four pixels of each 2 x 2 block: the lean stores write it as four scattered 32-byte pieces per packet,
+// and the two layers that carry it cost 3.5 x / 1.9 x their bare GEMMs, profiles/r04b_gemm_yardstick_c2.txt.)
 template <int TN>
 __device__ __forceinline__ bool lean_tp_ok(const ConvArgs& a, int cbase0) {
-    return lean_ok(a, cbase0, TN) && !a.up2 && !(a.split > 0 && cbase0 < a.split && cbase0 + 32 * TN > a.split);
+    return lean_ok(a, cbase0, TN) && !(a.split > 0 && cbase0 < a.split && cbase0 + 32 * TN > a.split);
 }
 template <int DT, int TN, int TM, bool RES>
 __device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int mbase, int lane, unsigned char* tw) {
@@ -434,6 +436,9 @@ __device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, cons
     char* const yb = second ? reinterpret_cast<char*>(a.y2) + (size_t)(cbase0 - a.split) * 2 : reinterpret_cast<char*>(a.y) + (size_t)cbase0 * 2;
     const size_t ycs = (size_t)(second ? a.y2_cs : a.y_cs) * 2;
     const int row_l = lane / LPR, chunk = lane - row_l * LPR;
+    char* const upb = reinterpret_cast<char*>(a.y2) + (size_t)cbase0 * 2;                                  // (a.up2 only) the (n, 2ho, 2wo) view, this wave's couts
+    const size_t up_px = (size_t)a.y2_cs * 2, up_row = (size_t)(2 * a.wo) * (size_t)a.y2_cs * 2;            // byte steps of the upsampled view
+    const int hw_o = a.ho * a.wo;
     auto pix = [&](int j, int64_t& m, bool& ok) {
         m = mbase + j * 32 + frow;
         ok = m < a.M;
@@ -458,7 +463,19 @@ __device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, cons
             const int row = jj * RPI + row_l;
             const u32x4 v = *reinterpret_cast<const u32x4*>(tw + row * PITCH + chunk * 16);
             const int64_t mr = (int64_t)mbase + j * 32 + row;
-            if (mr < a.M) st16(yb + (size_t)mr * ycs + chunk * 16, v);
+            if (mr < a.M) {
+                st16(yb + (size_t)mr * ycs + chunk * 16, v);
+                if (a.up2) {   // wave-uniform: the same row to the 2 x 2 pixels of the upsampled view
+                    const int img = fast_div((int)mr, hw_o, a.magic_hw);
+                    const int rem = (int)mr - img * hw_o;
+                    const int oy = fast_div(rem, a.wo, a.magic_w), ox = rem - oy * a.wo;
+                    char* up = upb + ((size_t)(img * 2 * a.ho + 2 * oy) * (size_t)(2 * a.wo) + 2 * (size_t)ox) * up_px + chunk * 16;
+                    st16(up, v);
+                    st16(up + up_px, v);
+                    st16(up + up_row, v);
+                    st16(up + up_row + up_px, v);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
