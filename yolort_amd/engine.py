@@ -320,8 +320,11 @@ class Plan:
                     # chain kind: 0 none, 1 chained 1x1 over this launch's output, 2 + the second source's channels (cv3 over the concat) -- the
                     # candidate tiles differ per kind, so a table entry must not be applied across kinds
                     0 if chain is None else (1 if len(chain) < 3 or chain[2] is None else 2 + chain[2].c))
+            pinned = tile_table().get(tile_key_str(tkey, self.dtype), 0) if self.use_tile_table else 0
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
+            elif pinned >= 132 and os.environ.get("YOLORT_AMD_RULES_FIRST", "0") != "1":
+                d.tile = pinned   # an entry written by a tuner that knew the resident-weights kernels (tiles 132 ...): it has measured them against each other on this shape
             elif self.rs and self._rs_ok(d):
                 d.tile = 136 + d.sh   # row-streaming 3x3 (conv3x3_rs.hip): tile 137 (stride 1, 64 -> 64, no shortcut) / 138 (stride 2, 64 -> 128); YOLORT_AMD_RS=0 keeps tiles 133 / 134
             elif self.res3x3 and self._res3x3_ok(d):
@@ -333,7 +336,7 @@ class Plan:
             elif self.rw3 and self._rw3_ok(d):
                 d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
-                d.tile = tile_table().get(tile_key_str(tkey, self.dtype), 0)
+                d.tile = pinned
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
@@ -394,11 +397,11 @@ class Plan:
         if d.cin % 32 == 0 and d.kh * d.kw <= 32:
             cands = cands + [t + 50 for t in cands]   # the same tiles with the software-pipelined main loop (61..65, 71..77)
             cands = cands + ([69, 70] if d.cout_pad > 32 else []) + ([66, 68] if d.cout_pad >= 128 else [])   # 3-stage / 256-pixel tiles
-        if os.environ.get("YOLORT_AMD_TUNE_TP", "1") != "0" and d.out_dtype == d.dtype and d.y2_mode == 0 and chain is None and d.cin % 32 == 0 and d.kh * d.kw <= 32 and \
-                d.k_pad == d.kh * d.kw * d.cin:
+        if os.environ.get("YOLORT_AMD_TUNE_TP", "1") != "0" and d.out_dtype == d.dtype and d.y2_mode in (0, 1) and chain is None and d.cin % 32 == 0 and d.kh * d.kw <= 32 and \
+                d.k_pad == d.kh * d.kw * d.cin:   # (y2_mode 1, round 4: the row-transposed stores also write the upsampled copy, as whole rows)
             # row-transposed-store forms of tiles 12 / 21 / 66 / 61 / 71 and of the 8-wave implicit GEMM (141-145, 151-155): bit-identical
             # to their base tiles (tests/test_c3_fused_gpu.py, tests/test_hipsim_kernels.py), offered to the tuner since round 3
-            cands = cands + [t for t, base in ((141, 12), (142, 21), (143, 66), (144, 61), (145, 71)) if base in cands]
+            cands = cands + [t for t, base in ((141, 12), (142, 21), (143, 66), (144, 61), (145, 71)) if base in cands or d.y2_mode == 1]
             cands = cands + ([155] if d.cout_pad > 128 else []) + ([151] if d.cout_pad > 64 else []) + ([152] if 32 < d.cout_pad <= 128 else [])
         if d.kh == 1 and d.kw == 1 and d.sh == 1 and d.sw == 1 and d.cin % 32 == 0 and d.cin <= 128 and d.k_pad == d.cin and d.out_dtype == d.dtype and d.y2_mode == 0 and d.cout % 32 == 0:
             # streaming 1x1 kernel (conv1x1_stream.hip): variant = cout tiles of 32 per wave; a split / chained conv fixes the block width
