@@ -555,6 +555,23 @@ def main():
     excl = {k: _elapsed(v) for k, v in yolo.bracket.items()}
     yolo.bracket = None
     mean = lambda v: (sum(v) / len(v)) if v else 0.0  # noqa: E731
+    # the host's submit path in SERVING mode (frozen weights + the conv stack as one hipGraph launch): a secondary measurement, the headline runs the defaults
+    serving = None
+    if rank == 0 and world == 1:
+        g0 = yolo.use_graph
+        model.freeze_weights(True)
+        yolo.use_graph = True
+        run_steps(3)
+        torch.cuda.synchronize()
+        host["enqueue"] = 0.0
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        serving = {"host_enqueue_ms_per_step": round(host["enqueue"] / args.steps * 1e3, 4), "images_per_s": round(args.batch * args.steps / el, 1),
+                   "mode": "YOLOv5.freeze_weights() + hipGraph replay of the conv stack (YOLORT_AMD_GRAPH=1)"}
+        model.freeze_weights(False)
+        yolo.use_graph = g0
     dyn = None
     if rank == 0 and world == 1 and args.shapes == "fixed" and not args.no_cpu_baseline:
         # secondary measurement ("<config>dyn"): the same model on a stream of the 8 cycled image sizes of SURVEY 8d, scaled to this config's
@@ -650,7 +667,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
                        "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
-                       "gather_second_rounds_rank0": second_rounds[0], "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
+                       "gather_second_rounds_rank0": second_rounds[0], "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4), "serving_mode_rank0": serving,
                        "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                        "candidates_per_step_rank0": n_cand, "records_sorted_per_step_rank0": n_cand_sorted, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
             # `frac` is the PER-LAYER fraction SURVEY.md 8d prescribes (sum over the conv launches of max(flops / MFMA peak, bytes / HBM peak),

@@ -214,6 +214,34 @@ def test_cpp_operator_registration_for_libtorch_consumers(dev):
     assert r.returncode == 0 and "CPP_OP_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
 
 
+def test_freeze_weights_serving_mode(dev):
+    """YOLOv5.freeze_weights(): the plan key keeps the signature taken at the call (no per-batch walk over every tensor's version) -- identical detections, graph replay
+    included; after freeze_weights(False) an in-place weight update is seen again (a new plan, other detections)"""
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    m = YOLOv5(arch=arch, size=(320, 320), score_thresh=0.3)
+    m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+    m = m.to(dev).half().eval()
+    imgs = [im.to(dev).half() for im in synth_images(2, 320, 320, seed=61)]
+    base = [_np(d) for d in m(imgs)]
+    m.freeze_weights()
+    m.model.use_graph = True
+    for _ in range(3):
+        got = [_np(d) for d in m(imgs)]
+        for a, b in zip(base, got):
+            assert all(np.array_equal(a[k], b[k]) for k in a)
+    n_plans = sum(len(r) for r in m.model._ring.values())
+    with torch.no_grad():
+        m.model.head.head[0].bias.add_(0.5)          # frozen: the promise is the caller's, the cached plan (old packed weights) keeps serving
+    got = [_np(d) for d in m(imgs)]
+    assert all(np.array_equal(a[k], b[k]) for a, b in zip(base, got) for k in a) and sum(len(r) for r in m.model._ring.values()) == n_plans
+    m.freeze_weights(False)
+    m.model.use_graph = False
+    got = [_np(d) for d in m(imgs)]                  # unfrozen: the update is part of the key again
+    assert any(len(a["scores"]) != len(b["scores"]) or not np.array_equal(a["scores"], b["scores"]) for a, b in zip(base, got))
+
+
 def test_two_fresh_processes_return_bit_identical_detections(dev):
     """tiles come from the pinned table (yolort_amd/data/tiles_gfx950.json) or the library heuristic, never from timing at plan
     build (YOLORT_AMD_AUTOTUNE is opt-in), so the K accumulation order -- and every detection bit -- is the same in every process"""

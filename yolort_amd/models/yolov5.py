@@ -39,6 +39,11 @@ class YOLOv5(nn.Module):
         self.transform = YOLOTransform(size[0], size[1], size_divisible=size_divisible, fixed_shape=fixed_shape, fill_color=fill_color)
         self._has_warned = False
 
+    def freeze_weights(self, frozen: bool = True) -> "YOLOv5":
+        """see YOLO.freeze_weights (serving mode: the plan key stops re-reading every tensor's version per batch)"""
+        self.model.freeze_weights(frozen)
+        return self
+
     def set_compute_dtype(self, dtype: torch.dtype) -> "YOLOv5":
         """see YOLO.set_compute_dtype (torch.float32 = fp32 parity mode for fp32-parameter models)"""
         self.model.set_compute_dtype(dtype)
