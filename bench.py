@@ -283,7 +283,8 @@ def conditioned_parity(args, dev):
     gold = os.path.join(ROOT, "tests", "golden")
     if tag is None or not os.path.exists(os.path.join(gold, f"cond_{tag}.npz")):
         return None
-    tol = {"s": (0.98, 1e-2), "l6": (0.98, 1e-2), "n": (0.95, 3e-2), "m": (0.90, 6e-2)}[tag]
+    # stated 16-bit tolerances (tests/test_golden_gpu.py); yolov5l6: none is stated -- the reference's own fp16 run pairs 6 of the golden's 27 detections -- the generous pairing is reported
+    tol = {"s": (0.98, 1e-2), "l6": (0.5, 0.1), "n": (0.95, 3e-2), "m": (0.90, 6e-2)}[tag]
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     out = {}
@@ -313,7 +314,7 @@ def conditioned_parity(args, dev):
                 blk[name] = direct_checks(ref, got, thr, score_eps=1e-4, iou_min=1 - 1e-3)
             else:
                 c = direct_checks(ref, got, thr, score_eps=tol[1], iou_min=tol[0])
-                c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": tol[1]}
+                c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": tol[1]} if tag != "l6" else None
                 c["map_vs_ref_50_95"] = coco_ap(ref, got)
                 g = direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)   # the generous pairing the reference's own 16-bit band was measured with
                 c["distance_from_fp32_reference"] = {"paired": g["paired"], "of": g["ref_dets"], "iou_deficit": round(1.0 - g["min_iou"], 6), "max_dscore": g["max_dscore"]}

@@ -358,20 +358,23 @@ def ref16_golden(kind, tag):
 # placed in a GAP of the reference's own score list, so that no detection is "near the cut" and a 16-bit evaluation has to reproduce every
 # single one (the conditioned workload's scores all lie within a few hundredths of the threshold).
 # ---------------------------------------------------------------------------------------------------------------------------
-def spread_evaluate(arch, seed, thr_range=(0.3, 0.8), verbose=True):
+def spread_evaluate(arch, seed, thr_range=(0.3, 0.8), verbose=True, variant="spread", min_dets=40):
+    """variant "spread": the spread recipe; variant "cond": the CONDITIONED recipe (round 3) evaluated the same way -- the threshold goes into a gap of the
+    reference's score list instead of sitting at 0.25 (yolov5l6: the spread recipe's gain-4 head is not reproducible in fp32 on the P6 network -- its fp64
+    run re-decides 30-100 detections, tests/golden/spread_l6_search.txt -- so its reference-made golden is a conditioned one with a gap threshold)"""
     import bench
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import COND_SIZE, conditioned_weights, spread_images
+    from yolort_amd.utils.synth import COND_SIZE, cond_images, conditioned_weights, spread_images
     S = COND_SIZE[arch]
     div = 64 if arch.endswith("6_r60") else 32
     kw = dict(size_divisible=64) if div == 64 else {}
-    sd = conditioned_weights(YOLOv5(arch=arch, size=(S, S), **kw).state_dict(), arch, seed, variant="spread")
-    imgs = spread_images(arch, seed)
+    sd = conditioned_weights(YOLOv5(arch=arch, size=(S, S), **kw).state_dict(), arch, seed, variant=variant)
+    imgs = spread_images(arch, seed) if variant == "spread" else cond_images(arch, seed)
     with torch.no_grad():
         low = _np_dets(_reference_model(arch, S, 0.15, sd).predict(imgs))     # everything down to 0.15: the score list the threshold is placed in
     pool = np.sort(np.concatenate([d["scores"] for d in low] + [np.asarray([0.15, 1.0], np.float32)]))
     # candidate thresholds: the middle of every gap of the pooled score list inside thr_range that keeps at least 40 detections above it; the widest one wins
-    gaps = [(float(b - a), float(0.5 * (a + b))) for a, b in zip(pool[:-1], pool[1:]) if thr_range[0] <= 0.5 * (a + b) <= thr_range[1] and int((pool >= b).sum()) - 1 >= 40]
+    gaps = [(float(b - a), float(0.5 * (a + b))) for a, b in zip(pool[:-1], pool[1:]) if thr_range[0] <= 0.5 * (a + b) <= thr_range[1] and int((pool >= b).sum()) - 1 >= min_dets]
     if not gaps:
         return {"arch": arch, "seed": seed, "dets": [len(d["scores"]) for d in low], "gap": 0.0}, None
     gap, thr = max(gaps)
@@ -393,7 +396,7 @@ def spread_evaluate(arch, seed, thr_range=(0.3, 0.8), verbose=True):
     for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):   # the reference's own 16-bit evaluation of this workload
         with torch.no_grad():
             own[name] = _band(ref, _np_dets32(_reference_model(arch, S, thr, sd, dt).predict([im.to(dt) for im in imgs])), thr)
-    ev = {"arch": arch, "seed": seed, "S": S, "thr": thr, "variant": "spread", "dets": [len(r["scores"]) for r in ref], "thr_gap": gap,
+    ev = {"arch": arch, "seed": seed, "S": S, "thr": thr, "variant": variant, "dets": [len(r["scores"]) for r in ref], "thr_gap": gap,
           "thr_margin": float(allsc.min() - thr) if len(allsc) else 0.0, "min_score_gap": sgap,
           "score_range": [float(allsc.min()), float(allsc.max())] if len(allsc) else None,
           "score_quartiles": [float(q) for q in np.quantile(allsc, [0.25, 0.5, 0.75])] if len(allsc) else None,
@@ -442,7 +445,37 @@ def spread_golden(arch, seeds=range(0, 40), force=False):
     raise RuntimeError(f"no usable seed for {arch} in {list(seeds)}")
 
 
+def cond_gap_golden(arch, seeds, force_last=True):
+    """the conditioned golden with its threshold in a gap of the reference's score list (`cond_<tag>.npz`, meta["thr"] instead of 0.25): the first seed whose fp32 / fp64 /
+    restatement runs agree exactly is committed; with `force_last` the last seed tried is committed whatever its margins are (recorded in the meta: VERDICT r3 item 2 --
+    a bounded search, then the best seed with its margins)"""
+    import subprocess
+    from yolort_amd.utils.synth import cond_bn_path
+    tag = COND_TAGS[arch]
+    seeds = list(seeds)
+    for n_, seed in enumerate(seeds):
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", f"--seed={seed}", arch], check=True, capture_output=True)
+        ev, ref = spread_evaluate(arch, seed, thr_range=(0.22, 0.5), variant="cond", min_dets=12)
+        n = len(ev.get("dets", []))
+        exact = "fp64" in ev and all(ev[k]["unexplained"] == 0 and ev[k]["at_cut"] == 0 and ev[k]["images_labels_equal"] == n for k in ("fp64", "oracle"))
+        if ref is not None and (exact or (force_last and n_ == len(seeds) - 1)):
+            ev["accepted_by"] = "exact fp32 / fp64 / restatement agreement" if exact else "forced: last seed of a bounded search, margins as recorded"
+            out = {"meta": json.dumps(ev)}
+            for i, r in enumerate(ref):
+                for k in ("boxes", "scores", "labels"):
+                    out[f"det{i}_{k}"] = r[k]
+            np.savez_compressed(os.path.join(HERE, f"cond_{tag}.npz"), **out)
+            print("conditioned gap golden", tag, "seed", seed, "thr", ev["thr"], "dets", ev["dets"], ev["accepted_by"], flush=True)
+            ref16_golden("cond", tag)
+            return seed
+        os.remove(cond_bn_path(arch, seed))
+    raise RuntimeError(f"no usable seed for {arch} in {seeds}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cond-gap":   # usage: cond-gap arch seed [seed ...]
+        cond_gap_golden(sys.argv[2], [int(a) for a in sys.argv[3:]])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "photo":
         if not os.path.exists(os.path.join(HERE, "bus.png")):
             photo_pngs()

@@ -116,11 +116,21 @@ def test_config5_yolov5l6_fp16_bs8_1280_k300_at_spec(dev):
     print(f"C5 at spec: candidates per image {n_cand} (HIP processed {n_cand_total} records after prefix selection), kept {[len(d['scores']) for d in dets]}")
     assert min(n_cand) >= 5000, n_cand                       # >= 5 k candidates / image ...
     assert all(len(d["scores"]) == 300 for d in dets)        # ... and 300 kept
-    # (1) sort + class-aware NMS + top-K at this crowding, given identical logits: exact
+    # (1) sort + class-aware NMS + top-K at this crowding, given identical logits: the same 300 detections.  On the most crowded image the scores saturate (0.99998...)
+    # and the hardware's exp2 / rcp and torch's CPU sigmoid round a few of them one unit in the last place apart, which permutes detections of (almost) equal score:
+    # the order is compared up to such ties (round 4: the re-tuned table changed the logits and with them which scores tie; profiles/r04p_c5_tie_case.txt)
     for i, (r, d) in enumerate(zip(ref_post, dets)):
-        np.testing.assert_array_equal(d["labels"].cpu().numpy(), r["labels"].numpy(), err_msg=f"image {i}")
-        np.testing.assert_allclose(d["scores"].cpu().numpy(), r["scores"].numpy(), rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(d["boxes"].cpu().numpy(), r["boxes"].numpy(), rtol=1e-5, atol=2e-3)   # 1280x1280 inputs: rescale is the identity
+        hl, hs, hb = d["labels"].cpu().numpy(), d["scores"].cpu().numpy(), d["boxes"].cpu().numpy()
+        rl, rs, rb = r["labels"].numpy(), r["scores"].numpy(), r["boxes"].numpy()
+        np.testing.assert_allclose(hs, rs, rtol=1e-5, atol=1e-6, err_msg=f"image {i}")       # the score SEQUENCE agrees (ties permute equal values)
+        used = np.zeros(len(rl), bool)
+        for j in range(len(hl)):   # every HIP detection is an oracle detection (label, box, score), at a position whose score is within two units in the last place
+            c = np.where((rl == hl[j]) & ~used & (np.abs(rs - hs[j]) <= 2.5e-7) & (np.abs(rb - hb[j]).max(axis=1) <= 2e-3))[0]
+            assert len(c) > 0, f"image {i}: detection {j} (label {hl[j]}, score {hs[j]}) has no counterpart"
+            k = c[np.argmin(np.abs(c - j))]
+            used[k] = True
+            assert k == j or abs(float(rs[k]) - float(rs[j])) <= 2.5e-7, f"image {i}: detection {j} sits at {k} in the oracle's order, beyond a score tie"
+        assert used.all()
     # (2) end to end against the fp32 oracle on two of the eight images (fp16-storage yardstick as in test_parity_gpu)
     sdf = {k: v.float() for k, v in sd.items()}
     with torch.no_grad():
