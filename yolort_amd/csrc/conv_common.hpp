@@ -75,6 +75,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// tuning aid (-DYMI_SETPRIO=n, never in the shipped build): raise the wave's issue priority around its MFMA groups so that the partner wave's DMA issue /
+// fragment reads fill the gaps instead of delaying the matrix pipe (measured: profiles/r04t_setprio.txt)
+#ifdef YMI_SETPRIO
+#define YMI_PRIO_HI() __builtin_amdgcn_s_setprio(YMI_SETPRIO)
+#define YMI_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define YMI_PRIO_HI() ((void)0)
+#define YMI_PRIO_LO() ((void)0)
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

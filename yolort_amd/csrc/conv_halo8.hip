@@ -221,10 +221,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
             } else if constexpr (sub - 1 < PW) {
                 if (issue_w) issue_w_piece(nkbase, ndy, std::integral_constant<int, sub - 1>{});
             }
+            YMI_PRIO_HI();
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(fw[sub & 1][i], fa[sub & 1][j], acc[i][j]);
+            YMI_PRIO_LO();
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage s before it reaches the next barrier
         H8_STAMP(6 + (chunk * 3 + dy) * 3);

@@ -196,10 +196,12 @@ __global__ __launch_bounds__(512, RING == 2 ? 2 : 1) void conv_igemm8_kernel(con
                 }
             }
             if (sub < 2 * subs_here) {
+                YMI_PRIO_HI();
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc[i][j] = Mfma<DT>::run(fw[sub & 1][i], fa[sub & 1][j], acc[i][j]);
+                YMI_PRIO_LO();
             }
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // done reading this stage before the next barrier

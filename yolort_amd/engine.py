@@ -171,6 +171,9 @@ class Plan:
         self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
         # Bottleneck j's 3x3 carries Bottleneck j+1's 1x1 in its epilogue (8-wave halo kernel, 8 x 1 waves: the outputs a wave holds are the 1x1's
         # activation fragments): one launch less per Bottleneck after the first
+        # opt-in: the same chain at hidden width 128 (the 40x40 C3s of yolov5s); value = the tile that carries it: 116 (8 x 1 waves of 32 px x 128 couts), 78 / 79 (4-wave
+        # pixel-major tiles).  Measured equal or slower than the two launches (profiles/r03*, r04t_chain128.txt): the chained epilogue reads the 32 KiB of weights per wave from L2
+        self.chain128 = int(os.environ.get("YOLORT_AMD_CHAIN128", "0"))
         self.chain_next = os.environ.get("YOLORT_AMD_CHAIN_NEXT", "0")   # opt-in: C2 0 ... +2.5 % depending on the box, C5 -0.7 % (profiles/r03u, r03w); "0" off, "1" every hidden width the kernel takes (32 / 64 / 128), "128": only that width
         self.chain_next = False if self.chain_next == "0" else (True if self.chain_next == "1" else int(self.chain_next))
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
@@ -337,6 +340,8 @@ class Plan:
                 d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
                 d.tile = pinned
+        if d.tile == 0 and chain is not None and self.chain128 and (split if out2 is not None else pc.cout) == 128 and (len(chain) < 3 or chain[2] is None):
+            d.tile = self.chain128
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
@@ -414,7 +419,7 @@ class Plan:
             # 8-wave implicit GEMM with 64-deep steps (conv_igemm8.hip); a chained 1x1 needs pixel-major waves of its K1 width
             if chain is not None:
                 k1 = d.cout_split if d.cout_split > 0 else d.cout
-                cands = cands + ([114] if k1 == 32 else ([113] if k1 == 64 else []))
+                cands = cands + ([114] if k1 == 32 else ([113] if k1 == 64 else ([116] if k1 == 128 else [])))
             else:
                 cands = cands + ([114] if d.cout_pad <= 32 else ([112, 113] if d.cout_pad <= 64 else ([111, 112, 116] if d.cout_pad <= 128 else [111, 115, 112])))
                 # (tiles 117-119 = 111 / 116 / 112 with a three-deep stage ring: measured equal to the two-deep ring on every
