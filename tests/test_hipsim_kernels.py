@@ -625,15 +625,18 @@ def _sim_letterbox(sim, imgs, size, out_dtype, c_out=4, div=32):
     return out, sizes
 
 
-@pytest.mark.parametrize("kernel", ["default", "pixel", "tile1", "1", "4"])
+@pytest.mark.parametrize("kernel", ["default", "pixel", "tile1", "1", "4", "dma8", "dma4", "dma8+3blocks", "dma4+1block", "d8", "d4"])
 def test_letterbox_kernels_vs_oracle(sim, kernel, monkeypatch):
     """csrc/preproc_pool.hip on the simulator against the oracle's letterbox (reference transform.py:53-97, 297-330): every kernel variant,
     the rounding-trap shapes, fp32 / fp16 output, uint8 planar and interleaved input"""
     from oracle import yolov5_oracle as O
     from yolort_amd.utils.synth import synth_images
     monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
+    monkeypatch.delenv("YOLORT_AMD_LB_BLOCKS", raising=False)
     if kernel != "default":
-        monkeypatch.setenv("YOLORT_AMD_LETTERBOX", kernel)
+        monkeypatch.setenv("YOLORT_AMD_LETTERBOX", kernel.split("+")[0])
+    if "+" in kernel:   # the persistent kernel with few blocks: every block walks several tiles (both staging buffers, tiles of different images)
+        monkeypatch.setenv("YOLORT_AMD_LB_BLOCKS", kernel.split("+")[1][0])
     shapes = [(135, 101), (60, 80), (90, 160), (47, 63), (100, 37), (81, 60)]
     imgs = [synth_images(1, h, w, seed=h + w)[0] for h, w in shapes]
     ref, sizes = O.letterbox(imgs, 96, 96, 32)
@@ -657,7 +660,7 @@ def test_letterbox_tile_whose_columns_map_to_one_uint8_source_column(sim, monkey
     from yolort_amd._lib import dtype_code
     g = torch.Generator().manual_seed(5)
     outs = {}
-    for knob in ("default", "pixel"):
+    for knob in ("default", "pixel", "dma8"):
         monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
         if knob != "default":
             monkeypatch.setenv("YOLORT_AMD_LETTERBOX", knob)
@@ -668,8 +671,8 @@ def test_letterbox_tile_whose_columns_map_to_one_uint8_source_column(sim, monkey
             out = torch.full((1, hb, wb, 4), 7.0, dtype=torch.float32)
             _check(sim, sim.ymi_letterbox(ptrs, geom, 1, dtype_code(torch.uint8), out.data_ptr(), hb, wb, 4, dtype_code(torch.float32), C.c_float(114.0), None))
             outs.setdefault(knob, []).append(out)
-    for a, b in zip(outs["default"], outs["pixel"]):
-        assert torch.equal(a, b)
+    for a, b, c in zip(outs["default"], outs["pixel"], outs["dma8"]):
+        assert torch.equal(a, b) and torch.equal(c, b)
 
 
 def test_letterbox_identity_sizes_are_exact(sim):

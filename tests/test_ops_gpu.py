@@ -528,7 +528,7 @@ def test_letterbox_vs_oracle(dev):
     assert (nt8.nchw().float().cpu() - ref8).abs().max().item() <= 5e-5
 
 
-@pytest.mark.parametrize("kernel", ["default", "1", "2", "4", "tile1", "2+cg2", "4+cg2", "1+cg2"])
+@pytest.mark.parametrize("kernel", ["default", "1", "2", "4", "tile1", "2+cg2", "4+cg2", "1+cg2", "dma8", "dma4", "dma8+b7", "dma4+b3", "d8", "d4"])
 @pytest.mark.parametrize("in_dtype,hwc", [(torch.float16, False), (torch.bfloat16, False), (torch.float32, False), (torch.uint8, False), (torch.uint8, True)])
 def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kernel, monkeypatch):
     """round 2: the tiled, LDS-staged letterbox kernels (16-byte source loads, two pixels per store; the lean one with 1 / 2 / 4
@@ -537,9 +537,12 @@ def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kern
     the reference"""
     monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
     monkeypatch.delenv("YOLORT_AMD_LB_CG", raising=False)
+    monkeypatch.delenv("YOLORT_AMD_LB_BLOCKS", raising=False)
     if kernel != "default":
         monkeypatch.setenv("YOLORT_AMD_LETTERBOX", kernel.split("+")[0])
         monkeypatch.setenv("YOLORT_AMD_LB_CG", "2" if kernel.endswith("cg2") else "1")
+        if "+b" in kernel:   # the persistent DMA-staged kernel with a handful of blocks: each walks many tiles of several images through both staging buffers
+            monkeypatch.setenv("YOLORT_AMD_LB_BLOCKS", kernel.split("+b")[1])
     from yolort_amd.engine import View
     from yolort_amd.models.transform import YOLOTransform
     from yolort_amd.utils.synth import synth_images
