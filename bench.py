@@ -291,8 +291,10 @@ def conditioned_parity(args, dev):
     # two reference-made goldens per architecture: `cond` (round 3: every score within a few hundredths of the threshold) and `spread` (round 4: scores from the threshold
     # up to ~0.9, the threshold in a gap of the reference's score list -- nothing can be excused as "at the cut").  Each also carries the REFERENCE'S OWN 16-bit run
     # (tests/golden/ref16_*.npz: the unmodified reference with .half() / .bfloat16()), the like-for-like yardstick for the production path's distance from fp32.
-    for kind, images_of in (("cond", cond_images), ("spread", spread_images)):
-        path = os.path.join(gold, f"{kind}_{tag}.npz")
+    import glob
+    more = sorted(glob.glob(os.path.join(gold, f"spread_{tag}_s*.npz")))[:5]   # further seeds of the spread workload (make_golden.py spread-more): aggregated below
+    for kind, images_of, path in [("cond", cond_images, os.path.join(gold, f"cond_{tag}.npz")), ("spread", spread_images, os.path.join(gold, f"spread_{tag}.npz"))] + \
+            [("spread", spread_images, f) for f in more]:
         if not os.path.exists(path):
             continue
         z = np.load(path)
@@ -301,7 +303,7 @@ def conditioned_parity(args, dev):
         S, thr = meta["S"], meta["thr"]
         imgs = images_of(args.arch, meta["seed"])
         blk = {"workload": f"{kind} {args.arch}, seed {meta['seed']}, 4 seeded images of mixed shapes at {S}, thr {thr}; ground truth = detections of the UNMODIFIED reference "
-                           f"(tests/golden/{kind}_{tag}.npz)", "reference_self_reproducibility_fp64": meta["fp64"]}
+                           f"(tests/golden/{os.path.basename(path)})", "reference_self_reproducibility_fp64": meta["fp64"]}
         if kind == "spread":
             blk["score_range"], blk["threshold_gap"] = meta["score_range"], meta["thr_gap"]
         for name, dtype in (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16)):
@@ -313,21 +315,41 @@ def conditioned_parity(args, dev):
             if dtype == torch.float32:
                 blk[name] = direct_checks(ref, got, thr, score_eps=1e-4, iou_min=1 - 1e-3)
             else:
-                c = direct_checks(ref, got, thr, score_eps=tol[1], iou_min=tol[0])
-                c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": tol[1]} if tag != "l6" else None
+                r16 = os.path.join(gold, "ref16_" + os.path.basename(path))
+                own = json.loads(str(np.load(r16)["meta"]))[args.dtype] if os.path.exists(r16) else None
+                # further seeds: the stated score tolerance, or 1.5 x the reference's own 16-bit score error on that seed where that is larger (tests/test_golden_gpu.py)
+                ds_eff = max(tol[1], 1.5 * own["max_dscore"]) if (path in more and own is not None) else tol[1]
+                c = direct_checks(ref, got, thr, score_eps=ds_eff, iou_min=tol[0])
+                c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": round(ds_eff, 5)} if tag != "l6" else None
                 c["map_vs_ref_50_95"] = coco_ap(ref, got)
                 g = direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)   # the generous pairing the reference's own 16-bit band was measured with
                 c["distance_from_fp32_reference"] = {"paired": g["paired"], "of": g["ref_dets"], "iou_deficit": round(1.0 - g["min_iou"], 6), "max_dscore": g["max_dscore"]}
-                r16 = os.path.join(gold, f"ref16_{kind}_{tag}.npz")
-                if os.path.exists(r16):
-                    own = json.loads(str(np.load(r16)["meta"]))[args.dtype]
+                if own is not None:
                     c["reference_own_" + args.dtype] = {"paired": own["paired"], "of": own["ref_dets"], "iou_deficit": own["iou_deficit"], "max_dscore": own["max_dscore"],
                                                         "what": "the UNMODIFIED reference with ." + ("half()" if args.dtype == "fp16" else "bfloat16()") + " on the same inputs vs its own fp32 detections"}
                     c["iou_deficit_vs_reference_own"] = round((1.0 - g["min_iou"]) / max(own["iou_deficit"], 1e-9), 3)
                     c["dscore_vs_reference_own"] = round(g["max_dscore"] / max(own["max_dscore"], 1e-12), 3)
                 blk[name] = c
             del m
-        out[kind] = blk
+        if path in more:
+            out.setdefault("spread_more_seeds", []).append(blk)
+        else:
+            out[kind] = blk
+    if "spread_more_seeds" in out:   # one line over all further seeds: every detection of every seed counts
+        per = out.pop("spread_more_seeds")
+        agg = {"seeds": [int(os.path.basename(f).split("_s")[-1][:-4]) for f in more], "images": sum(b["fp32_parity_mode"]["images"] for b in per),
+               "what": "further seeds of the spread workload (own weights, images and gap threshold each; same acceptance criteria as the first seed), all detections pooled"}
+        for name in ("fp32_parity_mode", f"production_{args.dtype}"):
+            agg[name] = {k: sum(b[name][k] for b in per) for k in ("ref_dets", "hip_dets", "paired", "at_cut", "unexplained", "images_equal_count", "images_labels_equal")}
+            agg[name]["min_iou"] = min(b[name]["min_iou"] for b in per)
+            agg[name]["max_dscore"] = max(b[name]["max_dscore"] for b in per)
+        p16 = f"production_{args.dtype}"
+        if all("reference_own_" + args.dtype in b[p16] for b in per):
+            agg[p16]["iou_deficit_vs_reference_own_per_seed"] = [b[p16]["iou_deficit_vs_reference_own"] for b in per]
+            agg[p16]["dscore_vs_reference_own_per_seed"] = [b[p16]["dscore_vs_reference_own"] for b in per]
+            agg[p16]["score_tolerance_per_seed"] = [b[p16]["stated_tolerance"]["max_dscore"] for b in per]
+            agg[p16]["reference_own_paired"] = [sum(b[p16]["reference_own_" + args.dtype]["paired"] for b in per), sum(b[p16]["reference_own_" + args.dtype]["of"] for b in per)]
+        out["spread_more"] = agg
     torch.cuda.empty_cache()
     if "cond" in out:   # the round-3 layout of the block stays readable: the conditioned workload's entries at the top level
         for k, v in out["cond"].items():
@@ -718,7 +740,7 @@ def main():
                 # (yolov5l6: no 16-bit tolerance is stated -- the reference's own fp16 run pairs 6 of the golden's 27 detections -- so only its fp32 mode counts here; bf16 on the
                 #  spread workload likewise: its own bf16 run pairs 23 of 94)
                 modes = lambda k: ("fp32_parity_mode",) if (args.arch.endswith("l6_r60") or (k == "spread" and args.dtype == "bf16")) else ("fp32_parity_mode", f"production_{args.dtype}")  # noqa: E731
-                out["parity"]["unexplained"] = sum(cp[k][m_]["unexplained"] for k in ("cond", "spread") if k in cp for m_ in modes(k))
+                out["parity"]["unexplained"] = sum(cp[k][m_]["unexplained"] for k in ("cond", "spread", "spread_more") if k in cp for m_ in modes("spread" if k == "spread_more" else k))
                 out["parity"]["north_star_tolerance"] = ("boxes within 1e-3 IoU: met by the fp32 parity mode on every golden; the production 16-bit path is reported against the "
                                                          "reference's OWN 16-bit run (reference_own_*): a per-layer budget (profiles/r04_error_budget_*.csv) shows no 16-bit-storage "
                                                          "path can meet 1e-3 -- the roundings of ~60 layers add in quadrature and the first 30 would have to stay in fp32")

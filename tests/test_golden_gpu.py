@@ -177,9 +177,15 @@ def test_conditioned_workload_16bit_path_meets_the_stated_tolerance(dev, tag, dt
 
 # ---- the SPREAD workload (round 4): reference scores from the threshold up to ~0.9, the threshold in a gap of the reference's score list ------------------
 SPREAD_TOL = {"s": (0.98, 1e-2), "m": (0.90, 6e-2)}   # the stated 16-bit tolerances of the conditioned workload, unchanged
+# further seeds of the spread workload (tests/golden/make_golden.py spread-more; VERDICT r3 weak 3: one seed of four images per architecture is thin): every
+# spread_<tag>_s<seed>.npz that is committed runs through the same two tests as the first seed -- own weights, own images, own gap threshold, same criteria
+SPREAD_MORE = sorted(os.path.basename(f)[len("spread_"):-len(".npz")] for f in __import__("glob").glob(os.path.join(GOLD, "spread_*_s*.npz")))
+# ... those that also meet the first seed's margin criterion (meta["strict_16bit"]: half the threshold gap >= the reference's own fp16 score error) take the
+# "pairs every detection" test; all of them take the fp32-mode test and the "no further than the reference's own 16-bit run" test
+SPREAD_MORE_STRICT = [t for t in SPREAD_MORE if json.loads(str(np.load(os.path.join(GOLD, f"spread_{t}.npz"))["meta"])).get("strict_16bit")]
 
 
-@pytest.mark.parametrize("tag", ["s", "m"])   # (yolov5l6: the gain-4 head is not reproducible in fp32 on the P6 network -- the reference's fp64 run re-decides 30-100 detections,
+@pytest.mark.parametrize("tag", ["s", "m"] + SPREAD_MORE)   # (yolov5l6: the gain-4 head is not reproducible in fp32 on the P6 network -- the reference's fp64 run re-decides 30-100 detections,
 def test_spread_workload_fp32_mode_reproduces_the_reference_exactly(dev, tag):   #  tests/golden/spread_l6_search.txt; its golden is the conditioned one with a gap threshold, cond_l6)
     from yolort_amd.utils.synth import spread_images
     meta, ref, _ = _golden("spread", tag)
@@ -210,7 +216,7 @@ def test_spread_workload_bf16_is_no_further_from_the_reference_than_its_own_bf16
         del m
 
 
-@pytest.mark.parametrize("tag,dtype", [("s", torch.float16)])
+@pytest.mark.parametrize("tag,dtype", [("s", torch.float16)] + [(t, torch.float16) for t in SPREAD_MORE_STRICT if t.startswith("s_")])
 def test_spread_workload_16bit_path_pairs_every_detection(dev, tag, dtype):
     """Nothing is excused here: the golden's threshold lies in a gap of the reference's score list (meta["thr_gap"]) and its scores spread over
     [thr, ~0.9], so `at the cut` cannot absorb a miss -- at least 95 % of the reference detections must be paired within the stated tolerance (fp16: all but at most one
@@ -220,7 +226,7 @@ def test_spread_workload_16bit_path_pairs_every_detection(dev, tag, dtype):
     meta, ref, _ = _golden("spread", tag)
     m = _model(meta, dev, dtype, "spread")
     got = [_np(d) for d in m.predict([im.to(dev).to(dtype) for im in spread_images(meta["arch"], meta["seed"])])]
-    iou_min, ds = SPREAD_TOL[tag]
+    iou_min, ds = SPREAD_TOL[tag.split("_")[0]]
     c = direct_checks(ref, got, meta["thr"], score_eps=ds, iou_min=iou_min)
     print(f"spread_{tag} 16-bit path, stated tolerance IoU >= {iou_min}, |dscore| <= {ds}:", c, "score range", meta["score_range"], "threshold gap", meta["thr_gap"])
     assert c["ref_dets"] >= 40
@@ -229,6 +235,24 @@ def test_spread_workload_16bit_path_pairs_every_detection(dev, tag, dtype):
     assert c["at_cut"] <= (0.02 if dtype == torch.float16 else 0.10) * (c["ref_dets"] + c["hip_dets"]), c
     assert c["min_iou"] >= iou_min and c["max_dscore"] <= ds, c
     _assert_no_further_than_the_reference_itself(ref, got, meta["thr"], _ref16("spread", tag, dtype), f"spread_{tag}")
+
+
+@pytest.mark.parametrize("tag", [t for t in SPREAD_MORE if t.startswith("s_")])
+def test_spread_more_seeds_fp16_path_is_no_further_from_the_reference_than_its_own_fp16_run(dev, tag):
+    """every further seed of the spread workload (reference-exact in fp32 / fp64, tests/golden/spread_s_more_search.txt) through the production fp16 path: worst IoU deficit and worst
+    score error at most 1.5 x those of the UNMODIFIED reference's own .half() run on the same inputs, every unpaired detection within that band of the threshold; and at least 95 % of the
+    reference's detections paired at IoU >= 0.98 (the stated box tolerance) with nothing unexplained"""
+    from yolort_amd.utils.synth import spread_images
+    meta, ref, _ = _golden("spread", tag)
+    m = _model(meta, dev, torch.float16, "spread")
+    got = [_np(d) for d in m.predict([im.to(dev).half() for im in spread_images(meta["arch"], meta["seed"])])]
+    own = _ref16("spread", tag, torch.float16)
+    iou_min, ds = SPREAD_TOL["s"]
+    ds = max(ds, 1.5 * own["max_dscore"])   # the stated score tolerance, or 1.5 x the reference's own fp16 score error on this seed where that is larger (seeds 2, 7, 8: 0.013-0.016)
+    c = direct_checks(ref, got, meta["thr"], score_eps=ds, iou_min=iou_min)
+    print(f"spread_{tag} fp16 path, tolerance IoU >= {iou_min}, |dscore| <= {ds:.4f}:", c, "threshold gap", meta["thr_gap"])
+    assert c["unexplained"] == 0 and c["paired"] >= 0.95 * c["ref_dets"] and c["min_iou"] >= iou_min, c
+    _assert_no_further_than_the_reference_itself(ref, got, meta["thr"], own, f"spread_{tag}")
 
 
 @pytest.mark.parametrize("tag", ["s"])
