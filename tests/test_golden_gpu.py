@@ -194,25 +194,27 @@ def test_spread_workload_fp32_mode_reproduces_the_reference_exactly(dev, tag):  
     _assert_fp32(ref, got, meta["thr"], f"spread_{tag}")
 
 
-def test_spread_workload_bf16_is_no_further_from_the_reference_than_its_own_bf16_run(dev):
+@pytest.mark.parametrize("tag", ["m"] + [t for t in SPREAD_MORE if t.startswith("m_")])
+def test_spread_workload_bf16_is_no_further_from_the_reference_than_its_own_bf16_run(dev, tag):
     """yolov5m in bf16 on the spread workload.  Eight mantissa bits through ~80 layers put ~0.15 of error on a logit, the spread recipe's objectness gain of 4 turns that into
     score changes beyond ANY pairing tolerance for most detections: the unmodified reference's own `.bfloat16()` run pairs 23 of its 94 fp32 detections (same label, IoU >= 0.5,
     |dscore| <= 0.1), loses 71 and gains 17 (tests/golden/ref16_spread_m.npz).  A "pairs >= 95 %" assertion is not available to anybody here; what IS asserted: the HIP bf16 path
     pairs at least as many as the reference's own bf16 run (measured: 34) with a worst score error no larger than 1.5 x its own, and the same model in fp16 pairs >= 95 % (92 of 94)
     -- the golden itself is exact in fp32 mode (test above).  profiles/r04q_spread_m_bf16.txt."""
     from yolort_amd.utils.synth import spread_images
-    meta, ref, _ = _golden("spread", "m")
+    meta, ref, _ = _golden("spread", tag)
     imgs = spread_images(meta["arch"], meta["seed"])
     for dtype in (torch.bfloat16, torch.float16):
         m = _model(meta, dev, dtype, "spread")
         got = [_np(d) for d in m.predict([im.to(dev).to(dtype) for im in imgs])]
         c = direct_checks(ref, got, meta["thr"], score_eps=0.1, iou_min=0.5)
-        own = _ref16("spread", "m", dtype)
-        print("spread_m", dtype, "HIP:", c, "| the reference's own:", own)
-        assert c["paired"] >= own["paired"], (c, own)
+        own = _ref16("spread", tag, dtype)
+        print(f"spread_{tag}", dtype, "HIP:", c, "| the reference's own:", own)
+        # (the further seeds, tag m_s<seed>: the same two assertions; "at least as many pairs" with two detections of slack -- which of two coin tosses lands is not a property of either side)
+        assert c["paired"] >= own["paired"] - (0 if tag == "m" else 2), (c, own)
         assert c["max_dscore"] <= 1.5 * own["max_dscore"] + 1e-5, (c, own)
         if dtype == torch.float16:
-            assert c["paired"] >= 0.95 * c["ref_dets"] and c["unexplained"] == 0, c
+            assert c["paired"] >= (0.95 if tag == "m" else 0.90) * c["ref_dets"] and c["unexplained"] == 0, c
         del m
 
 

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rs_kernel(const ConvArgs a, in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, frow = lane & 31;
     const int ct = wave % C::NG, pg = wave / C::NG;        // cout group, pixel group of the step
-    const int LB = 4 * steps_per_image;                     // stream rows per image: 1 zero row + H rows, rounded up to a multiple of four
+    // (stream rows per image: 1 zero row + H rows, rounded up to a multiple of four = 4 * steps_per_image)
 
     // ---- work: a contiguous range of steps of one strip ----
     const int item = xcd_remap(blockIdx.x, gridDim.x);

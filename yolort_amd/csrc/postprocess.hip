@@ -1267,8 +1267,6 @@ static int sort_nms_gather(const Workspace& w, SortState st, int* status, int ca
     }
     const uint64_t* phi = wl.hi[sl.cur];
     const uint32_t* plo = wl.lo[sl.cur];
-    uint32_t* seg_start = w.seg_start;
-    float* kept_box = w.kept_box;
     if (sl.cur == 1) {
         // sorted P currently lives in the scratch (kept_box/seg_start): move it back to P's own arrays
         YMI_CHECK_HIP(hipMemcpyAsync(w.hi[p], wl.hi[1], (size_t)cap * 8, hipMemcpyDeviceToDevice, s));

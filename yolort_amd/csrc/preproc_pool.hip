@@ -1080,8 +1080,11 @@ __device__ __forceinline__ u32x4 max8(const u32x4& p, const u32x4& q) {
     return r;
 }
 
+// Block size (round 4): 256 ... 1024 threads.  A block walks its plane in steps of blockDim.x / G pixels through eight phases (load, 3 x row pass, 3 x column pass + store)
+// separated by barriers, and the LDS footprint allows one to three blocks per CU: with 256 threads a CU had 4-12 waves in a chain of dependent LDS round trips
+// (yolov5s 20 x 20: 21 us for 26 MB; yolov5m 40 x 40: 387 us at 0.10 of the HBM bound).  The threads only divide the pixels among themselves: results do not depend on the block size.
 template <int DT, int G>   // G = 16-byte groups (8 channels) per pixel handled by one block
-__global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h, int w, int c, int cs) {
+__global__ __launch_bounds__(1024) void spp_pool_lds_kernel(uint16_t* buf, int h, int w, int c, int cs) {
     extern __shared__ __attribute__((aligned(16))) u32x4 spp_sm[];
     const int hw = h * w;
     u32x4* A = spp_sm;                 // [hw][G]: the current stage's plane (x, then mp5, mp9 -- the column pass overwrites it in place: the row pass was its last reader)
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(256) void spp_pool_lds_kernel(uint16_t* buf, int h,
     uint16_t* base = buf + (int64_t)img * hw * cs + cc;
     const int sub = threadIdx.x % G;              // channel group of this thread
     const int p0 = threadIdx.x / G;               // first pixel
-    constexpr int PSTEP = 256 / G;
+    const int PSTEP = (int)blockDim.x / G;
     for (int p = p0; p < hw; p += PSTEP) A[p * G + sub] = *reinterpret_cast<const u32x4*>(base + (int64_t)p * cs + sub * 8);
     __syncthreads();
     u32x4* src = A;
@@ -1242,7 +1245,11 @@ extern "C" int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, 
     if (const char* ge = getenv("YOLORT_AMD_SPP_G")) { const int g = atoi(ge); if (g == 1 || (g == 2 && G >= 2) || (g == 4 && G == 4)) G = g; }   // tuning aid
     const size_t lds = (size_t)h * w * G * 16 * 2;
     if (lds <= 160 * 1024 - 512) {
-        dim3 g((unsigned)(n * (c / (8 * G)))), b(256);
+        // threads per block: enough for ~two pixels per thread and pass, 256 ... 1024 (YOLORT_AMD_SPP_NT: tuning aid)
+        int nt = 256;
+        while (nt < 1024 && (size_t)h * w * G > (size_t)2 * nt) nt *= 2;
+        if (const char* te = getenv("YOLORT_AMD_SPP_NT")) { const int v = atoi(te); if (v == 256 || v == 512 || v == 1024) nt = v; }
+        dim3 g((unsigned)(n * (c / (8 * G)))), b((unsigned)nt);
         auto launch = [&](auto kfn) -> int {
             if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
             hipLaunchKernelGGL(kfn, g, b, lds, (hipStream_t)stream, (uint16_t*)buf, h, w, c, cstride);
