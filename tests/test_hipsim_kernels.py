@@ -270,7 +270,11 @@ def _run_conv(sim, dtype, tile, n, cin, cout, h, w, k, s, residual=False, seed=0
         r = torch.randn(n, cout, ho, wo, generator=g).to(dtype).float()
         ref = ref + r
         rb = Buf(n, ho, wo, cout, dtype, fill=r.permute(0, 2, 3, 1))
-    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc, yv, tile, k=k, pad=p, res=rb, stride=s))))
+    d = _conv_desc(xb, pc, yv, tile, k=k, pad=p, res=rb, stride=s)
+    if k > 1:
+        kt = pc.ktab(w, xb.cs)   # the im2col table of the general-tap kernels (cin % 32 != 0); the uniform-tap kernels ignore it
+        d.ktab = kt.data_ptr()
+    _check(sim, sim.sim_conv2d(C.byref(d)))
     got = yv.view().float().permute(0, 3, 1, 2)
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (tile, cin, cout, k, s)
