@@ -340,8 +340,8 @@ class Plan:
                 d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
                 d.tile = pinned
-        if d.tile == 0 and chain is not None and self.chain128 and (split if out2 is not None else pc.cout) == 128 and (len(chain) < 3 or chain[2] is None):
-            d.tile = self.chain128
+        if d.tile == 0 and chain is not None and getattr(self, "chain128", 0) and (split if out2 is not None else pc.cout) == 128 and (len(chain) < 3 or chain[2] is None):
+            d.tile = int(self.chain128)
         esz = 2
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
