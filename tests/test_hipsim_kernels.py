@@ -711,6 +711,20 @@ def test_spp_pool_and_upsample_exact(sim, spp_g, monkeypatch):
         g4 = b4.view().float().permute(0, 3, 1, 2)
         for i, k in enumerate((5, 9, 13)):
             assert torch.equal(g4[:, 32 * (i + 1): 32 * (i + 2)], F.max_pool2d(x4.float(), k, 1, k // 2)), f"40x40 maxpool{k} not exact"
+    # bfloat16 (round 4: the plane is held as order keys and reduced with packed unsigned maxima): negative values, zeros of both signs, repeated values, tiny and huge magnitudes
+    from yolort_amd._lib import YMI_BF16
+    xb = torch.randn(2, 32, 13, 21, generator=torch.Generator().manual_seed(9)) * torch.tensor([1e-30, 1.0, 3e4, 1e30]).repeat(8).view(1, 32, 1, 1)
+    xb[0, :, 3:6, 4:9] = 0.0
+    xb[0, :, 4, 5] = -0.0
+    xb[1, 5] = -xb[1, 5].abs() - 1.0          # an all-negative plane
+    xb = xb.to(torch.bfloat16)
+    bb = Buf(2, 13, 21, 128, torch.bfloat16)
+    bb.view()[..., :32] = xb.permute(0, 2, 3, 1)
+    _check(sim, sim.ymi_spp_pool(bb.ptr, 2, 13, 21, 32, 128, YMI_BF16, None))
+    gb = bb.view().float().permute(0, 3, 1, 2)
+    assert torch.equal(gb[:, :32], xb.float()), "the input slice is left as it was"
+    for i, k in enumerate((5, 9, 13)):
+        assert torch.equal(gb[:, 32 * (i + 1): 32 * (i + 2)], F.max_pool2d(xb.float(), k, 1, k // 2)), f"bf16 maxpool{k} not exact"
     up = Buf(2, 40, 34, 96, torch.float16)
     _check(sim, sim.ymi_upsample2x(buf.ptr, 256, 2, 20, 17, 64, up.slice_c(32, 64).ptr, 96, YMI_F16, None))
     gu = up.view().float().permute(0, 3, 1, 2)

@@ -504,6 +504,22 @@ def test_spp_pool_and_upsample_exact(dev, spp_g, monkeypatch):
     gu = up.as_tensor().float().cpu().permute(0, 3, 1, 2)
     assert torch.equal(gu[:, 32:96], F.interpolate(xf, scale_factor=2.0, mode="nearest"))
     assert gu[:, :32].abs().max().item() == 0
+    # bfloat16 (round 4: order keys + packed unsigned maxima): negative values, zeros of both signs, magnitudes over sixty orders, a 40 x 40 map (yolov5m's shape)
+    for (n, c, h, w) in ((2, 32, 13, 21), (1, 96, 40, 40)):
+        xb = torch.randn(n, c, h, w, generator=g) * torch.tensor([1e-30, 1.0, 3e4, 1e30]).repeat(c // 4).view(1, c, 1, 1)
+        xb[0, :, 3:6, 4:9] = 0.0
+        xb[0, :, 4, 5] = -0.0
+        xb[-1, 5] = -xb[-1, 5].abs() - 1.0
+        xb = xb.to(torch.bfloat16)
+        pb = engine.Plan(dev, torch.bfloat16)
+        bb = pb.alloc(n, h, w, 4 * c, zero=True)
+        bb.slice_c(0, c).as_tensor().copy_(_nhwc(xb).to(dev))
+        pb.spp_pool(bb, c)
+        pb.run()
+        gb = bb.as_tensor().float().cpu().permute(0, 3, 1, 2)
+        assert torch.equal(gb[:, :c], xb.float())
+        for i, k in enumerate((5, 9, 13)):
+            assert torch.equal(gb[:, c * (i + 1): c * (i + 2)], F.max_pool2d(xb.float(), k, 1, k // 2)), f"bf16 maxpool{k} not exact ({h}x{w})"
 
 
 def test_letterbox_vs_oracle(dev):

@@ -1068,14 +1068,45 @@ __device__ __forceinline__ u32x4 max8(const u32x4& p, const u32x4& q) {
             r[e] = me;
         }
     } else {
+        // bfloat16 has no packed max: the plane is held in LDS as ORDER KEYS (spp_key16: sign-magnitude -> unsigned order, two per dword) and the maximum of two
+        // keys is `v_pk_max_u16` -- one instruction per dword like the fp16 form.  (Round 3 converted both operands to fp32, compared and re-selected per element:
+        // ~14 VALU per dword, 1 300 per 8-channel group over the three stages -- yolov5m's 40 x 40 pool was bound by exactly that: 300 us for 315 MB.)
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float a0 = bf2f((uint16_t)(p[e] & 0xffff)), a1 = bf2f((uint16_t)(p[e] >> 16));
-            const float b0 = bf2f((uint16_t)(q[e] & 0xffff)), b1 = bf2f((uint16_t)(q[e] >> 16));
-            const uint32_t lo = fmaxf(a0, b0) == a0 ? (p[e] & 0xffff) : (q[e] & 0xffff);
-            const uint32_t hi = fmaxf(a1, b1) == a1 ? (p[e] >> 16) : (q[e] >> 16);
-            r[e] = lo | (hi << 16);
+            const uint32_t pe = p[e], qe = q[e];
+            us2 x, y;
+            __builtin_memcpy(&x, &pe, 4);
+            __builtin_memcpy(&y, &qe, 4);
+            const us2 m = __builtin_elementwise_max(x, y);   // v_pk_max_u16
+            uint32_t me;
+            __builtin_memcpy(&me, &m, 4);
+            r[e] = me;
         }
+    }
+    return r;
+}
+// bfloat16 <-> order key, two values per dword: negative values have all bits flipped, non-negative ones the sign bit set -- unsigned comparison of the keys is the
+// numerical order of the values (-0 below +0; the pool never sees a NaN).  fp16 planes stay as they are (DT-dispatched no-ops).
+template <int DT>
+__device__ __forceinline__ u32x4 spp_key16(const u32x4& v) {
+    if constexpr (DT == YMI_F16) return v;
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t neg = ((v[e] >> 15) & 0x00010001u) * 0xffffu;   // 0xffff in every half whose sign bit is set
+        r[e] = v[e] ^ (neg | 0x80008000u);
+    }
+    return r;
+}
+template <int DT>
+__device__ __forceinline__ u32x4 spp_unkey16(const u32x4& k) {
+    if constexpr (DT == YMI_F16) return k;
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t pos = ((k[e] >> 15) & 0x00010001u) * 0xffffu;   // keys of non-negative values have the top bit set
+        r[e] = k[e] ^ ((~pos) | 0x80008000u);
     }
     return r;
 }
@@ -1095,7 +1126,7 @@ __global__ __launch_bounds__(1024) void spp_pool_lds_kernel(uint16_t* buf, int h
     const int sub = threadIdx.x % G;              // channel group of this thread
     const int p0 = threadIdx.x / G;               // first pixel
     const int PSTEP = (int)blockDim.x / G;
-    for (int p = p0; p < hw; p += PSTEP) A[p * G + sub] = *reinterpret_cast<const u32x4*>(base + (int64_t)p * cs + sub * 8);
+    for (int p = p0; p < hw; p += PSTEP) A[p * G + sub] = spp_key16<DT>(*reinterpret_cast<const u32x4*>(base + (int64_t)p * cs + sub * 8));
     __syncthreads();
     u32x4* src = A;
     u32x4* dst = A;
@@ -1113,7 +1144,7 @@ __global__ __launch_bounds__(1024) void spp_pool_lds_kernel(uint16_t* buf, int h
             const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 > h - 1 ? h - 1 : y + 2;
             u32x4 m = B[(y0 * w + x) * G + sub];
             for (int yy = y0 + 1; yy <= y1; ++yy) m = max8<DT>(m, B[(yy * w + x) * G + sub]);
-            *reinterpret_cast<u32x4*>(base + (int64_t)p * cs + (stage + 1) * c + sub * 8) = m;
+            *reinterpret_cast<u32x4*>(base + (int64_t)p * cs + (stage + 1) * c + sub * 8) = spp_unkey16<DT>(m);
             dst[p * G + sub] = m;
         }
         __syncthreads();
