@@ -649,6 +649,14 @@ def test_letterbox_kernels_vs_oracle(sim, kernel, monkeypatch):
     assert (got[..., :3].permute(0, 3, 1, 2) - ref).abs().max().item() <= 5e-5 and got[..., 3].abs().max().item() == 0
     got16, _ = _sim_letterbox(sim, imgs, 96, torch.float16)
     assert (got16[..., :3].float().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-3
+    gotb, _ = _sim_letterbox(sim, imgs, 96, torch.bfloat16)   # bf16 output: pair conversion in the tiled kernels, software rounding in the per-pixel one -- the same bits
+    assert (gotb[..., :3].float().permute(0, 3, 1, 2) - ref).abs().max().item() <= 8e-3
+    monkeypatch.setenv("YOLORT_AMD_LETTERBOX", "pixel")
+    refb, _ = _sim_letterbox(sim, imgs, 96, torch.bfloat16)
+    assert torch.equal(gotb.view(torch.int16), refb.view(torch.int16))
+    monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("YOLORT_AMD_LETTERBOX", kernel.split("+")[0])
     u8 = [(im * 255).round().to(torch.uint8) for im in imgs]
     ref8, _ = O.letterbox([u.float() / 255.0 for u in u8], 96, 96, 32)
     got8, _ = _sim_letterbox(sim, u8, 96, torch.float32)

@@ -546,7 +546,8 @@ def test_letterbox_vs_oracle(dev):
 
 @pytest.mark.parametrize("kernel", ["default", "1", "2", "4", "tile1", "2+cg2", "4+cg2", "1+cg2", "dma8", "dma4", "dma8+b7", "dma4+b3", "d8", "d4"])
 @pytest.mark.parametrize("in_dtype,hwc", [(torch.float16, False), (torch.bfloat16, False), (torch.float32, False), (torch.uint8, False), (torch.uint8, True)])
-def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kernel, monkeypatch):
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16])   # (bf16: the tiled kernels round with v_cvt_pk_bf16_f32, the per-pixel kernel in software)
+def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kernel, out_dtype, monkeypatch):
     """round 2: the tiled, LDS-staged letterbox kernels (16-byte source loads, two pixels per store; the lean one with 1 / 2 / 4
     rows per wave and the first tiled kernel) must reproduce the per-pixel kernel bit for bit -- up / down scaling, odd sizes,
     rows that are not 16-byte aligned, every input type; the 8-channel output form still takes the per-pixel kernel and serves as
@@ -579,7 +580,7 @@ def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kern
         (hb, wb), sizes, pads = tr.geometry([tr.image_hw(im) for im in imgs])
         outs = []
         for c_out in (4, 8):
-            t = torch.full((len(imgs) * hb * wb * c_out,), 7.0, device=dev, dtype=torch.float16)
+            t = torch.full((len(imgs) * hb * wb * c_out,), 7.0, device=dev, dtype=out_dtype)
             v = View(t, 0, len(imgs), hb, wb, c_out, c_out)
             tr.letterbox_into(imgs, v, sizes, pads)
             torch.cuda.synchronize()

@@ -84,6 +84,23 @@ __device__ __forceinline__ float load_elem(const void* p, int64_t i) {
     else if constexpr (DT == YMI_F32) return ((const float*)p)[i];
     else return (float)((const uint8_t*)p)[i] / 255.0f;   // YMI_U8 / YMI_U8_HWC: true division, like the reference's `read_image(...) / 255.0`
 }
+// two fp32 values -> one dword of two 16-bit values with the hardware pair conversion (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: round-to-nearest-even like f2h / f2bf;
+// the software f2bf is 6-7 VALU instructions per value)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int DT>
+__device__ __forceinline__ uint32_t cvt_pk16(f32x2 v) {
+    uint32_t u;
+    if constexpr (DT == YMI_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 h = __builtin_convertvector(v, h2);
+        __builtin_memcpy(&u, &h, 4);
+    } else {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const b2 b = __builtin_convertvector(v, b2);
+        __builtin_memcpy(&u, &b, 4);
+    }
+    return u;
+}
 template <int DT>
 __device__ __forceinline__ uint16_t to16(float v) {
     if constexpr (DT == YMI_F16) return f2h(v);

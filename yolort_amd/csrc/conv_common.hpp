@@ -242,21 +242,7 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
 // (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round-to-nearest-even like the scalar path) and one 32-bit per-lane offset per
 // pixel group against wave-uniform base pointers.  Same operations in the same order as the general path: bit-identical.
 // ---------------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int DT>
-__device__ __forceinline__ uint32_t cvt_pk16(f32x2 v) {
-    uint32_t u;
-    if constexpr (DT == YMI_F16) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 h = __builtin_convertvector(v, h2);
-        __builtin_memcpy(&u, &h, 4);
-    } else {
-        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-        const b2 b = __builtin_convertvector(v, b2);
-        __builtin_memcpy(&u, &b, 4);
-    }
-    return u;
-}
+// (f32x2 / cvt_pk16: the hardware pair conversion, common.hpp)
 template <int DT>
 __device__ __forceinline__ f32x2 unpack16(uint32_t u) {
     f32x2 r = {from16<DT>((uint16_t)(u & 0xffffu)), from16<DT>((uint16_t)(u >> 16))};

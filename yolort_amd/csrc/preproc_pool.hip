@@ -458,10 +458,10 @@ __global__ __launch_bounds__(256) void letterbox_tile2_kernel(const LetterboxTil
         } else {
             uint16_t* op = (uint16_t*)a.out + o;
             u32x4 q;
-            q[0] = (uint32_t)to16<ODT>(v[0][0]) | ((uint32_t)to16<ODT>(v[0][1]) << 16);
-            q[1] = (uint32_t)to16<ODT>(v[0][2]);
-            q[2] = (uint32_t)to16<ODT>(v[1][0]) | ((uint32_t)to16<ODT>(v[1][1]) << 16);
-            q[3] = (uint32_t)to16<ODT>(v[1][2]);
+            q[0] = cvt_pk16<ODT>(f32x2{v[0][0], v[0][1]});   // hardware pair conversions (round 4; same rounding as to16: bf16 output was ~40 VALU per pixel pair in software)
+            q[1] = cvt_pk16<ODT>(f32x2{v[0][2], 0.f});
+            q[2] = cvt_pk16<ODT>(f32x2{v[1][0], v[1][1]});
+            q[3] = cvt_pk16<ODT>(f32x2{v[1][2], 0.f});
             if (two && (a.wb & 1) == 0) *reinterpret_cast<u32x4*>(op) = q;
             else {
                 u32x2 h0 = {q[0], q[1]};
@@ -571,17 +571,19 @@ __device__ __forceinline__ void lb_stage_dma(const LbTileGeom& g, unsigned char*
 // of the NEXT tile writes from the one these reads come from): the block would wait for the tile it has just requested.  The reads below are invisible to that
 // pass; the buffer hand-over is ordered by the counted wait + barrier at the top of the tile loop.  The wait carries the 24 registers as read-write operands, so
 // no use of them can be scheduled above it.  (The CPU simulator takes the plain C++ form.)
+// (bfloat16 taps through `ds_read_u16_d16_hi` into registers whose low halves stay zero -- no shift per element -- were tried: the in-out operands cost more register
+// copies than the shifts they save, 247 v_mov against 96 v_lshlrev per tile.)
 template <int IDT>
 __device__ __forceinline__ void lb_read24(const unsigned char* sm, const int (&off)[24], float (&val)[24]) {
 #ifdef YMI_HIPSIM
 #pragma unroll
     for (int i = 0; i < 24; ++i) val[i] = lds_elem<IDT>(sm + off[i]);
 #else
-    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sm;
+    (void)sm;   // (the offsets already carry the buffer's LDS address: lb_lds_base, folded into the scalar row bases by the caller)
     uint32_t r[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
-        const unsigned ad = base + (unsigned)off[i];
+        const unsigned ad = (unsigned)off[i];
         if constexpr (IDT == YMI_F32) asm volatile("ds_read_b32 %0, %1" : "=v"(r[i]) : "v"(ad));
         else if constexpr (IDT == YMI_F16 || IDT == YMI_BF16) asm volatile("ds_read_u16 %0, %1" : "=v"(r[i]) : "v"(ad));
         else asm volatile("ds_read_u8 %0, %1" : "=v"(r[i]) : "v"(ad));
@@ -598,6 +600,14 @@ __device__ __forceinline__ void lb_read24(const unsigned char* sm, const int (&o
         else if constexpr (IDT == YMI_BF16) val[i] = bf2f((uint16_t)r[i]);
         else val[i] = (float)r[i] / 255.0f;
     }
+#endif
+}
+__device__ __forceinline__ int lb_lds_base(const unsigned char* sm) {   // LDS byte address of a staging buffer (the inline-assembly reads take absolute addresses); simulator: 0
+#ifdef YMI_HIPSIM
+    (void)sm;
+    return 0;
+#else
+    return (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sm;
 #endif
 }
 template <int IDT, int ODT, int NW, int RPW>
@@ -631,6 +641,7 @@ __device__ __forceinline__ int lb_tile_rows(const LetterboxArgs& a, const LbTile
         }
     }
     const bool two = x + 1 < a.wb;
+    const int sm_lds = lb_lds_base(sm);
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int y = g.y0t + NW * j + wv;
@@ -651,8 +662,8 @@ __device__ __forceinline__ int lb_tile_rows(const LetterboxArgs& a, const LbTile
             for (int c = 0; c < 3; ++c) {
                 const int pc = HWC ? 0 : c;
                 const int sub = HWC ? c : 0;
-                const int r0 = (pc * g.nrows + (sy0 - g.ry0)) * g.pitch + ((g.al_a + pc * g.al_p + sy0 * g.al_r) & 15) + sub;
-                const int r1 = (pc * g.nrows + (sy1 - g.ry0)) * g.pitch + ((g.al_a + pc * g.al_p + sy1 * g.al_r) & 15) + sub;
+                const int r0 = sm_lds + (pc * g.nrows + (sy0 - g.ry0)) * g.pitch + ((g.al_a + pc * g.al_p + sy0 * g.al_r) & 15) + sub;   // wave-uniform (scalar) row bases
+                const int r1 = sm_lds + (pc * g.nrows + (sy1 - g.ry0)) * g.pitch + ((g.al_a + pc * g.al_p + sy1 * g.al_r) & 15) + sub;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {   // branch-free: a pixel outside the resized region reads offset 0 of the rows and keeps the fill value
                     off[c * 8 + p * 4 + 0] = r0 + ox0[p];
@@ -685,10 +696,10 @@ __device__ __forceinline__ int lb_tile_rows(const LetterboxArgs& a, const LbTile
         } else {
             uint16_t* op = (uint16_t*)a.out + o;
             u32x4 q;
-            q[0] = (uint32_t)to16<ODT>(v[0][0]) | ((uint32_t)to16<ODT>(v[0][1]) << 16);
-            q[1] = (uint32_t)to16<ODT>(v[0][2]);
-            q[2] = (uint32_t)to16<ODT>(v[1][0]) | ((uint32_t)to16<ODT>(v[1][1]) << 16);
-            q[3] = (uint32_t)to16<ODT>(v[1][2]);
+            q[0] = cvt_pk16<ODT>(f32x2{v[0][0], v[0][1]});   // hardware pair conversions (round 4; same rounding as to16: bf16 output was ~40 VALU per pixel pair in software)
+            q[1] = cvt_pk16<ODT>(f32x2{v[0][2], 0.f});
+            q[2] = cvt_pk16<ODT>(f32x2{v[1][0], v[1][1]});
+            q[3] = cvt_pk16<ODT>(f32x2{v[1][2], 0.f});
             if (two && (a.wb & 1) == 0) *reinterpret_cast<u32x4*>(op) = q;
             else {
                 u32x2 h0 = {q[0], q[1]};
