@@ -542,6 +542,42 @@ def test_igemm8_kernel_logic(sim, tile, cout):
     _run_conv(sim, torch.bfloat16, tile, 1, 64, cout, 12, 10, 3, 2, seed=tile + 1)
 
 
+@pytest.mark.parametrize("tile,k", [(21, 1), (61, 1), (111, 1), (115, 3), (91, 3), (31, 3), (142, 1)])
+def test_cout_96_and_192_take_the_lean_epilogue_and_equal_the_padded_convolution(sim, tile, k):
+    """round 4: a wave tile whose trailing 32-cout sub-tiles lie completely past cout (cout = 96 / 192 in a 128-wide block: yolov5m's widths) runs the lean epilogue for the
+    sub-tiles inside -- until then every second wave column went through the general one.  Against torch (inside _run_conv, neighbours of the output slice untouched), with and
+    without a shortcut, both 16-bit types; and BIT-IDENTICAL to the first 96 / 192 channels of the same convolution zero-padded to 128 / 256 couts (whole wave tiles: the path
+    that was lean before)"""
+    from yolort_amd import engine
+    for dtype, cout, res in [(torch.float16, 96, False), (torch.bfloat16, 96, True), (torch.float16, 192, True)]:
+        n, cin, h, w, s_ = 2, 64, 9, 11, 1
+        got = _run_conv(sim, dtype, tile, n, cin, cout, h, w, k, s_, residual=res, seed=tile + cout)
+        # the same operands (same generator stream as _run_conv), weights and bias zero-padded to the next multiple of 128
+        g = torch.Generator().manual_seed(tile + cout)
+        p = k // 2
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        cp = (cout + 127) // 128 * 128
+        wt_p, bias_p = torch.zeros(cp, cin, k, k), torch.zeros(cp)
+        wt_p[:cout], bias_p[:cout] = wt, bias
+        pc = engine.PackedConv(wt_p, bias_p, None, dtype, torch.device("cpu"))
+        xb = Buf(n, h, w, cin, dtype, fill=x.permute(0, 2, 3, 1))
+        yb = Buf(n, h, w, cp, dtype)
+        rb = None
+        if res:
+            r = torch.randn(n, cout, h, w, generator=g).to(dtype).float()
+            r_p = torch.zeros(n, cp, h, w)
+            r_p[:, :cout] = r
+            rb = Buf(n, h, w, cp, dtype, fill=r_p.permute(0, 2, 3, 1))
+        d = _conv_desc(xb, pc, yb, tile, k=k, pad=p, res=rb, stride=s_)
+        if k > 1:
+            kt = pc.ktab(w, xb.cs)
+            d.ktab = kt.data_ptr()
+        _check(sim, sim.sim_conv2d(C.byref(d)))
+        assert torch.equal(yb.view()[..., :cout].contiguous().view(torch.int16), got.contiguous().view(torch.int16)), (dtype, cout, res)
+
+
 @pytest.mark.parametrize("tile,cout", [(12, 64), (21, 128), (24, 128), (27, 64), (61, 128), (64, 128), (66, 128)])
 def test_igemm_v2_kernel_logic(sim, tile, cout):
     """conv_igemm_impl.hpp (4-wave LDS-DMA implicit GEMM): the tiles the yolov5s table uses, 1x1 / 3x3 / strided 3x3"""

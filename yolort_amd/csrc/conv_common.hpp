@@ -179,8 +179,8 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
         uint32_t pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            pk[g][0] = (uint32_t)to16<DT>(v[g][0]) | ((uint32_t)to16<DT>(v[g][1]) << 16);
-            pk[g][1] = (uint32_t)to16<DT>(v[g][2]) | ((uint32_t)to16<DT>(v[g][3]) << 16);
+            pk[g][0] = cvt_pk16<DT>(f32x2{v[g][0], v[g][1]});   // hardware pair conversion (round 4; the lean path's: same rounding as to16 -- bf16 in software is ~7 VALU per value)
+            pk[g][1] = cvt_pk16<DT>(f32x2{v[g][2], v[g][3]});
         }
         const bool wide = (cbase + 32 <= a.cout) && ((a.split & 7) == 0);   // wave-uniform
         if (wide) {
@@ -352,11 +352,13 @@ __device__ __forceinline__ void unswap_residual_packet(const u32x4& w, u32x2 (&r
 template <int TN>
 __device__ __forceinline__ void lean_load_residual(const ConvArgs& a, int cbase0, const LeanPix& p, u32x2 (&rv)[TN][4], int hi) {
     const char* const rb = reinterpret_cast<const char*>(a.res + cbase0);
-    u32x4 w[TN][2];
+    u32x4 w[TN][2] = {};
 #pragma unroll
     for (int i = 0; i < TN; ++i)
+        if (cbase0 + i * 32 < a.cout) {   // wave-uniform: a sub-tile past cout (cout % 32 == 0, lean_ok) has no shortcut to read
 #pragma unroll
-        for (int q = 0; q < 2; ++q) w[i][q] = *reinterpret_cast<const u32x4*>(rb + (size_t)p.ro + (size_t)(8 * hi) + (i * 32 + q * 16) * 2);   // p.ro carries 4 * hi channels: + 4 more
+            for (int q = 0; q < 2; ++q) w[i][q] = *reinterpret_cast<const u32x4*>(rb + (size_t)p.ro + (size_t)(8 * hi) + (i * 32 + q * 16) * 2);   // p.ro carries 4 * hi channels: + 4 more
+        }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -392,6 +394,7 @@ __device__ __forceinline__ void finish_wave_tile_lean(const ConvArgs& a, const f
         if constexpr (RES) lean_load_residual<TN>(a, cbase0, p, rv, hi);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
+            if (cbase0 + i * 32 >= a.cout) continue;   // wave-uniform: a whole sub-tile past cout (see lean_ok)
             u32x4 o[2];
             silu_pack_subtile<DT, RES>(acc[i][j], rv[i], o);
             lean_store(a, p, cbase0 + i * 32, o);
@@ -399,10 +402,17 @@ __device__ __forceinline__ void finish_wave_tile_lean(const ConvArgs& a, const f
     }
 }
 
-// wave-uniform preconditions of the lean path; 32-bit byte offsets need every addressed tensor below 4 GiB
-__device__ __forceinline__ bool lean_ok(const ConvArgs& a, int cbase0, int tn) {
+// wave-uniform preconditions of the lean path; 32-bit byte offsets need every addressed tensor below 4 GiB.
+// Every 32-cout sub-tile of the wave tile must be either completely inside cout or completely past it (round 4: until then the whole wave tile had to be inside, and
+// a cout of 96 / 192 -- yolov5m's widths -- sent every second wave column of a 128-wide block through the general epilogue: scalar SiLU, per-store predicates).
+__device__ __forceinline__ bool lean_ok_whole(const ConvArgs& a, int cbase0, int tn) {
     const int64_t cs_max = a.y_cs > a.y2_cs ? (a.y_cs > a.res_cs ? a.y_cs : a.res_cs) : (a.y2_cs > a.res_cs ? a.y2_cs : a.res_cs);
     return a.act == YMI_ACT_SILU && cbase0 + 32 * tn <= a.cout && (a.split & 15) == 0 && ((int64_t)a.M + 1) * cs_max * (a.up2 ? 4 : 1) < ((int64_t)1 << 31);
+}
+__device__ __forceinline__ bool lean_ok(const ConvArgs& a, int cbase0, int tn) {
+    const int64_t cs_max = a.y_cs > a.y2_cs ? (a.y_cs > a.res_cs ? a.y_cs : a.res_cs) : (a.y2_cs > a.res_cs ? a.y2_cs : a.res_cs);
+    return a.act == YMI_ACT_SILU && cbase0 < a.cout && (cbase0 + 32 * tn <= a.cout || (a.cout & 31) == 0) && (a.split & 15) == 0 &&
+           ((int64_t)a.M + 1) * cs_max * (a.up2 ? 4 : 1) < ((int64_t)1 << 31);
 }
 
 // ROW-TRANSPOSED form of the lean epilogue for wave tiles whose pixel groups are 32 CONSECUTIVE output pixels (the implicit-GEMM
@@ -420,7 +430,7 @@ template <int TN> constexpr int LEAN_TP_BYTES = 32 * LEAN_TP_PITCH<TN>;
 // and the two layers that carry it cost 3.5 x / 1.9 x their bare GEMMs, profiles/r04b_gemm_yardstick_c2.txt.)
 template <int TN>
 __device__ __forceinline__ bool lean_tp_ok(const ConvArgs& a, int cbase0) {
-    return lean_ok(a, cbase0, TN) && !(a.split > 0 && cbase0 < a.split && cbase0 + 32 * TN > a.split);
+    return lean_ok_whole(a, cbase0, TN) && !(a.split > 0 && cbase0 < a.split && cbase0 + 32 * TN > a.split);
 }
 template <int DT, int TN, int TM, bool RES>
 __device__ __forceinline__ void finish_wave_tile_lean_tp(const ConvArgs& a, const f32x16 (&acc)[TN][TM], int cbase0, int mbase, int lane, unsigned char* tw) {
@@ -532,7 +542,7 @@ __device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const 
     typedef typename Mfma<DT>::frag frag;
     constexpr int S2MAX = 8;   // second-source k16 steps (chain_k2 <= 128)
     // lean form (the case every chained launch of the YOLOv5 graphs is in): one K source, no shortcut on the producer
-    if (a.res == nullptr && a.chain_x2 == nullptr && !a.up2 && lean_ok(a, 0, TN) && ((int64_t)a.M + 1) * a.chain_y_cs < ((int64_t)1 << 31)) {
+    if (a.res == nullptr && a.chain_x2 == nullptr && !a.up2 && lean_ok_whole(a, 0, TN) && ((int64_t)a.M + 1) * a.chain_y_cs < ((int64_t)1 << 31)) {
         ConvArgs a2 = a;   // output side of the chained conv
         a2.y = a.chain_y; a2.y_cs = a.chain_y_cs; a2.split = 0; a2.up2 = 0;
         const int tn2 = a.chain_cout >> 5;   // 1..4 (wave-uniform)

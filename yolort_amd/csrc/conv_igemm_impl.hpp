@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                     uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.y_cs + co;
                     if (co + 3 < a.cout) {
                         u32x2 o;
-                        o[0] = (uint32_t)to16<DT>(v[0]) | ((uint32_t)to16<DT>(v[1]) << 16);
-                        o[1] = (uint32_t)to16<DT>(v[2]) | ((uint32_t)to16<DT>(v[3]) << 16);
+                        o[0] = cvt_pk16<DT>(f32x2{v[0], v[1]});
+                        o[1] = cvt_pk16<DT>(f32x2{v[2], v[3]});
                         *reinterpret_cast<u32x2*>(yp) = o;
                     } else {
                         for (int e = 0; e < 4 && co + e < a.cout; ++e) yp[e] = to16<DT>(v[e]);
