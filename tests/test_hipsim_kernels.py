@@ -544,12 +544,12 @@ def test_igemm8_kernel_logic(sim, tile, cout):
 
 @pytest.mark.parametrize("tile,k", [(21, 1), (61, 1), (111, 1), (115, 3), (91, 3), (31, 3), (142, 1)])
 def test_cout_96_and_192_take_the_lean_epilogue_and_equal_the_padded_convolution(sim, tile, k):
-    """round 4: a wave tile whose trailing 32-cout sub-tiles lie completely past cout (cout = 96 / 192 in a 128-wide block: yolov5m's widths) runs the lean epilogue for the
-    sub-tiles inside -- until then every second wave column went through the general one.  Against torch (inside _run_conv, neighbours of the output slice untouched), with and
+    """round 4: a wave tile whose trailing 16-channel packet pairs lie completely past cout (cout = 96 / 192 in a 128-wide block, 48 in a 64-wide one: yolov5m's widths; 80, 16)
+    runs the lean epilogue for the packets inside -- until then every such wave tile went through the general one.  Against torch (inside _run_conv, neighbours of the output slice untouched), with and
     without a shortcut, both 16-bit types; and BIT-IDENTICAL to the first 96 / 192 channels of the same convolution zero-padded to 128 / 256 couts (whole wave tiles: the path
     that was lean before)"""
     from yolort_amd import engine
-    for dtype, cout, res in [(torch.float16, 96, False), (torch.bfloat16, 96, True), (torch.float16, 192, True)]:
+    for dtype, cout, res in [(torch.float16, 96, False), (torch.bfloat16, 96, True), (torch.float16, 192, True), (torch.bfloat16, 48, True), (torch.float16, 80, False), (torch.float16, 16, True)]:
         n, cin, h, w, s_ = 2, 64, 9, 11, 1
         got = _run_conv(sim, dtype, tile, n, cin, cout, h, w, k, s_, residual=res, seed=tile + cout)
         # the same operands (same generator stream as _run_conv), weights and bias zero-padded to the next multiple of 128

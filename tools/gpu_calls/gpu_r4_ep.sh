@@ -3,7 +3,7 @@
 # Conv tests + per-launch parity (every conv launch of the plans vs the oracle's layers), then same-box A/B on C3 (and C2 / C5 as controls) against HEAD~'s library
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r04ep
+O=gpurun_out/r04ep2
 mkdir -p $O
 timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_parity_gpu.py tests/test_c3_fused_gpu.py -x -q -m gpu -k "conv or every_conv_launch or fused or chain" -p no:cacheprovider 2>&1 | tail -3 | cut -c1-300 | tee $O/tests.txt
 run() { cfg=$1; lbl=$2; shift; shift
@@ -23,5 +23,5 @@ for rep in 1 2; do
 done
 run c2 old YOLORT_AMD_LIB=$PWD/tools/_ab/libyolort_amd_old.so | tee -a $O/ab.txt
 run c2 new A=1 | tee -a $O/ab.txt
-run c5 old YOLORT_AMD_LIB=$PWD/tools/_ab/libyolort_amd_old.so | tee -a $O/ab.txt
-run c5 new A=1 | tee -a $O/ab.txt
+
+

@@ -355,9 +355,10 @@ __device__ __forceinline__ void lean_load_residual(const ConvArgs& a, int cbase0
     u32x4 w[TN][2] = {};
 #pragma unroll
     for (int i = 0; i < TN; ++i)
-        if (cbase0 + i * 32 < a.cout) {   // wave-uniform: a sub-tile past cout (cout % 32 == 0, lean_ok) has no shortcut to read
+        {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) w[i][q] = *reinterpret_cast<const u32x4*>(rb + (size_t)p.ro + (size_t)(8 * hi) + (i * 32 + q * 16) * 2);   // p.ro carries 4 * hi channels: + 4 more
+            for (int q = 0; q < 2; ++q)   // wave-uniform: a 16-channel packet pair past cout (cout % 16 == 0, lean_ok) has no shortcut to read
+                if (cbase0 + i * 32 + q * 16 < a.cout) w[i][q] = *reinterpret_cast<const u32x4*>(rb + (size_t)p.ro + (size_t)(8 * hi) + (i * 32 + q * 16) * 2);   // p.ro carries 4 * hi channels: + 4 more
         }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -373,6 +374,7 @@ __device__ __forceinline__ void lean_store(const ConvArgs& a, const LeanPix& p, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int co = cb + q * 16;   // a multiple of 16: the 16 channels of a packet pair are on one side of the split
+        if (co >= a.cout) continue;   // ... and on one side of cout (cout % 16 == 0 on this path: lean_ok)
         if (a.split > 0 && co >= a.split) st16(y2b + (size_t)(co - a.split) * 2 + (size_t)p.y2o, o[q]);
         else st16(yb + (size_t)co * 2 + (size_t)p.yo, o[q]);
         if (a.up2) {   // the same 8 channels to the 2x2 pixels of the upsampled view
@@ -403,15 +405,16 @@ __device__ __forceinline__ void finish_wave_tile_lean(const ConvArgs& a, const f
 }
 
 // wave-uniform preconditions of the lean path; 32-bit byte offsets need every addressed tensor below 4 GiB.
-// Every 32-cout sub-tile of the wave tile must be either completely inside cout or completely past it (round 4: until then the whole wave tile had to be inside, and
-// a cout of 96 / 192 -- yolov5m's widths -- sent every second wave column of a 128-wide block through the general epilogue: scalar SiLU, per-store predicates).
+// Every 16-channel packet pair of the wave tile must be either completely inside cout or completely past it: cout % 16 == 0 (round 4: until then the whole wave tile had to
+// be inside, and a cout of 96 / 192 / 48 -- yolov5m's widths -- sent every second wave column of a 128-wide block, or the whole 64-wide tile of a 48-cout layer such as its
+// stem, through the general epilogue: scalar SiLU, software rounding, per-store predicates).
 __device__ __forceinline__ bool lean_ok_whole(const ConvArgs& a, int cbase0, int tn) {
     const int64_t cs_max = a.y_cs > a.y2_cs ? (a.y_cs > a.res_cs ? a.y_cs : a.res_cs) : (a.y2_cs > a.res_cs ? a.y2_cs : a.res_cs);
     return a.act == YMI_ACT_SILU && cbase0 + 32 * tn <= a.cout && (a.split & 15) == 0 && ((int64_t)a.M + 1) * cs_max * (a.up2 ? 4 : 1) < ((int64_t)1 << 31);
 }
 __device__ __forceinline__ bool lean_ok(const ConvArgs& a, int cbase0, int tn) {
     const int64_t cs_max = a.y_cs > a.y2_cs ? (a.y_cs > a.res_cs ? a.y_cs : a.res_cs) : (a.y2_cs > a.res_cs ? a.y2_cs : a.res_cs);
-    return a.act == YMI_ACT_SILU && cbase0 < a.cout && (cbase0 + 32 * tn <= a.cout || (a.cout & 31) == 0) && (a.split & 15) == 0 &&
+    return a.act == YMI_ACT_SILU && cbase0 < a.cout && (cbase0 + 32 * tn <= a.cout || (a.cout & 15) == 0) && (a.split & 15) == 0 &&
            ((int64_t)a.M + 1) * cs_max * (a.up2 ? 4 : 1) < ((int64_t)1 << 31);
 }
 
