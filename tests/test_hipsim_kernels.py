@@ -298,6 +298,15 @@ def test_halo8_3x3_kernel_logic(sim, tile, cout):
     _run_conv(sim, torch.bfloat16, tile, 1, 32, cout, 20, 20, 3, 1, seed=tile + 1)
 
 
+def test_halo8_96_cout_blocks_equal_the_128_wide_tile(sim):
+    """round 4: conv_halo8_kernel<.., 96, 8> (tile 96: 8 x 1 waves of 32 pixels x 96 couts -- yolov5m's 96 -> 96 and 192 -> 192 3x3 layers without the idle quarter of a 128-wide
+    block): against torch and BIT-IDENTICAL to tile 91 (same K order), one and two cout blocks, with a shortcut, ragged maps, both 16-bit types, two and three channel chunks"""
+    for dtype, (n, cin, cout, h, w, res) in [(torch.float16, (2, 96, 96, 9, 12, True)), (torch.bfloat16, (1, 64, 192, 20, 20, False)), (torch.float16, (1, 96, 192, 7, 5, True))]:
+        a = _run_conv(sim, dtype, 91, n, cin, cout, h, w, 3, 1, residual=res, seed=96 + cin)
+        b = _run_conv(sim, dtype, 96, n, cin, cout, h, w, 3, 1, residual=res, seed=96 + cin)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (dtype, cin, cout)
+
+
 @pytest.mark.parametrize("tile,c_,residual", [(93, 64, True), (93, 64, False), (95, 128, True), (94, 32, True)])
 def test_halo8_with_a_chained_1x1_equals_the_two_launches(sim, tile, c_, residual):
     """conv_halo8.hip, 8 x 1 wave forms, with the NEXT Bottleneck's 1x1 riding in the epilogue (round 3: m.j.cv2 + m.(j+1).cv1 as one launch,

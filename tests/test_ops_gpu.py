@@ -284,6 +284,39 @@ def test_conv_halo8_kernel(dev, variant, shape):
     _run_conv(dev, torch.bfloat16, k=3, s=1, p=1, tile=variant, seed=variant + 1, **shape)
 
 
+def test_conv_halo8_96_cout_blocks(dev):
+    """tile 96 (conv_halo8_kernel<.., 96, 8>): yolov5m's 96 -> 96 / 192 -> 192 3x3 shapes at a reduced batch, with a shortcut; against torch and equal to tile 91 bit for bit"""
+    from yolort_amd import engine
+    for dtype, (n, cin, cout, h, w, res) in [(torch.bfloat16, (2, 96, 96, 160, 160, True)), (torch.float16, (2, 192, 192, 80, 80, False)), (torch.bfloat16, (1, 96, 192, 37, 29, True))]:
+        g = torch.Generator().manual_seed(96 + cin + h)
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        ref = F.silu(F.conv2d(x, wt, bias, 1, 1))
+        r = torch.randn(n, cout, h, w, generator=g).to(dtype).float() if res else None
+        if res:
+            ref = ref + r
+        outs = []
+        for tile in (91, 96):
+            plan = engine.Plan(dev, dtype)
+            xv = plan.alloc(n, h, w, cin)
+            xv.as_tensor().copy_(_nhwc(x).to(dev, dtype))
+            pc = engine.PackedConv(wt, bias, None, dtype, dev)
+            yv = plan.alloc(n, h, w, cout, zero=True)
+            rv = None
+            if res:
+                rv = plan.alloc(n, h, w, cout)
+                rv.as_tensor().copy_(_nhwc(r).to(dev, dtype))
+            plan.conv(xv, pc, 1, 1, out=yv, res=rv, tile=tile)
+            plan.run()
+            torch.cuda.synchronize()
+            outs.append(yv.as_tensor().clone())
+        got = outs[1].float().cpu().permute(0, 3, 1, 2)
+        tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("cout", [32, 64])
 @pytest.mark.parametrize("shape", [dict(n=2, h=40, w=40), dict(n=1, h=33, w=21), dict(n=3, h=8, w=16), dict(n=2, h=5, w=7), dict(n=9, h=64, w=96), dict(n=1, h=160, w=160)])

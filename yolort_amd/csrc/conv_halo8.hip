@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(const ConvArgs a, co
         ok = p < npix && oy < a.ho && ox < a.wo;
         m = ((int64_t)img * a.ho + oy) * a.wo + ox;
     };
-    if constexpr (ODT == DT && WAVES_M == 8 && TM == 1 && TN <= 4) {   // 8 x 1 waves: a wave owns ALL couts of its 32 pixels -- a chained 1x1 (the next
+    if constexpr (ODT == DT && WAVES_M == 8 && TM == 1 && TN <= 4 && TN != 3) {   // 8 x 1 waves: a wave owns ALL couts of its 32 pixels -- a chained 1x1 (the next
         if (a.chain_w != nullptr) {                                     // Bottleneck's cv1, or C3.cv3) runs from the outputs in registers
             finish_wave_tile_chain<DT, TN, TM>(a, acc, lane >> 5, lane, pix);
             H8_STAMP(127);
@@ -302,7 +302,7 @@ static int launch_halo8(const ConvArgs& a0, hipStream_t s) {
     g.magic_tw = magic(g.tw);
     g.magic_pw = magic(g.pw);
     a.nblk_m = a.n * g.tiles_x * g.tiles_y;
-    a.nblk_n = cdiv(a.cout_pad, BN);
+    a.nblk_n = BN == 96 ? cdiv(a.cout, BN) : cdiv(a.cout_pad, BN);   // (96: the packed rows are padded to a multiple of 128, not of 96 -- no block past cout)
     size_t lds = (size_t)(a.cin > 32 ? 2 : 1) * g.ppieces * 1024 + (size_t)3 * 3 * BN * 64;
     auto kfn = conv_halo8_kernel<DT, ODT, BN, WAVES_M>;
     if (lds < lds_floor_bytes()) lds = lds_floor_bytes();
@@ -327,6 +327,7 @@ static int halo8_variant(const ConvArgs& a, int variant, hipStream_t s) {
         case 3: return launch_halo8<DT, ODT, 64, 8>(a, s);    // 8x1 waves of 32 px x 64 cout
         case 4: return launch_halo8<DT, ODT, 32, 8>(a, s);    // 8x1 waves of 32 px x 32 cout
         case 5: return launch_halo8<DT, ODT, 128, 8>(a, s);   // 8x1 waves of 32 px x 128 cout
+        case 6: return launch_halo8<DT, ODT, 96, 8>(a, s);    // 8x1 waves of 32 px x 96 cout (round 4: yolov5m's 96 / 192-cout layers paid for a quarter of idle MFMAs in the 128-wide blocks)
         default: set_error("ymi_conv2d: unknown halo8 variant %d", variant); return YMI_EINVAL;
     }
 }
@@ -334,6 +335,7 @@ static int halo8_variant(const ConvArgs& a, int variant, hipStream_t s) {
 int conv_halo8_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s) {
     YMI_REQUIRE(a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.cin % 32 == 0 && a.zeros != nullptr && a.split == 0 && a.up2 == 0,
                 "ymi_conv2d: the 8-wave LDS-halo kernel handles plain 3x3 stride-1 pad-1 convolutions with cin %% 32 == 0 (and needs desc.zeros)");
+    YMI_REQUIRE(variant != 6 || (a.cout % 96 == 0 && a.chain_w == nullptr), "ymi_conv2d: tile 96 (96-cout blocks) needs cout %% 96 == 0 and no chained convolution");
     if (a.chain_w != nullptr) {   // chained 1x1: the 8 x 1 variants only, one cout block whose width is the chain's fresh K
         const int bn = variant == 3 ? 64 : (variant == 4 ? 32 : (variant == 5 ? 128 : 0));
         YMI_REQUIRE(bn != 0 && bn == a.chain_k && a.cout_pad == bn && out_dtype == dtype,

@@ -429,6 +429,8 @@ class Plan:
             cands = cands + ([33, 36] if d.cout_pad <= 32 else ([32, 35, 37, 33] if d.cout_pad <= 64 else [31, 34, 32, 37]))
             if chain is None:   # 8-wave halo kernel (conv_halo8.hip): 256-pixel patches, <= 2 DMA pieces per wave per step
                 cands = cands + ([94] if d.cout_pad <= 32 else ([92, 93] if d.cout_pad <= 64 else [91, 92, 93, 95]))
+                if d.cout % 96 == 0:
+                    cands = cands + [96]   # ... in 96-cout blocks (yolov5m's 96 / 192-cout layers)
             else:               # ... its 8 x 1 forms take a chained 1x1 whose K is the whole cout width (round 3)
                 k1 = d.cout_split if d.cout_split > 0 else d.cout
                 cands = cands + ([94] if k1 == 32 == d.cout_pad else ([93] if k1 == 64 == d.cout_pad else ([95] if k1 == 128 == d.cout_pad else [])))
