@@ -17,7 +17,7 @@ int sim_conv2d_v2(const ymi::ConvArgs& a, const ymi_conv_desc* d);   // sim_kern
 
 int sim_conv2d_gemm(const ymi::ConvArgs& a, const ymi_conv_desc* d) {
     if (d->tile >= 91 && d->tile <= 99) return ymi::conv_halo8_launch(a, d->dtype, d->out_dtype, d->tile - 90, nullptr);
-    if (d->tile >= 111 && d->tile <= 119) return ymi::conv_igemm8_launch(a, d->dtype, d->out_dtype, d->tile - 110, nullptr);
+    if (d->tile >= 111 && d->tile <= 120) return ymi::conv_igemm8_launch(a, d->dtype, d->out_dtype, d->tile - 110, nullptr);
     if (d->tile >= 151 && d->tile <= 159) return ymi::conv_igemm8_launch(a, d->dtype, d->out_dtype, d->tile - 140, nullptr);   // row-transposed stores
     if (d->tile >= 31 && d->tile <= 39) return ymi::conv3x3_halo_launch(a, d->dtype, d->out_dtype, d->tile - 30, nullptr);
     return sim_conv2d_v2(a, d);

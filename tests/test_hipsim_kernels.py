@@ -298,6 +298,15 @@ def test_halo8_3x3_kernel_logic(sim, tile, cout):
     _run_conv(sim, torch.bfloat16, tile, 1, 32, cout, 20, 20, 3, 1, seed=tile + 1)
 
 
+def test_igemm8_192_cout_blocks_equal_the_128_wide_tile(sim):
+    """round 4: conv_igemm8_kernel<.., 192, 4, ..> (tile 120: 4 x 2 waves of 64 pixels x 96 couts; yolov5m's 192-cout layers): against torch and BIT-IDENTICAL to tile 111,
+    strided 3x3 / 1x1 / 3x3 with a shortcut, one and two cout blocks, ragged maps, both 16-bit types"""
+    for dtype, (n, cin, cout, h, w, k, s_, res) in [(torch.float16, (2, 96, 192, 13, 11, 3, 2, False)), (torch.bfloat16, (1, 64, 384, 9, 10, 1, 1, True)), (torch.float16, (1, 32, 192, 8, 7, 3, 1, True))]:
+        a = _run_conv(sim, dtype, 111, n, cin, cout, h, w, k, s_, residual=res, seed=120 + cin)
+        b = _run_conv(sim, dtype, 120, n, cin, cout, h, w, k, s_, residual=res, seed=120 + cin)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (dtype, cin, cout, k, s_)
+
+
 def test_halo8_96_cout_blocks_equal_the_128_wide_tile(sim):
     """round 4: conv_halo8_kernel<.., 96, 8> (tile 96: 8 x 1 waves of 32 pixels x 96 couts -- yolov5m's 96 -> 96 and 192 -> 192 3x3 layers without the idle quarter of a 128-wide
     block): against torch and BIT-IDENTICAL to tile 91 (same K order), one and two cout blocks, with a shortcut, ragged maps, both 16-bit types, two and three channel chunks"""

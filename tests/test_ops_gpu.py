@@ -284,6 +284,42 @@ def test_conv_halo8_kernel(dev, variant, shape):
     _run_conv(dev, torch.bfloat16, k=3, s=1, p=1, tile=variant, seed=variant + 1, **shape)
 
 
+def test_conv_igemm8_192_cout_blocks(dev):
+    """tile 120 (conv_igemm8_kernel<.., 192, 4, ..>): yolov5m's 96 -> 192 and 192 -> 192 stride-2 3x3 shapes at a reduced batch and a 1x1 with a shortcut; against torch and equal to
+    tile 111 bit for bit"""
+    from yolort_amd import engine
+    for dtype, (n, cin, cout, h, w, k, s_, res) in [(torch.bfloat16, (2, 96, 192, 160, 160, 3, 2, False)), (torch.float16, (2, 192, 192, 80, 80, 3, 2, False)), (torch.bfloat16, (1, 192, 384, 37, 29, 1, 1, True))]:
+        g = torch.Generator().manual_seed(120 + cin + h)
+        p_ = k // 2
+        x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+        wt = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).to(dtype).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        ref = F.silu(F.conv2d(x, wt, bias, s_, p_))
+        r = torch.randn(*ref.shape, generator=g).to(dtype).float() if res else None
+        if res:
+            ref = ref + r
+        outs = []
+        for tile in (111, 120):
+            plan = engine.Plan(dev, dtype)
+            xv = plan.alloc(n, h, w, cin)
+            xv.as_tensor().copy_(_nhwc(x).to(dev, dtype))
+            pc = engine.PackedConv(wt, bias, None, dtype, dev)
+            ho, wo = engine.conv_out_hw(h, w, (k, k), (s_, s_), (p_, p_))
+            yv = plan.alloc(n, ho, wo, cout, zero=True)
+            rv = None
+            if res:
+                rv = plan.alloc(n, ho, wo, cout)
+                rv.as_tensor().copy_(_nhwc(r).to(dev, dtype))
+            plan.conv(xv, pc, s_, p_, out=yv, res=rv, tile=tile)
+            plan.run()
+            torch.cuda.synchronize()
+            outs.append(yv.as_tensor().clone())
+        got = outs[1].float().cpu().permute(0, 3, 1, 2)
+        tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 def test_conv_halo8_96_cout_blocks(dev):
     """tile 96 (conv_halo8_kernel<.., 96, 8>): yolov5m's 96 -> 96 / 192 -> 192 3x3 shapes at a reduced batch, with a shortcut; against torch and equal to tile 91 bit for bit"""
     from yolort_amd import engine

@@ -95,7 +95,7 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile >= 31 && tile <= 39) return conv3x3_halo_launch(a, DT, ODT, tile - 30, s);   // LDS-halo 3x3 s1 kernel
     if (tile == 41) return conv_stem_launch(a, DT, ODT, s);
     if (tile >= 91 && tile <= 99) return conv_halo8_launch(a, DT, ODT, tile - 90, s);     // 8-wave LDS-halo 3x3 s1 kernel
-    if (tile >= 111 && tile <= 119) return conv_igemm8_launch(a, DT, ODT, tile - 110, s);  // 8-wave implicit GEMM, 64-deep steps
+    if (tile >= 111 && tile <= 120) return conv_igemm8_launch(a, DT, ODT, tile - 110, s);  // 8-wave implicit GEMM, 64-deep steps (120: 192-cout blocks)
     if (tile >= 151 && tile <= 159) return conv_igemm8_launch(a, DT, ODT, tile - 140, s);  // ... with row-transposed stores (variants 11 .. 19)
     if (tile >= 121 && tile <= 124) return conv1x1_stream_launch(a, DT, ODT, tile - 120, s);   // streaming 1x1 (cin <= 128), no LDS
     if (tile == 131) return conv3x3_c32_launch(a, DT, ODT, 1, s);                              // resident-weights persistent 3x3, cin = 32

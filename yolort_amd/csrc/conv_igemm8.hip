@@ -221,6 +221,10 @@ static int launch_igemm8(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nblk_m = cdiv(a.M, 256);
     a.nblk_n = cdiv(a.cout_pad, BN);
+    if (BN == 192 && (a.cout % 192 != 0 || a.split != 0)) {
+        set_error("ymi_conv2d: tile 120 (192-cout blocks) needs cout %% 192 == 0 and no channel split");
+        return YMI_EINVAL;
+    }
     if (a.chain_w != nullptr && !(WAVES_M == 8 && BN == a.chain_k && BN <= 128)) {
         set_error("ymi_conv2d: this tile does not fit the chained 1x1 convolution (pixel-major waves, cout width %d)", a.chain_k);
         return YMI_EINVAL;
@@ -247,6 +251,8 @@ static int igemm8_variant(const ConvArgs& a, int variant, hipStream_t s) {
         case 7: return launch_igemm8<DT, ODT, 128, 4, 3>(a, s);
         case 8: return launch_igemm8<DT, ODT, 128, 8, 3>(a, s);
         case 9: return launch_igemm8<DT, ODT, 64, 4, 3>(a, s);
+        // 192-cout blocks (round 4; tile 120): 4x2 waves of 64 px x 96 cout -- yolov5m's 192-cout layers (96 -> 192 and 192 -> 192 stride 2) left a quarter of a 2 x 128 block's MFMAs on zero rows
+        case 10: return launch_igemm8<DT, ODT, 192, 4>(a, s);
         default: break;
     }
     if constexpr (ODT == DT) {   // variants 1 / 2 / 5 with row-transposed stores

@@ -422,6 +422,8 @@ class Plan:
                 cands = cands + ([114] if k1 == 32 else ([113] if k1 == 64 else ([116] if k1 == 128 else [])))
             else:
                 cands = cands + ([114] if d.cout_pad <= 32 else ([112, 113] if d.cout_pad <= 64 else ([111, 112, 116] if d.cout_pad <= 128 else [111, 115, 112])))
+                if d.cout % 192 == 0 and d.cout_split == 0:
+                    cands = cands + [120]   # ... in 192-cout blocks (yolov5m's 192 / 384 / 768-cout layers)
                 # (tiles 117-119 = 111 / 116 / 112 with a three-deep stage ring: measured equal to the two-deep ring on every
                 # yolov5s layer, profiles/r02z_conv_bench_ring3.txt -- the steps are not DMA-latency-bound; not offered to the tuner)
         if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and d.pw == 1 and d.cin % 32 == 0 and d.cout_split == 0 and d.k_pad == 9 * d.cin:
