@@ -46,6 +46,8 @@ MFMA_PEAK = 2.5e15  # FLOP/s dense fp16/bf16
 #   * memory: a device-to-device copy of a C3 canvas streams 4.99 TB/s (profiles/r02z_letterbox.txt), the best streaming kernel here 5.3 TB/s.
 MFMA_MEASURED = 1.0e15
 HBM_MEASURED = 5.0e12
+F32_MFMA_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact fp32) -- MI355X_MICROARCH.md "Matrix cores": 64 FLOP/clk/SIMD = 1/16 of the bf16 rate
+F32_DEPTH = int(os.environ.get("YOLORT_AMD_F32_PIPELINE", "3"))   # plan instances (batches in flight) of the fp32 mode at 640 x 640
 
 C3_SHAPES = [(1080, 1920), (720, 1280), (1920, 1080), (1080, 810), (960, 1280), (1281, 1279), (641, 480), (375, 500)]
 CONFIGS = {   # BASELINE.json `configs`
@@ -65,7 +67,9 @@ def parse():
     ap.add_argument("--arch", default=None)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=None)
-    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
+    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16", "fp32"],
+                    help="fp32: the fp32 mode (fp32 storage + exact f32-input MFMA arithmetic: the mode that meets north_star's 1e-3 box tolerance) as a line of its own, "
+                         "roofline priced at 157.3 TFLOP/s / 8 TB/s with 4-byte elements")
     ap.add_argument("--shapes", default=None, choices=["fixed", "dynamic"], help="dynamic: image sizes cycled from SURVEY 8d's list (real letterbox)")
     ap.add_argument("--score-thresh", type=float, default=None)
     ap.add_argument("--head-gain", type=float, default=None)
@@ -266,7 +270,7 @@ def direct_checks(ref, got, thr, k=300, score_eps=5e-4, iou_min=1 - 1e-3):
     return out
 
 
-def conditioned_parity(args, dev):
+def conditioned_parity(args, dev, fp32_only=False):
     """The parity claim on the workload that can carry it (tests/test_golden_gpu.py): the CONDITIONED synthetic network of this architecture
     (yolort_amd/utils/synth.py COND_*) on its four seeded images, against detections of the UNMODIFIED reference committed as
     tests/golden/cond_<tag>.npz (made by tests/golden/make_golden.py in the build container) -- no oracle involved at run time.
@@ -287,6 +291,7 @@ def conditioned_parity(args, dev):
     tol = {"s": (0.98, 1e-2), "l6": (0.5, 0.1), "n": (0.95, 3e-2), "m": (0.90, 6e-2)}[tag]
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    mode_list = (("fp32_parity_mode", torch.float32),) if fp32_only else (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16))
     out = {}
     # two reference-made goldens per architecture: `cond` (round 3: every score within a few hundredths of the threshold) and `spread` (round 4: scores from the threshold
     # up to ~0.9, the threshold in a gap of the reference's score list -- nothing can be excused as "at the cut").  Each also carries the REFERENCE'S OWN 16-bit run
@@ -306,7 +311,7 @@ def conditioned_parity(args, dev):
                            f"(tests/golden/{os.path.basename(path)})", "reference_self_reproducibility_fp64": meta["fp64"]}
         if kind == "spread":
             blk["score_range"], blk["threshold_gap"] = meta["score_range"], meta["thr_gap"]
-        for name, dtype in (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16)):
+        for name, dtype in mode_list:
             m = YOLOv5(arch=args.arch, size=(S, S), score_thresh=thr, nms_thresh=0.45, detections_per_img=300, **kw)
             m.load_state_dict(conditioned_weights(m.state_dict(), args.arch, meta["seed"], variant=kind))
             m = m.to(dev).eval()
@@ -339,12 +344,12 @@ def conditioned_parity(args, dev):
         per = out.pop("spread_more_seeds")
         agg = {"seeds": [int(os.path.basename(f).split("_s")[-1][:-4]) for f in more], "images": sum(b["fp32_parity_mode"]["images"] for b in per),
                "what": "further seeds of the spread workload (own weights, images and gap threshold each; same acceptance criteria as the first seed), all detections pooled"}
-        for name in ("fp32_parity_mode", f"production_{args.dtype}"):
+        for name, _dt in mode_list:
             agg[name] = {k: sum(b[name][k] for b in per) for k in ("ref_dets", "hip_dets", "paired", "at_cut", "unexplained", "images_equal_count", "images_labels_equal")}
             agg[name]["min_iou"] = min(b[name]["min_iou"] for b in per)
             agg[name]["max_dscore"] = max(b[name]["max_dscore"] for b in per)
         p16 = f"production_{args.dtype}"
-        if all("reference_own_" + args.dtype in b[p16] for b in per):
+        if not fp32_only and all("reference_own_" + args.dtype in b[p16] for b in per):
             agg[p16]["iou_deficit_vs_reference_own_per_seed"] = [b[p16]["iou_deficit_vs_reference_own"] for b in per]
             agg[p16]["dscore_vs_reference_own_per_seed"] = [b[p16]["dscore_vs_reference_own"] for b in per]
             agg[p16]["score_tolerance_per_seed"] = [b[p16]["stated_tolerance"]["max_dscore"] for b in per]
@@ -357,7 +362,7 @@ def conditioned_parity(args, dev):
     return out
 
 
-def fp32_mode_throughput(args, dev, images_cpu, steps=6):
+def fp32_mode_throughput(args, dev, images_cpu, steps=12):
     """throughput of the mode that meets the north-star box tolerance (fp32 storage + exact fp32 MFMA arithmetic, csrc/conv_f32.hip) on the benchmark workload itself:
     what the tolerance costs (`only the un-benchmarked fp32 parity mode meets 1 - 1e-3`)"""
     from yolort_amd.models import YOLOv5
@@ -367,16 +372,26 @@ def fp32_mode_throughput(args, dev, images_cpu, steps=6):
     m = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300, **kw)
     m.load_state_dict(synth_weights(m.state_dict(), args.arch, seed=0, head_gain=args.head_gain))
     m = m.to(dev).eval().set_compute_dtype(torch.float32)
-    # fp32 activations are twice the size and the mode keeps every reference conv's output: ONE plan instance (no batches in flight), and at most 8 images per batch
-    # on the 1280 x 1280 configurations (yolov5m bs 64 in fp32 with four instances asked for 286 GiB in the first measurement set of round 4)
-    m.model.pipeline_depth = 1
+    # fp32 activations are twice the size and the mode keeps every reference conv's output: at most 8 images per batch and ONE plan instance on the 1280 x 1280
+    # configurations (yolov5m bs 64 in fp32 with four instances asked for 286 GiB in the first measurement set of round 4); three batches in flight at 640 x 640
+    # (7.8 GB of activations per instance for yolov5s bs 32), the regime the headline is measured in
+    depth = F32_DEPTH if args.size <= 640 else 1
+    m.model.pipeline_depth = depth
     imgs = [im.to(dev) for im in (images_cpu if args.size <= 640 else images_cpu[:8])]
-    for _ in range(2):
-        m.forward_async(imgs).result()
+
+    def run(k):
+        pend = []
+        for _ in range(k):
+            pend.append(m.forward_async(imgs))
+            if len(pend) >= depth:
+                pend.pop(0).result()
+        for p in pend:
+            p.result()
+
+    run(depth + 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        m.forward_async(imgs).result()
+    run(steps)
     torch.cuda.synchronize()
     ips = len(imgs) * steps / (time.perf_counter() - t0)
     del m
@@ -441,8 +456,120 @@ def _elapsed(pairs):
     return [s.elapsed_time(t) for s, t in zip(*pairs)]
 
 
+def main_fp32(args):
+    """`--dtype fp32`: the fp32 mode as a bench line of its own.  Same step, same workload, same timing contract as the headline; the model keeps
+    fp32 parameters, activations are stored in fp32 and every convolution is exact fp32 arithmetic on v_mfma_f32_32x32x2_f32 (csrc/conv_f32_pipe.hip) -- the arithmetic of
+    the reference's CPU path (common.py:69-70 in torch.float32).  Roofline: per-launch bound max(flops / 157.3 TFLOP/s, bytes / 8 TB/s) at 4 bytes per element."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--dtype fp32 is a single-GPU line (the sharded path is dtype-agnostic: run the default dtype with --gpus N)")
+    dev = torch.device("cuda", int(os.environ.get("YOLORT_AMD_BENCH_DEVICE", "0")))
+    torch.cuda.set_device(dev)
+    from yolort_amd.models import YOLOv5
+    from yolort_amd.utils.synth import synth_images, synth_weights
+
+    kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
+    model = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300, **kw)
+    sd = synth_weights(model.state_dict(), args.arch, seed=0, head_gain=args.head_gain)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval().set_compute_dtype(torch.float32)
+    if args.shapes == "dynamic":
+        images_cpu = [synth_images(1, *C3_SHAPES[i % len(C3_SHAPES)], seed=1 + i)[0] for i in range(args.batch)]
+    else:
+        images_cpu = list(synth_images(args.batch, args.size, args.size, seed=1))
+    images_gpu = [im.to(dev) for im in images_cpu]
+    yolo = model.model
+    yolo.pipeline_depth = int(os.environ.get("YOLORT_AMD_PIPELINE", str(F32_DEPTH if args.size <= 640 else 1)))
+    depth = max(1, yolo.pipeline_depth - 1)
+    host = {"enqueue": 0.0}
+
+    def run_steps(k):
+        pending, dets = [], None
+        for _ in range(k):
+            t_a = time.perf_counter()
+            pending.append(model.forward_async(images_gpu))
+            host["enqueue"] += time.perf_counter() - t_a
+            if len(pending) > depth:
+                dets = pending.pop(0).result()
+        while pending:
+            dets = pending.pop(0).result()
+        return dets
+
+    run_steps(max(args.warmup, 1))
+    torch.cuda.synchronize()
+    e = next(iter(yolo._entries.values()))
+
+    def timed_region():
+        torch.cuda.synchronize()
+        host["enqueue"] = 0.0
+        t0 = time.perf_counter()
+        d = run_steps(args.steps)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, host["enqueue"] / args.steps * 1e3, d
+
+    reps = [timed_region() for _ in range(max(1, args.repeats))]
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    elapsed, host_enqueue_ms, dets = reps[order[len(order) // 2]]
+    rep_ips = [round(args.batch * args.steps / r[0], 1) for r in reps]
+    # the conv launches with ONE batch in flight: HIP events on the stream they are launched on
+    yolo.bracket = {"pre": ([], []), "conv": ([], []), "post": ([], [])}
+    n_excl = 6
+    for _ in range(n_excl):
+        model.forward_async(images_gpu).result()
+        torch.cuda.synchronize()
+    excl = {k: _elapsed(v) for k, v in yolo.bracket.items()}
+    yolo.bracket = None
+    mean = lambda v: (sum(v) / len(v)) if v else 0.0  # noqa: E731
+    conv_meta = [m for m in e.plan.meta if m["kind"] == "conv"]
+    n_conv = len(conv_meta)
+    bytes_step, flops_step = sum(m["bytes"] for m in conv_meta), sum(m["flops"] for m in conv_meta)
+    bound_s = sum(max(m["flops"] / F32_MFMA_PEAK, m["bytes"] / HBM_PEAK) for m in conv_meta)
+    n_mfma_bound = sum(1 for m in conv_meta if m["flops"] / F32_MFMA_PEAK >= m["bytes"] / HBM_PEAK)
+    conv_s = mean(excl["conv"]) * 1e-3
+    step_s = elapsed / args.steps
+    ips = args.batch * args.steps / elapsed
+    tiles = {}
+    for m in conv_meta:
+        tiles[str(m.get("tile"))] = tiles.get(str(m.get("tile")), 0) + 1
+    out = {
+        "metric": ("images/sec at 640x640 (bs=32) yolov5s" if args.config == "c2" else f"images/sec at {args.size}x{args.size} (bs={args.batch}) {args.arch}") + " -- fp32 mode",
+        "value": round(ips, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+        "repeats": {"n": len(reps), "images_per_s": rep_ips, "median": round(ips, 2), "min": min(rep_ips), "max": max(rep_ips),
+                    "spread_pct": round(100.0 * (max(rep_ips) - min(rep_ips)) / max(ips, 1e-9), 2)},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.arch} fp32 mode (fp32 storage, exact fp32 arithmetic on the f32-input MFMA) bs={args.batch}/GPU {args.size}x{args.size} "
+                               + ("dynamic-shape letterbox (8 cycled sizes, SURVEY 8d)" if args.shapes == "dynamic" else "fixed-size stream (letterbox kernel: planar fp32 -> NHWC4 canvas)")
+                               + " -> backbone+PAN+head -> decode+NMS HIP path", "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
+                   "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "batches_in_flight": depth, "plan_instances": yolo.pipeline_depth,
+                   "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4), "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
+                   "conv_tiles": tiles, "plan_activation_bytes": e.plan.bytes_allocated},
+        "roofline": {"bound": "mfma", "achieved": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0,
+                     "frac_definition": f"per-launch bound sum_l max(flops_l / 157.3 TFLOP/s, bytes_l / 8 TB/s) at 4 bytes per element / measured serial conv time; {n_mfma_bound} of {n_conv} launches are MFMA-bound",
+                     "frac_mfma": round(flops_step / conv_s / F32_MFMA_PEAK, 4) if conv_s > 0 else 0.0, "traffic": None,
+                     "kernel": "conv_f32_pipe_kernel (every conv launch of one step; csrc/conv_f32_pipe.hip)", "launches_per_step": n_conv,
+                     "algorithmic_flops_per_step": flops_step, "algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_launch": round(flops_step / max(n_conv, 1)),
+                     "per_layer_bound_ms": round(bound_s * 1e3, 4),
+                     "serial": {"conv_ms_per_step": round(conv_s * 1e3, 4), "avg_launch_us": round(conv_s / max(n_conv, 1) * 1e6, 2),
+                                "timing": f"HIP events on the plan's stream around the conv launches, one batch in flight, mean of {n_excl} steps right after the timed region"},
+                     "pipelined": {"batches_in_flight": depth, "ms_per_step": round(step_s * 1e3, 4), "frac_of_per_layer_bound": round(bound_s / step_s, 4),
+                                   "tflops": round(flops_step / step_s / 1e12, 2)},
+                     "other_kernels": {"letterbox": {"ms": round(mean(excl["pre"]), 4)} if excl["pre"] else None, "postprocess": {"ms": round(mean(excl["post"]), 4)} if excl["post"] else None}},
+    }
+    if not args.no_cpu_baseline:
+        sd_cpu = {k: v.float().cpu() for k, v in model.state_dict().items()}
+        cp = conditioned_parity(args, dev, fp32_only=True)
+        out["parity"] = {} if cp is None else dict(cp)
+        if cp is not None:
+            out["parity"]["unexplained"] = sum(cp[k]["fp32_parity_mode"]["unexplained"] for k in ("cond", "spread", "spread_more") if k in cp)
+            out["parity"]["north_star_tolerance"] = "boxes within 1e-3 IoU, |dscore| <= 1e-4, identical label sequences against detections of the UNMODIFIED reference (tests/golden/*.npz)"
+        out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.dtype == "fp32":
+        return main_fp32(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -106,7 +106,7 @@ typedef struct ymi_conv_desc {
      * reference common.py:172-173).  cout_split == 0 disables; must be a multiple of 8. */
     void* y2;
     int32_t y2_cstride, cout_split;
-    /* y2_mode 0: channel split as above.  y2_mode 1 (cout_split must be 0, cout % 32 == 0, 16-bit output): y2 is an
+    /* y2_mode 0: channel split as above.  y2_mode 1 (cout_split must be 0, cout % 32 == 0, output of the compute dtype): y2 is an
      * (n, 2*ho, 2*wo) view that receives ALL output channels nearest-neighbour upsampled x2, in addition to y --
      * the nn.Upsample(scale_factor=2) of path_aggregation_network.py:221-223 folded into its producer's epilogue. */
     int32_t y2_mode, reserved0;
@@ -136,6 +136,11 @@ typedef struct ymi_conv_desc {
 int ymi_conv2d(const ymi_conv_desc* d, void* stream);
 /* fills host array ktab[k_pad/8][2] for the geometry in d (x_cstride, w_in, cin, kh, kw) */
 int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_pad, int32_t* ktab_host);
+/* fp32 mode (dtype = out_dtype = YMI_F32: fp32 activations and weights, exact fp32 arithmetic on the f32-input MFMA -- the
+ * arithmetic of the reference's CPU path, common.py:69-70 run in torch.float32): the tile ymi_conv2d takes for tile == 0,
+ * a function of (n*ho*wo, cout_pad) only, so every process sums in the same order.  Tiles 201-206 are the LDS-DMA
+ * pipelined kernels (need desc.zeros); a negative tile id selects the register-staged kernel of rounds 2-4. */
+int ymi_conv_f32_pick_tile(int m_pixels, int cout_pad);
 
 /* ------------------------------------------------------------------------------------------
  * A whole C3 block in one launch: y = cv3(cat(m(cv1(x)), cv2(x))), m = ONE Bottleneck
@@ -143,8 +148,8 @@ int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_
  * (Bottleneck.forward) inlined, every Conv being :69-70 with BatchNorm folded into W/bias.
  * Intermediates never reach memory; results are bit-identical to the separate ymi_conv2d launches.
  * This build holds ONE instance: c_in = 64, c_hidden = 32, c_out = 64, one shortcut Bottleneck
- * (yolov5s backbone.body.2); anything else returns YMI_EINVAL.  OPT-IN (YOLORT_AMD_FUSE_C3=1 on the
- * Python side): written at the end of round 2 without GPU time left, see DESIGN.md section 4.
+ * (yolov5s backbone.body.2); anything else returns YMI_EINVAL.  The Python side emits it by default since
+ * round 3 (YOLORT_AMD_FUSE_C3=0 restores the separate launches).
  *   x / y       NHWC views (n,h,w,c_in) / (n,h,w,c_out), 16-bit, pixel strides x_cstride / y_cstride
  *   w12, b12    cv1 and cv2 stacked along cout: packed [>= 2*c_hidden][k12_pad] like ymi_conv_desc.w
  *               (rows 0..c_hidden-1 = cv1), fp32 bias [2*c_hidden]

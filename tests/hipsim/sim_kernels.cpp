@@ -47,6 +47,7 @@ alignas(16) uint16_t smem[SIM_LDS / 2];
 int sim_conv2d_gemm(const ymi::ConvArgs& a, const ymi_conv_desc* d);
 int sim_conv2d_stem(const ymi::ConvArgs& a, const ymi_conv_desc* d);   // sim_kernels_stem.cpp
 int sim_conv2d_f32(const ymi::ConvArgs& a, const ymi_conv_desc* d);    // sim_kernels_f32.cpp
+int sim_conv2d_f32p(const ymi::ConvArgs& a, const ymi_conv_desc* d);   // sim_kernels_f32p.cpp
 
 #include "sim_fill.h"
 
@@ -54,7 +55,7 @@ extern "C" int sim_c3_fused(const ymi_c3_desc* d) { return ymi_c3_fused(d, nullp
 extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     ymi::ConvArgs a;
     sim_fill(d, a);
-    if (d->dtype == YMI_F32) return sim_conv2d_f32(a, d);   // fp32 parity mode: one kernel, no tile choice
+    if (d->dtype == YMI_F32) return (d->tile >= 0 && d->zeros != nullptr) ? sim_conv2d_f32p(a, d) : sim_conv2d_f32(a, d);   // fp32 mode: pipelined tiles 201-206 (0 = by shape) / the register-staged kernel (negative tile)
     if (d->tile >= 121 && d->tile <= 124) return ymi::conv1x1_stream_launch(a, d->dtype, d->out_dtype, d->tile - 120, nullptr);
     if (d->tile == 131) return ymi::conv3x3_c32_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 132) return ymi::conv3x3_res_launch(a, d->dtype, d->out_dtype, 1, nullptr);

@@ -39,7 +39,7 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem", "sim_kernels_f32"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem", "sim_kernels_f32", "sim_kernels_f32p"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
     csrc = os.path.join(ROOT, "yolort_amd", "csrc")
     srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp", "sim_fill.h")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
@@ -60,6 +60,7 @@ def sim():
     from yolort_amd._lib import C3Desc, ConvDesc
     lib.sim_c3_fused.argtypes, lib.sim_c3_fused.restype = [C.POINTER(C3Desc)], C.c_int
     lib.sim_conv2d.argtypes, lib.sim_conv2d.restype = [C.POINTER(ConvDesc)], C.c_int
+    lib.sim_conv_f32_pick_tile.argtypes, lib.sim_conv_f32_pick_tile.restype = [C.c_int, C.c_int], C.c_int
     lib.sim_last_error.restype = C.c_char_p
     lib.sim_max_lds.restype = C.c_int
     lib.ymi_letterbox.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
@@ -1187,6 +1188,100 @@ def test_fp32_parity_kernel_logic(sim, k, s_, cin, cout):
     _check(sim, sim.sim_conv2d(C.byref(d)))
     got = yb.permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def _f32_desc(x_buf, pc, y, tile, k, s_, p, res=None, y2=None, split=0, up2=False, act=None):
+    """fp32-mode conv descriptor over host NHWC fp32 buffers (x_buf: flat tensor with the 256-byte zero tail the plan buffers carry)"""
+    from yolort_amd._lib import ACT_SILU, ConvDesc, YMI_F32
+    xt, n, h, w, cs, tail = x_buf
+    d = ConvDesc()
+    d.x, d.w, d.bias, d.y = xt.data_ptr(), pc.w.data_ptr(), pc.bias.data_ptr(), y.data_ptr()
+    kt = pc.ktab(w, cs)
+    d.ktab = kt.data_ptr()
+    d._keep = kt
+    d.n, d.h, d.w_in, d.cin, d.x_cstride = n, h, w, pc.cin, cs
+    ho, wo = (h + 2 * p - k) // s_ + 1, (w + 2 * p - k) // s_ + 1
+    d.ho, d.wo, d.cout, d.cout_pad, d.y_cstride = ho, wo, pc.cout, pc.cout_pad, y.shape[-1]
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.k_pad = k, k, s_, s_, p, p, pc.k_pad
+    d.act, d.dtype, d.out_dtype, d.tile = ACT_SILU if act is None else act, YMI_F32, YMI_F32, tile
+    d.zeros = xt.data_ptr() + 4 * tail
+    if res is not None:
+        d.res, d.res_cstride = res.data_ptr(), res.shape[-1]
+    if y2 is not None:
+        d.y2, d.y2_cstride, d.cout_split, d.y2_mode = y2.data_ptr(), y2.shape[-1], split, 1 if up2 else 0
+    return d
+
+
+@pytest.mark.parametrize("tile", [201, 202, 203, 204, 205, 206, 0])
+@pytest.mark.parametrize("k,s_,cin,cout", [(1, 1, 64, 96), (1, 1, 40, 128), (3, 1, 32, 40), (3, 2, 48, 64), (3, 1, 24, 32), (6, 2, 4, 32)])
+def test_fp32_pipelined_kernel_logic(sim, tile, k, s_, cin, cout):
+    """csrc/conv_f32_pipe.hip (round 5: the fp32 mode's LDS-DMA pipelined tiles): every tile in its three operand forms (pointwise, uniform tap,
+    im2col table) against torch's fp32 convolution to rounding-order accuracy, and against the register-staged kernel it replaces"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(k * 10 + cin + tile)
+    n, h, w, p = 2, 13, 10, k // 2 if k != 6 else 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x, wt, bias, s_, p))
+    ho, wo = ref.shape[2], ref.shape[3]
+    pc = engine.PackedConv(wt, bias, None, torch.float32, torch.device("cpu"), cin_pad=(cin + 7) // 8 * 8)
+    numel = n * h * w * pc.cin
+    xt = torch.zeros(numel + 64)
+    xt[:numel].view(n, h, w, pc.cin)[..., :cin] = x.permute(0, 2, 3, 1)
+    outs = []
+    for t in (tile, -100):
+        yb = torch.zeros(n, ho, wo, cout)
+        d = _f32_desc((xt, n, h, w, pc.cin, numel), pc, yb, t, k, s_, p)
+        _check(sim, sim.sim_conv2d(C.byref(d)))
+        outs.append(yb.permute(0, 3, 1, 2))
+    scale = max(1.0, ref.abs().max().item())
+    assert (outs[0] - ref).abs().max().item() <= 2e-6 * scale
+    # the same k pairs in the same order, the same 64-element partial sums: BIT-IDENTICAL to the kernel the reference-made goldens were validated with
+    assert torch.equal(outs[0], outs[1]), f"max difference {(outs[0] - outs[1]).abs().max().item()}"
+
+
+@pytest.mark.parametrize("tile", [201, 202, 206])
+def test_fp32_pipelined_kernel_split_shortcut_upsample(sim, tile):
+    """the fp32 tiles' epilogue features: channel split into a second view (C3.cv1 + cv2 in one launch, common.py:172-173), the Bottleneck shortcut added after
+    the activation (common.py:115-116), and the x2-upsampled second output (path_aggregation_network.py:221-223) -- written into channel slices of wider buffers"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(tile)
+    n, h, w, cin = 2, 9, 7, 32
+    x = torch.randn(n, cin, h, w, generator=g)
+    numel = n * h * w * cin
+    xt = torch.zeros(numel + 64)
+    xt[:numel].view(n, h, w, cin)[:] = x.permute(0, 2, 3, 1)
+    xb = (xt, n, h, w, cin, numel)
+    # (a) split: couts [0, 32) -> y (own buffer), [32, 64) -> channels [8, 40) of a 48-wide buffer
+    wt = torch.randn(64, cin, 1, 1, generator=g) / np.sqrt(cin)
+    bias = torch.randn(64, generator=g) * 0.1
+    pc = engine.PackedConv(wt, bias, None, torch.float32, torch.device("cpu"), cin_pad=cin)
+    ref = F.silu(F.conv2d(x, wt, bias)).permute(0, 2, 3, 1)
+    y, wide = torch.zeros(n, h, w, 32), torch.zeros(n, h, w, 48)
+    d = _f32_desc(xb, pc, y, tile, 1, 1, 0, y2=wide[..., 8:], split=32)
+    d.y2_cstride = 48
+    _check(sim, sim.sim_conv2d(C.byref(d)))
+    assert (y - ref[..., :32]).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert (wide[..., 8:40] - ref[..., 32:]).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert wide[..., :8].abs().max().item() == 0 and wide[..., 40:].abs().max().item() == 0
+    # (b) 3x3 with the shortcut
+    wt3 = torch.randn(32, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b3 = torch.randn(32, generator=g) * 0.1
+    pc3 = engine.PackedConv(wt3, b3, None, torch.float32, torch.device("cpu"), cin_pad=cin)
+    res = torch.randn(n, h, w, 32, generator=g)
+    ref3 = F.silu(F.conv2d(x, wt3, b3, 1, 1)).permute(0, 2, 3, 1) + res
+    y3 = torch.zeros(n, h, w, 32)
+    _check(sim, sim.sim_conv2d(C.byref(_f32_desc(xb, pc3, y3, tile, 3, 1, 1, res=res))))
+    assert (y3 - ref3).abs().max().item() <= 2e-6 * ref3.abs().max().item()
+    # (c) the upsampled copy: channels [0, 32) of a (n, 2h, 2w, 40) buffer
+    up = torch.zeros(n, 2 * h, 2 * w, 40)
+    y4 = torch.zeros(n, h, w, 32)
+    pc4 = engine.PackedConv(wt[:32], bias[:32], None, torch.float32, torch.device("cpu"), cin_pad=cin)
+    d4 = _f32_desc(xb, pc4, y4, tile, 1, 1, 0, y2=up, up2=True)
+    _check(sim, sim.sim_conv2d(C.byref(d4)))
+    assert torch.equal(y4, y)
+    assert torch.equal(up[..., :32], y4.repeat_interleave(2, 1).repeat_interleave(2, 2)) and up[..., 32:].abs().max().item() == 0
 
 
 def test_layout_edges_and_view_copy(sim):

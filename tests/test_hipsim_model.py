@@ -98,8 +98,11 @@ class _SimLib:
     def ymi_conv_build_ktab(self, *a):
         return self.real.ymi_conv_build_ktab(*a)
 
+    def ymi_conv_f32_pick_tile(self, m, cout_pad):
+        return self.sim.sim_conv_f32_pick_tile(int(m), int(cout_pad))
 
-def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None, small_tiles=False):
+
+def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None, small_tiles=False, f32_v1=False):
     from yolort_amd import _lib, engine
     p = engine.Plan.__new__(engine.Plan)   # Plan.__init__ insists on an MI355X; the attributes it would set:
     p.lib = _SimLib(sim_lib, _lib.load(require_gpu=False), substitute, small_tiles)
@@ -113,8 +116,9 @@ def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None, small_tiles=False):
     p.rw2 = not p.fp32                                    # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2), as in production
     p.rs = False
     p.rw3 = not p.fp32                                    # tile 135 (its K-split form for cin = 128): executed inside the whole-model runs here
-    if p.fp32:   # fp32 parity mode (engine.Plan.__init__): one launch per reference conv, no fused pairs / chains
-        p.use_v1, p.chain_1x1, p.chain_cv3, p.fuse_c3 = True, False, False, False
+    p.chain128, p.chain_next = 0, False
+    if p.fp32:   # fp32 mode (engine.Plan.__init__): the pipelined fp32 tiles with the cv1 + cv2 pair and the folded upsample; f32_v1: one register-staged launch per reference conv
+        p.use_v1, p.chain_1x1, p.chain_cv3, p.fuse_c3 = f32_v1, False, False, False
     return p
 
 
@@ -235,8 +239,10 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, 
         assert hit >= (0.9 if dtype == torch.float16 else 0.8) * len(need)   # bf16 storage: 8 mantissa bits (the GPU suite's bf16 bound is looser still)
 
 
-def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim):
-    """the fp32 parity mode (csrc/conv_f32.hip, fp32 pool / upsample / logits: `YOLOv5.set_compute_dtype(torch.float32)` on the GPU) end to end
+@pytest.mark.parametrize("f32_v1", [False, True])
+def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim, f32_v1):
+    """the fp32 mode (csrc/conv_f32_pipe.hip: pipelined fp32 tiles, cv1 + cv2 in one launch, folded upsample; f32_v1: csrc/conv_f32.hip, one launch per
+    reference conv; fp32 pool / upsample / logits: `YOLOv5.set_compute_dtype(torch.float32)` on the GPU) end to end
     on the simulator, yolov5n on two differently shaped images, against the fp32 oracle with the DIRECT checks of SURVEY.md 8d:
     equal counts, equal labels, |score difference| <= 1e-4, IoU >= 1 - 1e-3"""
     from oracle import yolov5_oracle as O
@@ -253,12 +259,15 @@ def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim):
         ref = O.yolov5_forward(imgs, {k: v.float() for k, v in model.state_dict().items()}, size=(S, S), score_thresh=thr)
     canvas, _ = _sim_letterbox(sim, imgs, S, dtype)
     n, hb, wb, _ = canvas.shape
-    plan = _sim_plan(sim, dtype, fuse_c3=False)
+    plan = _sim_plan(sim, dtype, fuse_c3=False, f32_v1=f32_v1)
     x = plan.alloc(n, hb, wb, 4, zero=True)
     x.as_tensor().copy_(canvas)
     yolo = model.model
     feats = yolo.backbone.emit(plan, x)
     logits = yolo.head.emit(plan, feats)
+    if not f32_v1:   # the launches the GPU plan records: pipelined tiles everywhere, the C3 pairs and both folded upsamples
+        assert all(201 <= t <= 206 for t in plan.lib.tiles), plan.lib.tiles
+        assert sum(n_.endswith(".cv1+cv2") for n_ in plan.names) == 8 and not any("upsample" in n_ or "inner_blocks.2" in n_ or "inner_blocks.5" in n_ for n_ in plan.names), plan.names
     ag = yolo.anchor_generator
     rescale = torch.zeros(n, 3, dtype=torch.float32)
     for i, im in enumerate(imgs):

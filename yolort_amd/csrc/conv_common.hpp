@@ -664,6 +664,9 @@ __device__ __forceinline__ void finish_wave_tile_chain(const ConvArgs& a, const 
 
 // fp32 parity-mode kernel (conv_f32.hip): fp32 activations / weights / arithmetic
 int conv_f32_launch(const ConvArgs& a, bool is1x1, hipStream_t s);
+// fp32 mode, LDS-DMA pipelined tiles 201-206 (conv_f32_pipe.hip; tile 0 = chosen from the shape by conv_f32_pick_tile)
+int conv_f32_pipe_launch(const ConvArgs& a, bool is1x1, int tile, hipStream_t s);
+int conv_f32_pick_tile(int M, int cout_pad);
 // 3x3 stride-1 LDS-halo kernel (conv3x3_halo.hip); returns YMI_EINVAL when the shape does not apply
 int conv3x3_halo_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s);
 // 8-wave LDS-halo 3x3 stride-1 kernel (conv_halo8.hip), patch shape chosen per feature-map size

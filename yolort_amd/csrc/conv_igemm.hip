@@ -185,8 +185,11 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
         YMI_REQUIRE(d->y_cstride % 8 == 0 || d->out_dtype == YMI_F32, "ymi_conv2d: y_cstride must be a multiple of 8");
     }
     if (a.M == 0) return YMI_OK;
-    if (d->dtype == YMI_F32) {   // fp32 parity mode (conv_f32.hip): exact fp32 arithmetic, one tile configuration
-        YMI_REQUIRE(d->chain_w == nullptr && d->y2_mode == 0, "ymi_conv2d: fp32 parity mode has no chained conv / upsampled second output");
+    if (d->dtype == YMI_F32) {   // fp32 mode: exact fp32 arithmetic.  LDS-DMA pipelined tiles (conv_f32_pipe.hip) whenever the zero page is supplied;
+        // a negative tile id (or no zero page: foreign input buffers) selects the register-staged kernel of rounds 2-4 (conv_f32.hip)
+        YMI_REQUIRE(d->chain_w == nullptr, "ymi_conv2d: the fp32 mode has no chained convolution");
+        if (d->tile >= 0 && a.zeros != nullptr) return conv_f32_pipe_launch(a, is1x1, d->tile, s);
+        YMI_REQUIRE(d->y2_mode == 0, "ymi_conv2d: the register-staged fp32 kernel has no upsampled second output");
         return conv_f32_launch(a, is1x1, s);
     }
     if (d->dtype == YMI_F16) {
@@ -368,6 +371,7 @@ extern "C" int ymi_conv_head_decode(const ymi_conv_desc* conv, const ymi_post_de
     return ymi::conv_head_decode_launch(conv, post, level, (hipStream_t)stream);
 }
 
+extern "C" int ymi_conv_f32_pick_tile(int m_pixels, int cout_pad) { return ymi::conv_f32_pick_tile(m_pixels, cout_pad); }
 extern "C" int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_pad, int32_t* t) {
     if (cin % 8 != 0 || k_pad % 32 != 0 || t == nullptr) {
         ymi::set_error("ymi_conv_build_ktab: cin %% 8 and k_pad %% 32 must be 0");

@@ -199,11 +199,17 @@ class Plan:
         self.rw3 = os.environ.get("YOLORT_AMD_RW3", "0") == "1"   # tile 135 (its K-split form, cin = 128): opt-in until measured
         self.rs = os.environ.get("YOLORT_AMD_RS", "0") == "1"     # tiles 137 / 138 (row-streaming 3x3, conv3x3_rs.hip): opt-in until measured
         if self.fp32:
+            # fp32 mode: the LDS-DMA pipelined fp32 tiles (csrc/conv_f32_pipe.hip, tiles 201-206, chosen from the shape by the library) with the fusions that do not
+            # change what is summed -- cv1 + cv2 of a C3 in one launch, the PAN's nn.Upsample folded into its producer -- and none that hold 16-bit operands in
+            # registers (chained 1x1s, the five-layer C3, the fused stem, the fused head).  YOLORT_AMD_F32_V1=1: the register-staged kernel of rounds 2-4
+            # (csrc/conv_f32.hip), one launch per reference conv -- the A/B and bisect partner.
             self.res3x3 = 0
             self.rw2, self.rw3, self.rs = 0, False, False
-            self.use_v1, self.chain_1x1, self.chain_cv3, self.autotune = True, False, False, False
+            self.use_v1 = os.environ.get("YOLORT_AMD_F32_V1", "0") == "1"
+            self.chain_1x1, self.chain_cv3 = False, False
             self.fuse_c3 = False
             self.chain_next = False
+            self.chain128 = 0
 
     def __del__(self):
         try:
@@ -342,7 +348,9 @@ class Plan:
                 d.tile = pinned
         if d.tile == 0 and chain is not None and getattr(self, "chain128", 0) and (split if out2 is not None else pc.cout) == 128 and (len(chain) < 3 or chain[2] is None):
             d.tile = int(self.chain128)
-        esz = 2
+        esz = 4 if self.fp32 else 2
+        if self.fp32 and d.tile == 0 and d.zeros:
+            d.tile = int(self.lib.ymi_conv_f32_pick_tile(x.n * ho * wo, pc.cout_pad))   # what the library would choose itself: recorded so that the layer tables name the tile
         flops = 2.0 * x.n * ho * wo * pc.cout * pc.k_real  # algorithmic MACs (zero padding not counted)
         # algorithmic bytes follow SURVEY.md 8d: every reference conv reads its input once and writes its
         # output once; a fused cv1+cv2 launch stands for two reference convs, so its input counts twice.
@@ -394,6 +402,8 @@ class Plan:
         hit = Plan._TUNE_CACHE.get(key)
         if hit is not None:
             return hit
+        if self.fp32:
+            return self._autotune_time(d, key, [201, 202, 203, 204, 205, 206])
         cands = [11, 12, 14, 15, 21, 22, 24, 25, 27]
         if d.cout_pad <= 32:
             cands = [13, 23, 26, 25]
@@ -451,6 +461,9 @@ class Plan:
                 cands = cands + [133]   # ... weights in registers, two blocks per CU (conv3x3_rw.hip)
         if d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.x_cstride == 8 and d.cout_pad <= 64 and not d.res:
             cands = cands + [41]   # dedicated stem kernel
+        return self._autotune_time(d, key, cands)
+
+    def _autotune_time(self, d: ConvDesc, key: Tuple, cands: List[int]) -> int:
         best, best_ms = 0, float("inf")
         stream = _lib.stream_ptr()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -511,18 +524,18 @@ class Plan:
     def spp_pool(self, buf: View, c: int, name: str = "spp_pool") -> None:
         assert buf.c == 4 * c
         self._record(self.lib.ymi_plan_add_spp_pool(self.handle, buf.ptr, buf.n, buf.h, buf.w, c, buf.cs, dtype_code(buf.dtype)), name,
-                     kind="pool", flops=0.0, bytes=float(buf.n * buf.h * buf.w * c * 2 * 4), shape=f"c{c} {buf.h}x{buf.w}")
+                     kind="pool", flops=0.0, bytes=float(buf.n * buf.h * buf.w * c * buf.base.element_size() * 4), shape=f"c{c} {buf.h}x{buf.w}")
 
     def upsample2x(self, x: View, out: View, name: str = "upsample2x") -> View:
         assert (out.n, out.h, out.w, out.c) == (x.n, 2 * x.h, 2 * x.w, x.c)
         self._record(self.lib.ymi_plan_add_upsample2x(self.handle, x.ptr, x.cs, x.n, x.h, x.w, x.c, out.ptr, out.cs, dtype_code(x.dtype)), name,
-                     kind="upsample", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * 2 * 5), shape=f"c{x.c} {x.h}x{x.w}")
+                     kind="upsample", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * x.base.element_size() * 5), shape=f"c{x.c} {x.h}x{x.w}")
         return out
 
     def copy(self, x: View, out: View, name: str = "copy") -> View:
         assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, x.c)
         self._record(self.lib.ymi_plan_add_copy_view(self.handle, x.ptr, x.cs, x.n * x.h * x.w, x.c, out.ptr, out.cs, dtype_code(x.dtype)), name,
-                     kind="copy", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * 2 * 2), shape=f"c{x.c} {x.h}x{x.w}")
+                     kind="copy", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * x.base.element_size() * 2), shape=f"c{x.c} {x.h}x{x.w}")
         return out
 
     def post_desc(self, levels: Sequence[Tuple[int, int]], n: int, strides: Sequence[float], anchors: Sequence[Sequence[float]], num_classes: int,
@@ -637,7 +650,7 @@ class Plan:
 
     def stem_planar_ok(self, images: Sequence[Tensor], canvas_hw: Tuple[int, int]) -> bool:
         d = self.conv_descs.get(0)
-        if d is None or not d.zeros or not (d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.cout_pad <= 64 and not d.res):
+        if self.fp32 or d is None or not d.zeros or not (d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.cout_pad <= 64 and not d.res):
             return False
         hb, wb = canvas_hw
         if wb % 8 or d.h != hb or d.w_in * 2 != wb or len(images) != d.n:

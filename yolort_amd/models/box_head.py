@@ -54,7 +54,7 @@ class YOLOHead(HipModule):
 
     def can_fuse_decode(self, plan: Plan, x: Sequence[View]) -> bool:
         """the fused head needs <= 128 outputs per anchor, 3 anchors, 32-aligned input channels and the pipelined kernels"""
-        return (self.num_anchors == 3 and self.num_outputs <= 128 and not plan.use_v1 and all(f.c % 32 == 0 and f.tail >= 0 and f.h * f.w >= 1 for f in x))
+        return (self.num_anchors == 3 and self.num_outputs <= 128 and not plan.use_v1 and not plan.fp32 and all(f.c % 32 == 0 and f.tail >= 0 and f.h * f.w >= 1 for f in x))
 
     def packed_anchor_major(self, i: int, dtype, device, cin_view: int) -> PackedConv:
         """head weights for ymi_conv_head_decode: anchor q's K rows at q*RA .. q*RA+K-1, RA = round_up(K, 32), rest zero"""
