@@ -103,3 +103,115 @@ def test_all_gather_world2_gloo():
     for p in procs:
         p.join(timeout=30)
     assert res == [(0, True, (0, 3)), (1, True, (3, 6))]
+
+
+# ---- round 5: the GLOBAL canvas of a sharded dynamic-shape stream (reference transform.py:307-314) and the stale protocol at world 4 ----------
+def _canvas_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import yolov5_oracle as O
+        from yolort_amd import dist as yd
+        from yolort_amd.models import YOLOv5
+        from yolort_amd.utils.synth import synth_images, synth_weights
+        torch.set_num_threads(2)
+        arch, S, thr, k = "yolov5_darknet_pan_n_r60", 96, 0.2, 300
+        # four images whose shards have DIFFERENT local maxima: rank 0 sees two landscape images (local canvas 64 x 96 / 72 -> 96 x 96 after the resize rule below),
+        # rank 1 a portrait and a small landscape one
+        shapes = [(60, 96), (48, 96), (96, 56), (40, 72)]
+        model = YOLOv5(arch=arch, size=(S, S), score_thresh=thr)
+        sd = synth_weights(model.state_dict(), arch, seed=0, head_gain=0.6)
+        imgs = [synth_images(1, h, w, seed=40 + i)[0] for i, (h, w) in enumerate(shapes)]
+        lo, hi = yd.shard_range(len(imgs), rank, world)
+        t = model.transform
+        local = t.canvas_of(shapes[lo:hi])
+        agreed = yd.agree_canvas(t, shapes[lo:hi])
+        ok = agreed == t.canvas_of(shapes)            # == the canvas the reference pads the WHOLE list to
+        with torch.no_grad():
+            single = O.yolov5_forward(imgs, sd, size=(S, S), score_thresh=thr)                                   # the reference's semantics: one process, whole list
+            mine_global = O.yolov5_forward(imgs[lo:hi], sd, size=(S, S), score_thresh=thr, fixed_shape=agreed)    # this rank's shard on the agreed canvas
+            mine_local = O.yolov5_forward(imgs[lo:hi], sd, size=(S, S), score_thresh=thr)                         # ... on its own canvas (what round 4 did)
+        full = yd.gather_detections(mine_global, k)
+        same = all(torch.equal(f["labels"], s_["labels"]) and torch.equal(f["scores"], s_["scores"]) and torch.equal(f["boxes"], s_["boxes"]) for f, s_ in zip(full, single))
+        ok = ok and len(full) == len(imgs) and same and sum(len(s_["scores"]) for s_ in single) >= 8
+        full_local = yd.gather_detections(mine_local, k)
+        differs = any(f["scores"].shape != s_["scores"].shape or not torch.equal(f["boxes"], s_["boxes"]) for f, s_ in zip(full_local, single))
+        # the product's host geometry for this shard on the agreed canvas == the single-process geometry of the same images (sizes, pads, rescale rows)
+        from yolort_amd.models.transform import rescale_params
+        (hb, wb), sizes_all, pads_all = t.geometry(shapes)
+        (hb2, wb2), sizes_sh, pads_sh = t.geometry(shapes[lo:hi], canvas=agreed)
+        ok = ok and (hb2, wb2) == (hb, wb) and sizes_sh == sizes_all[lo:hi] and pads_sh == pads_all[lo:hi]
+        ok = ok and [rescale_params((hb2, wb2), o) for o in shapes[lo:hi]] == [rescale_params((hb, wb), o) for o in shapes[lo:hi]]
+        try:
+            t.geometry(shapes, canvas=(32, 32))
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, bool(ok), bool(differs), tuple(local), tuple(agreed)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_dynamic_shape_stream_on_the_global_canvas_equals_the_single_process_result_world2_gloo():
+    """Two ranks whose shards have different local canvases agree on the canvas of the whole list (one MAX all-reduce of two integers), letterbox onto it, and the
+    gathered detections equal the single-process result on the whole list bit for bit; on their own canvases they do not (the reference pads to the maximum over the
+    WHOLE list, transform.py:307-314).  The arithmetic here is the oracle's (CPU); that the HIP path honours `canvas=` is tests/test_e2e_gpu.py's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_canvas_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=280) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res
+    assert res[0][3] != res[1][3] and res[0][4] == res[1][4] == (96, 96), res      # different local canvases, one agreed canvas
+    assert res[0][2] or res[1][2], "per-rank canvases were expected to change some shard's detections"
+
+
+def _stale4_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolort_amd import dist as yd
+        n, k = 8, 4
+        lo, hi = yd.shard_range(n, rank, world)
+        g = torch.Generator().manual_seed(99)
+        boxes, scores, labels = torch.rand(n, k, 4, generator=g), torch.rand(n, k, generator=g), torch.randint(0, 80, (n, k), generator=g)
+        count = torch.tensor([4, 0, 3, 1, 4, 2, 2, 4], dtype=torch.int32)
+        stale_ranks = (1, 3)    # two of the four ranks have to re-run the batch locally
+        stale = torch.tensor([1 if rank in stale_ranks else 0], dtype=torch.int32)
+        wrong = torch.full_like(scores[lo:hi], -7.0)
+        local = yd.pack_slab(boxes[lo:hi], wrong if rank in stale_ranks else scores[lo:hi], labels[lo:hi], count[lo:hi], stale=stale)
+        out = torch.empty(world * local.shape[0], local.shape[1])
+        dist.all_gather_into_tensor(out, local)
+        first = yd.unpack_slab(out, k)
+        ok = first[3].tolist() == [4, 0, -1, -1, 4, 2, -1, -1]
+        calls = []
+
+        def final():
+            calls.append(1)
+            return boxes[lo:hi], scores[lo:hi], labels[lo:hi], count[lo:hi]
+        (b, s, l, c), second = yd.resolve_stale(first, final)
+        ok = ok and second and len(calls) == 1 and torch.equal(b, boxes) and torch.equal(s, scores) and torch.equal(l, labels) and torch.equal(c, count)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_stale_shard_protocol_world4_two_stale_ranks_gloo():
+    """the second round of the per-batch exchange (dist.resolve_stale) with four ranks of which two marked their shard stale: every rank sees both markers in its own
+    copy of the first slab, all four enter the second all-gather exactly once, and the final slab is the global batch"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stale4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert res == [(r, True) for r in range(4)]

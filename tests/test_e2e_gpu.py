@@ -377,3 +377,35 @@ def test_api_errors(dev):
         m.forward([torch.rand(3, 64, 64)])  # CPU tensor: no fallback
     out = m.predict(torch.rand(3, 64, 64, device=dev))
     assert out[0]["boxes"].shape == (0, 4) and out[0]["scores"].shape == (0,) and out[0]["labels"].dtype == torch.int64
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_sharded_dynamic_shape_batch_on_the_global_canvas_equals_the_whole_batch(dev, dtype):
+    """SURVEY.md 8e / reference transform.py:307-314: the reference pads to the maximum over the WHOLE list.  A list of differently shaped images is run (a) as one
+    batch and (b) as two shards whose own canvases differ from each other, each letterboxed onto the canvas of the whole list (`canvas=`, what every rank of a
+    sharded stream passes: transform.canvas_of / dist.agree_canvas): the shards' detections equal the whole batch's BIT FOR BIT (an image's computation does not
+    depend on its batch neighbours once the canvas is fixed); on their own canvases they differ.  fp32 mode: shards of two images against the batch of four (every
+    fp32 tile sums in the same order, so the batch size does not matter either); fp16: the shards are filled up to the whole batch's size with copies, so that both
+    runs take the same plan (16-bit plans of different batch sizes may pick tiles that accumulate K in another order)."""
+    from yolort_amd.utils.synth import synth_images
+    arch, S = "yolov5_darknet_pan_s_r60", 320
+    m = _model(arch, dev, torch.float16 if dtype == torch.float16 else torch.float32, size=(S, S), score_thresh=0.2, head_gain=0.5)
+    if dtype == torch.float32:
+        m = m.float().set_compute_dtype(torch.float32)
+    shapes = [(200, 320), (150, 320), (320, 180), (120, 240)]      # shard 0: two landscape images (canvas 224 x 320), shard 1: a portrait and a small one (320 x 192 -> 320 x 320)
+    imgs = [synth_images(1, h, w, seed=60 + i)[0].to(dev).to(dtype) for i, (h, w) in enumerate(shapes)]
+    t = m.transform
+    whole_canvas = t.canvas_of(shapes)
+    local = [t.canvas_of(shapes[:2]), t.canvas_of(shapes[2:])]
+    assert local[0] != whole_canvas and local[0] != local[1]
+    fill = 1 if dtype == torch.float32 else 2
+    sh0, sh1 = imgs[:2] * fill, imgs[2:] * fill
+    whole = [_np(d) for d in m.forward(imgs)]
+    shards = [_np(d) for d in m.forward(sh0, canvas=whole_canvas)[:2]] + [_np(d) for d in m.forward(sh1, canvas=whole_canvas)[:2]]
+    assert sum(len(d["scores"]) for d in whole) >= 8
+    for a, b in zip(whole, shards):
+        assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["scores"], b["scores"]) and np.array_equal(a["boxes"], b["boxes"])
+    own = [_np(d) for d in m.forward(sh0)[:2]] + [_np(d) for d in m.forward(sh1)[:2]]
+    assert any(a["scores"].shape != b["scores"].shape or not np.array_equal(a["boxes"], b["boxes"]) for a, b in zip(whole[:2], own[:2]))   # shard 0's own canvas is 224 x 320
+    with pytest.raises(ValueError):
+        m.forward(imgs, canvas=(64, 64))

@@ -1213,7 +1213,7 @@ def _f32_desc(x_buf, pc, y, tile, k, s_, p, res=None, y2=None, split=0, up2=Fals
 
 
 @pytest.mark.parametrize("tile", [201, 202, 203, 204, 205, 206, 0])
-@pytest.mark.parametrize("k,s_,cin,cout", [(1, 1, 64, 96), (1, 1, 40, 128), (3, 1, 32, 40), (3, 2, 48, 64), (3, 1, 24, 32), (6, 2, 4, 32)])
+@pytest.mark.parametrize("k,s_,cin,cout", [(1, 1, 64, 96), (1, 1, 40, 128), (3, 1, 32, 40), (3, 2, 48, 64), (3, 1, 24, 32), (6, 2, 4, 32), (1, 1, 16, 32), (1, 1, 8, 40)])
 def test_fp32_pipelined_kernel_logic(sim, tile, k, s_, cin, cout):
     """csrc/conv_f32_pipe.hip (round 5: the fp32 mode's LDS-DMA pipelined tiles): every tile in its three operand forms (pointwise, uniform tap,
     im2col table) against torch's fp32 convolution to rounding-order accuracy, and against the register-staged kernel it replaces"""

@@ -278,3 +278,75 @@ def test_evaluator_consumes_the_gathered_slab():
     import pytest
     with pytest.raises(ValueError):
         DetectionEvaluator(3).update_from_slab(stale, tg)
+
+
+def test_pinned_resident_weight_tiles_are_validated_against_the_launch():
+    """engine.Plan._pinned_ok: a table entry >= 132 is keyed by shape only; the kernels behind tiles 132-138 also require SiLU, no chained conv, 32-bit
+    offsets ... -- a launch that does not meet them must fall through to the general tiles instead of failing at plan build, and an explicit opt-out wins over the table"""
+    from yolort_amd import engine
+    from yolort_amd._lib import ACT_NONE, ACT_SILU, ConvDesc, YMI_F16
+
+    def desc(cin, cout, s, act, h=80):
+        d = ConvDesc()
+        d.n, d.h, d.w_in, d.cin, d.x_cstride = 32, h, h, cin, cin
+        d.ho = d.wo = (h + 2 - 3) // s + 1
+        d.cout, d.cout_pad, d.y_cstride, d.res_cstride = cout, (cout + 31) // 32 * 32, cout, 0
+        d.kh = d.kw = 3
+        d.sh = d.sw = s
+        d.ph = d.pw = 1
+        d.k_pad, d.act, d.dtype, d.out_dtype = 9 * cin, act, YMI_F16, YMI_F16
+        d.zeros = 1   # (a non-null zero page)
+        return d
+
+    p = engine.Plan.__new__(engine.Plan)
+    p.res3x3, p.rw2, p.rw3, p.rs = 2, 1, False, False
+    assert p._pinned_ok(desc(64, 64, 1, ACT_SILU), 133) and p._pinned_ok(desc(64, 64, 1, ACT_SILU), 132)
+    assert not p._pinned_ok(desc(64, 64, 1, ACT_NONE), 133)             # Conv(act=False) on a pinned shape: tile 133's launcher requires SiLU
+    assert p._pinned_ok(desc(64, 64, 1, ACT_NONE), 132)                 # ... tile 132 takes it
+    assert p._pinned_ok(desc(64, 128, 2, ACT_SILU), 134) and not p._pinned_ok(desc(64, 128, 2, ACT_NONE), 134)
+    assert p._pinned_ok(desc(64, 64, 1, ACT_SILU), 137) and not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 138)   # 138 is the stride-2 form
+    assert p._pinned_ok(desc(128, 128, 2, ACT_SILU), 135) and not p._pinned_ok(desc(128, 128, 2, ACT_NONE), 135)
+    assert p._pinned_ok(desc(128, 128, 1, ACT_NONE), 143)               # row-transposed-store forms of the general tiles: no such preconditions
+    p.res3x3, p.rw2 = 0, 0                                              # YOLORT_AMD_RES3X3=0 / YOLORT_AMD_RW2=0 win over the table
+    assert not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 133) and not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 132) and not p._pinned_ok(desc(64, 128, 2, ACT_SILU), 134)
+
+
+def test_weights_signature_sees_every_way_a_module_tree_can_change():
+    """hipmodule.weights_signature is the plan cache's key: it re-reads the live `_parameters` / `_buffers` / `_modules` dicts on every call (the round-4
+    form cached the tensor objects behind process-wide registration hooks and missed `del`, `= None` and `_apply` with overwrite-on-conversion)"""
+    import copy
+
+    from torch import nn
+
+    from yolort_amd.hipmodule import weights_signature
+    from yolort_amd.models import yolo
+
+    base = yolo.yolov5_darknet_pan_n_r60().eval()
+    s0 = weights_signature(base)
+    assert weights_signature(base) == s0 and weights_signature(copy.deepcopy(base)) != s0    # stable; another set of tensors is another key
+    import torch.nn.modules.module as M
+    assert not M._global_parameter_registration_hooks and not M._global_buffer_registration_hooks and not M._global_module_registration_hooks   # importing the package installs no process-wide hooks
+
+    def changed(mutate):
+        m = copy.deepcopy(base)
+        a = weights_signature(m)
+        mutate(m)
+        return weights_signature(m) != a
+
+    assert changed(lambda m: m.head.head.__delitem__(2))                                      # a sub-module deleted (__delattr__ fires no registration hook)
+    assert changed(lambda m: setattr(m.head.head[0], "bias", None))                           # register_parameter(None) fires none either
+    def convert(m):
+        torch.__future__.set_overwrite_module_params_on_conversion(True)
+        try:
+            m.double()                                                                        # _apply writes NEW Parameter objects straight into _parameters
+        finally:
+            torch.__future__.set_overwrite_module_params_on_conversion(False)
+    assert changed(convert)
+    def inplace(m):
+        with torch.no_grad():
+            m.head.head[0].weight.add_(1.0)
+    assert changed(inplace)                                                                   # _version
+    assert changed(lambda m: m.half())                                                        # same Parameter objects, new storage: data_ptr
+    assert changed(lambda m: m.backbone.body["0"].act.register_buffer("k", torch.zeros(1)))   # a buffer on a module that had no tensors
+    assert changed(lambda m: m.backbone.body["0"].act.add_module("extra", nn.Conv2d(1, 1, 1)))  # a child under a former leaf
+    assert changed(lambda m: m.head.head.__setitem__(1, nn.Conv2d(256, 255, 1)))              # a replaced sub-module

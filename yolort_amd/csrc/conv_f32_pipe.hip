@@ -48,16 +48,26 @@ __device__ __forceinline__ void pair_even_odd(f32x4& f) {
 }
 
 // MODE 0: im2col table (any cin % 8 == 0: the stem's super-pixels), 1: pointwise (k1 s1 p0), 2: uniform tap (cin % 16 == 0: a step lies inside one tap)
+// What was tried on top of this loop in round 5 and measured on every convolution of the yolov5s bs-32 plan (profiles/r05c_f32_tile_sweep_pipelined_c2.txt,
+// r05d_f32_tile_experiments_c2.txt, r05d_f32_one_block_per_cu_c2.txt) -- all bit-identical, none kept:
+//   * a software-pipelined loop (next half-step's ds_read_b128 and the ring refill issued between the MFMAs): +-1 % on every layer -- the 64-cycle f32 MFMA leaves the
+//     issue port idle anyway;
+//   * a four-deep ring: +-1 % (the loop is not DMA-latency-bound);
+//   * single-wave blocks of 64 x 64 (no s_barrier at all): 1.2-1.3 x SLOWER (twice the L2 -> LDS operand traffic per flop);
+//   * one block per CU (LDS floor): 1.2-1.7 x slower -- a single block reaches ~0.6 of its matrix-pipe time, the second resident block fills the rest.
+// SQ_VALU_MFMA_BUSY_CYCLES is 0.53 of the SIMD-cycles at an effective clock of 2.3 GHz (profiles/r05b_rocprof_summary_c2_fp32.csv): the remainder is block-count
+// quantisation over 256 CUs (400-800 blocks per launch at 40 x 40 / 20 x 20), the LDS-DMA issue cost inside the MFMA stream and the exact-SiLU epilogue.
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a) {
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-    static_assert(BM % 64 == 0 && BN % 16 == 0, "activation pieces are dealt 1:1 to the 4 waves");
+    constexpr int NW = 4;
+    static_assert((BM / WM) * (BN / WN) == NW, "4 waves per block");
+    static_assert(BM % 16 == 0 && BN % 16 == 0 && (BM / 16) % NW == 0, "activation pieces are dealt evenly to the waves");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int PA = BM / 64;                  // activation pieces (1 KiB = 16 rows x 64 B) per wave per stage
+    constexpr int PA = BM / 16 / NW;             // activation pieces (1 KiB = 16 rows x 64 B) per wave per stage
     constexpr int W_PIECES = BN / 16;
-    constexpr int PW = (W_PIECES + 3) / 4;       // weight pieces per wave per stage (surplus waves re-send the last piece: identical bytes)
+    constexpr int PW = (W_PIECES + NW - 1) / NW; // weight pieces per wave per stage (surplus waves re-send the last piece: identical bytes)
     constexpr int P = PA + PW;                   // DMA instructions per wave per stage, the same for every wave
     constexpr int STAGE_BYTES = (BM + BN) * 64;
 
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a)
         }
 
     if constexpr (MODE == 0) {
-        for (int i = tid; i < a.k_pad / 8; i += 256) ktab_lds[i] = a.ktab[i];
+        for (int i = tid; i < a.k_pad / 8; i += 64 * NW) ktab_lds[i] = a.ktab[i];
     }
 
     // ---- per-lane DMA geometry (element = float offsets against a.x / a.w; out-of-range chunks read the zero page in x's own tail) ----
@@ -134,38 +144,45 @@ __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a)
     }
 
     int u_tap = 0, u_c0 = 0, u_dx = 0, u_kbase = 0;   // MODE 2 running state (stages are issued in order): wave-uniform scalars
-    auto issue = [&](int step) {
-        unsigned char* const stage = f32p_sm + (step % STAGES) * STAGE_BYTES;
-        int koff = 0, dy = 0, dx = 0;
-        bool tap_ok = true;
+    // one stage = issue_begin(step); issue_piece(0 .. P-1); issue_end()   (pieces 0 .. PA-1 activations, PA .. P-1 weights)
+    unsigned char* cur_stage = f32p_sm;
+    int cur_koff = 0, cur_dy = 0, cur_dx = 0, cur_step = 0;
+    bool cur_tap_ok = true;
+    auto issue_begin = [&](int step) {
+        cur_stage = f32p_sm + (step % STAGES) * STAGE_BYTES;
+        cur_step = step;
         if constexpr (MODE == 2) {
-            koff = u_kbase + chunk * 4;
+            cur_koff = u_kbase + chunk * 4;
         } else if constexpr (MODE == 1) {
-            koff = step * FBK + chunk * 4;
-            tap_ok = koff < a.cin;
+            cur_koff = step * FBK + chunk * 4;
+            cur_tap_ok = cur_koff < a.cin;
         } else {
             const int2 t = ktab_lds[step * 2 + (chunk >> 1)];   // one table entry per 8 elements: two 4-float chunks
-            koff = t.x + (chunk & 1) * 4;
-            tap_ok = t.y >= 0;
-            dy = t.y >> 16;
-            dx = t.y & 0xffff;
+            cur_koff = t.x + (chunk & 1) * 4;
+            cur_tap_ok = t.y >= 0;
+            cur_dy = t.y >> 16;
+            cur_dx = t.y & 0xffff;
         }
-#pragma unroll
-        for (int j = 0; j < PA; ++j) {
+    };
+    auto issue_piece = [&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        if constexpr (j < PA) {
             bool ok;
             if constexpr (MODE == 2) {
                 ok = (a_aux[j] >> u_tap) & 1;
             } else {
-                ok = tap_ok & (a_aux[j] >= 0);
+                ok = cur_tap_ok & (a_aux[j] >= 0);
                 if constexpr (MODE == 0) {
-                    const int iy = (a_aux[j] >> 16) - 16384 + dy, ix = (a_aux[j] & 0xffff) - 16384 + dx;
+                    const int iy = (a_aux[j] >> 16) - 16384 + cur_dy, ix = (a_aux[j] & 0xffff) - 16384 + cur_dx;
                     ok = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w_in);
                 }
             }
-            glds16f(X + (ok ? a_off[j] + koff : a.x_zero_off), stage + (wave * PA + j) * 1024);
+            glds16f(X + (ok ? a_off[j] + cur_koff : a.x_zero_off), cur_stage + (wave * PA + j) * 1024);
+        } else if constexpr (j < P) {
+            glds16f(Wt + (w_off[j - PA] + cur_step * FBK), cur_stage + w_slot[j - PA]);
         }
-#pragma unroll
-        for (int j = 0; j < PW; ++j) glds16f(Wt + (w_off[j] + step * FBK), stage + w_slot[j]);
+    };
+    auto issue_end = [&]() {
         if constexpr (MODE == 2) {
             u_c0 += FBK;
             u_kbase += FBK;
@@ -181,6 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a)
             }
         }
     };
+    auto issue = [&](int step) {
+        issue_begin(step);
+        static_for<0, P>(issue_piece);
+        issue_end();
+    };
 
     f32x16 acc[TN][TM], part[TN][TM];
 #pragma unroll
@@ -191,12 +213,22 @@ __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a)
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; part[i][j][r] = 0.f; }
 
     if constexpr (MODE == 0) __syncthreads();   // table visible (no DMA in flight yet)
+    const int swz = (lane >> 2) & 3;
+    const int pos0 = ((0 + hi) ^ swz) * 16, pos1 = ((2 + hi) ^ swz) * 16;   // byte offset of this lane's k-chunk within its row, ks = 0 / 1
+    auto fold = [&](int step) {
+        if ((step & 3) == 3 || step + 1 == nsteps) {   // 64 k per partial sum
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[i][j][r] += part[i][j][r]; part[i][j][r] = 0.f; }
+        }
+    };
+
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nsteps) issue(s);
-
-    const int swz = (lane >> 2) & 3;
-    const int pos0 = ((0 + hi) ^ swz) * 16, pos1 = ((2 + hi) ^ swz) * 16;   // byte offset of this lane's k-chunk within its row, ks = 0 / 1
 
     for (int step = 0; step < nsteps; ++step) {
         // this wave's pieces of stage `step` have landed once at most `ahead` later stages are pending
@@ -232,14 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a)
                     for (int j = 0; j < TM; ++j) part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][e], af[j][e], part[i][j], 0, 0, 0);
             }
         }
-        if ((step & 3) == 3 || step + 1 == nsteps) {   // 64 k per partial sum
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc[i][j][r] += part[i][j][r]; part[i][j][r] = 0.f; }
-        }
+        fold(step);
     }
 
     // ---- epilogue: + bias, exact SiLU, + shortcut (after the activation), 16-byte fp32 stores ----

@@ -24,6 +24,22 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def agree_canvas(transform, local_shapes, group=None) -> Tuple[int, int]:
+    """The reference's batch canvas of the GLOBAL list when every rank only knows the (h, w) of its own shard: each rank computes the canvas of its
+    images (`YOLOTransform.canvas_of`: resize rule, maximum, round up to `size_divisible` -- all integers), one MAX all-reduce of two integers combines them.
+    max over ranks of ceil(max_r / d) * d == ceil(max over everything / d) * d, so the result is exactly `transform.canvas_of(all shapes)` -- the canvas the
+    reference would pad the whole list to (transform.py:307-314).  Host-side and tiny; ranks that already know every image size (the process that shards the
+    stream usually does) call `transform.canvas_of(all_shapes)` instead and skip the collective.  An empty shard contributes (0, 0)."""
+    hb, wb = transform.canvas_of(local_shapes) if len(local_shapes) else (0, 0)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return hb, wb
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([hb, wb], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hb, wb = (int(v) for v in t.tolist())
+    return hb, wb
+
+
 SLAB_STALE = -1   # count column of a shard whose rank has to re-run the batch locally (see resolve_stale)
 
 

@@ -332,7 +332,7 @@ class Plan:
             pinned = tile_table().get(tile_key_str(tkey, self.dtype), 0) if self.use_tile_table else 0
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
-            elif pinned >= 132 and os.environ.get("YOLORT_AMD_RULES_FIRST", "0") != "1":
+            elif pinned >= 132 and os.environ.get("YOLORT_AMD_RULES_FIRST", "0") != "1" and self._pinned_ok(d, pinned):
                 d.tile = pinned   # an entry written by a tuner that knew the resident-weights kernels (tiles 132 ...): it has measured them against each other on this shape
             elif self.rs and self._rs_ok(d):
                 d.tile = 136 + d.sh   # row-streaming 3x3 (conv3x3_rs.hip): tile 137 (stride 1, 64 -> 64, no shortcut) / 138 (stride 2, 64 -> 128); YOLORT_AMD_RS=0 keeps tiles 133 / 134
@@ -366,6 +366,23 @@ class Plan:
                      ref_convs=ref_reads + (1 if chain is not None else 0), tile=int(d.tile),
                      shape=f"{x.c}->{pc.cout} k{pc.kh}x{pc.kw} s{s[0]} {x.h}x{x.w}->{ho}x{wo}")
         return out
+
+    def _pinned_ok(self, d: ConvDesc, tile: int) -> bool:
+        """A table entry >= 132 names a kernel with hard preconditions the table key does not carry (activation, a chained conv, the shortcut's stride, 32-bit offsets):
+        it is taken only when THIS launch meets them, and an explicit opt-out (YOLORT_AMD_RES3X3=0 / RW2=0 / RW3=0 / RS=0) wins over the table.  Otherwise the rule chain /
+        the general tiles apply -- a Conv with another activation on a pinned shape builds its plan instead of failing."""
+        env = os.environ.get
+        if tile == 132:
+            return bool(self.res3x3) and self._res3x3_ok(d)
+        if tile == 133:
+            return self.res3x3 == 2 and self._res3x3_ok(d) and d.cout == 64 and d.act == ACT_SILU and not d.chain_w
+        if tile in (134, 136):
+            return bool(self.rw2) and self._rw2_ok(d)
+        if tile == 135:
+            return env("YOLORT_AMD_RW3", "1") != "0" and self._rw3_ok(d)
+        if tile in (137, 138):
+            return env("YOLORT_AMD_RS", "1") != "0" and self._rs_ok(d) and tile == 136 + d.sh
+        return tile in (141, 142, 143, 144, 145, 151, 152, 155) and d.out_dtype == d.dtype   # row-transposed-store forms: general tiles (the kernels fall back inside for the cases they do not take)
 
     @staticmethod
     def _res3x3_ok(d: ConvDesc) -> bool:
@@ -403,7 +420,7 @@ class Plan:
         if hit is not None:
             return hit
         if self.fp32:
-            return self._autotune_time(d, key, [201, 202, 203, 204, 205, 206])
+            return self._autotune_time(d, key, [int(t) for t in os.environ.get("YOLORT_AMD_F32_TUNE_TILES", "201,202,203,204,205,206").split(",")])
         cands = [11, 12, 14, 15, 21, 22, 24, 25, 27]
         if d.cout_pad <= 32:
             cands = [13, 23, 26, 25]

@@ -87,10 +87,22 @@ class YOLOTransform(nn.Module):
         self.fill_color = fill_color / 255
 
     # ---- host geometry -------------------------------------------------------------------
-    def geometry(self, shapes: Sequence[Tuple[int, int]]) -> Tuple[Tuple[int, int], List[Tuple[int, int]], List[Tuple[int, int]]]:
-        """canvas (Hb,Wb), resized sizes and (top,left) pads for a list of (h,w) -- batch_images :297-330"""
+    def canvas_of(self, shapes: Sequence[Tuple[int, int]]) -> Tuple[int, int]:
+        """the reference's batch canvas for a list of (h, w): `fixed_shape`, or the maximum resized size rounded up to `size_divisible`
+        (transform.py:307-314).  A stream that is SHARDED over ranks keeps the reference's detections only when every rank letterboxes onto the canvas of the
+        WHOLE list (the reference pads to the maximum over the whole list, :311): evaluate this on the global list of image sizes -- a host computation over
+        integers -- and hand the result to every rank's `YOLOv5.forward(..., canvas=...)` (or let the ranks agree on it: yolort_amd.dist.agree_canvas)."""
+        return self.geometry(shapes)[0]
+
+    def geometry(self, shapes: Sequence[Tuple[int, int]], canvas: Optional[Tuple[int, int]] = None) -> Tuple[Tuple[int, int], List[Tuple[int, int]], List[Tuple[int, int]]]:
+        """canvas (Hb,Wb), resized sizes and (top,left) pads for a list of (h,w) -- batch_images :297-330.  `canvas`: the canvas of a larger list this one is a
+        shard of (see canvas_of); it takes the place of this list's own maximum exactly like the reference's `fixed_shape` (:307-308) would."""
         sizes = [resized_hw(h, w, float(self.min_size), float(self.max_size)) for h, w in shapes]
-        if self.fixed_shape is not None:
+        if canvas is not None:
+            hb, wb = int(canvas[0]), int(canvas[1])
+            if any(s[0] > hb or s[1] > wb for s in sizes):
+                raise ValueError(f"canvas {(hb, wb)} is smaller than a letterboxed image of this batch ({max(s[0] for s in sizes)} x {max(s[1] for s in sizes)}): it must be the canvas of a list that contains this batch")
+        elif self.fixed_shape is not None:
             hb, wb = int(self.fixed_shape[0]), int(self.fixed_shape[1])
         else:
             stride = float(self.size_divisible)

@@ -49,12 +49,15 @@ class YOLOv5(nn.Module):
         self.model.set_compute_dtype(dtype)
         return self
 
-    def forward(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
+    def forward(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None, canvas: Optional[Tuple[int, int]] = None):
         """inputs: iterable of (3,H,W) tensors in 0-1 range (or uint8 0-255), possibly of different sizes
-        (reference yolov5.py:135-189).  Returns List[Dict] with boxes in ORIGINAL image coordinates."""
-        return self.forward_async(inputs, targets).result()
+        (reference yolov5.py:135-189).  Returns List[Dict] with boxes in ORIGINAL image coordinates.
+        `canvas` (Hb, Wb): letterbox onto the canvas of a LARGER list this batch is a shard of (`transform.canvas_of(all sizes)` /
+        `yolort_amd.dist.agree_canvas`): the reference pads to the maximum over the whole list it is given (transform.py:307-314), so a
+        dynamic-shape stream sharded over ranks reproduces its single-process detections only with the global canvas."""
+        return self.forward_async(inputs, targets, canvas=canvas).result()
 
-    def forward_async(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
+    def forward_async(self, inputs: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None, canvas: Optional[Tuple[int, int]] = None):
         """Enqueues one batch and returns a handle whose `.result()` yields forward()'s List[Dict].
         Serving loops keep two batches in flight (submit i+1, then collect i): the host work and the
         sort/NMS tail of batch i then overlap the convolutions of batch i+1."""
@@ -71,10 +74,11 @@ class YOLOv5(nn.Module):
         original = [self.transform.image_hw(im) for im in images]   # (3, H, W) planar, or (H, W, 3) interleaved uint8
         # host geometry (resize / pad / rescale rows) depends on the list of image sizes only: memoised, a serving loop sees
         # the same few size lists again and again
-        gkey = (tuple(original), self.transform.min_size, self.transform.max_size, self.transform.size_divisible, self.transform.fixed_shape)
+        gkey = (tuple(original), self.transform.min_size, self.transform.max_size, self.transform.size_divisible, self.transform.fixed_shape,
+                None if canvas is None else (int(canvas[0]), int(canvas[1])))
         geo = self._geo_cache.get(gkey) if hasattr(self, "_geo_cache") else None
         if geo is None:
-            (hb, wb), sizes, pads = self.transform.geometry(original)
+            (hb, wb), sizes, pads = self.transform.geometry(original, canvas)
             geo = ((hb, wb), sizes, pads, [rescale_params((hb, wb), o) for o in original],
                    all(o == (hb, wb) for o in original) and all(s_ == (hb, wb) for s_ in sizes))
             if not hasattr(self, "_geo_cache"):
@@ -122,11 +126,11 @@ class YOLOv5(nn.Module):
             return model._submit_entry(e, rows, first_op, ev0, planar=images if planar else None)
 
     @torch.no_grad()
-    def predict(self, x: Any, image_loader: Optional[Callable] = None) -> List[Dict[str, Tensor]]:
-        """Reference yolov5.py:202-216."""
+    def predict(self, x: Any, image_loader: Optional[Callable] = None, canvas: Optional[Tuple[int, int]] = None) -> List[Dict[str, Tensor]]:
+        """Reference yolov5.py:202-216 (`canvas`: see forward -- the global canvas of a sharded list)."""
         image_loader = image_loader or self.default_loader
         images = self.collate_images(x, image_loader)
-        return self.forward(images)
+        return self.forward(images, canvas=canvas)
 
     def default_loader(self, img_path: str) -> Tensor:
         """RGB uint8 image as decoded, (H, W, 3); the permute and the /255 of the reference (yolov5.py:218-228) are fused into
