@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(host cpus, 32))")
     ap.add_argument("--per-op", default="", help="write a per-op profile (json) to this path after the timed run")
     ap.add_argument("--repeats", type=int, default=5, help="the timed region of --steps steps is run this many times back to back; value / ms_per_step are the MEDIAN repeat, all repeats are reported")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="keep repeating the timed region until the regions add up to this much wall time (>= --repeats regions)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("YOLORT_AMD_GRAPH", "0")), help="replay the conv stack as a captured hipGraph")
     a = ap.parse_args()
     preset = CONFIGS[a.config]
@@ -272,16 +273,16 @@ def direct_checks(ref, got, thr, k=300, score_eps=5e-4, iou_min=1 - 1e-3):
 
 def conditioned_parity(args, dev, fp32_only=False):
     """The parity claim on the workload that can carry it (tests/test_golden_gpu.py): the CONDITIONED synthetic network of this architecture
-    (yolort_amd/utils/synth.py COND_*) on its four seeded images, against detections of the UNMODIFIED reference committed as
+    (workloads/synth.py COND_*) on its four seeded images, against detections of the UNMODIFIED reference committed as
     tests/golden/cond_<tag>.npz (made by tests/golden/make_golden.py in the build container) -- no oracle involved at run time.
       fp32 parity mode : every detection paired, same label, IoU >= 1 - 1e-3, |dscore| <= 1e-4, identical label sequences
       production 16-bit: the stated tolerance of tests/test_golden_gpu.py (TOL)"""
     import numpy as np
 
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import cond_images, conditioned_weights
+    from workloads.synth import cond_images, conditioned_weights
 
-    from yolort_amd.utils.synth import spread_images
+    from workloads.synth import spread_images
 
     tag = {"yolov5_darknet_pan_n_r60": "n", "yolov5_darknet_pan_s_r60": "s", "yolov5_darknet_pan_m_r60": "m", "yolov5_darknet_pan_l6_r60": "l6"}.get(args.arch)
     gold = os.path.join(ROOT, "tests", "golden")
@@ -289,6 +290,7 @@ def conditioned_parity(args, dev, fp32_only=False):
         return None
     # stated 16-bit tolerances (tests/test_golden_gpu.py); yolov5l6: none is stated -- the reference's own fp16 run pairs 6 of the golden's 27 detections -- the generous pairing is reported
     tol = {"s": (0.98, 1e-2), "l6": (0.5, 0.1), "n": (0.95, 3e-2), "m": (0.90, 6e-2)}[tag]
+    spread_tol = {"s": (0.98, 1.5e-2)}.get(tag, tol)   # tests/test_golden_gpu.py SPREAD_TOL: constants, the same for every seed
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     mode_list = (("fp32_parity_mode", torch.float32),) if fp32_only else (("fp32_parity_mode", torch.float32), (f"production_{args.dtype}", dt16))
@@ -322,10 +324,9 @@ def conditioned_parity(args, dev, fp32_only=False):
             else:
                 r16 = os.path.join(gold, "ref16_" + os.path.basename(path))
                 own = json.loads(str(np.load(r16)["meta"]))[args.dtype] if os.path.exists(r16) else None
-                # further seeds: the stated score tolerance, or 1.5 x the reference's own 16-bit score error on that seed where that is larger (tests/test_golden_gpu.py)
-                ds_eff = max(tol[1], 1.5 * own["max_dscore"]) if (path in more and own is not None) else tol[1]
-                c = direct_checks(ref, got, thr, score_eps=ds_eff, iou_min=tol[0])
-                c["stated_tolerance"] = {"min_iou": tol[0], "max_dscore": round(ds_eff, 5)} if tag != "l6" else None
+                tk = spread_tol if kind == "spread" else tol
+                c = direct_checks(ref, got, thr, score_eps=tk[1], iou_min=tk[0])
+                c["stated_tolerance"] = {"min_iou": tk[0], "max_dscore": tk[1]} if tag != "l6" else None
                 c["map_vs_ref_50_95"] = coco_ap(ref, got)
                 g = direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)   # the generous pairing the reference's own 16-bit band was measured with
                 c["distance_from_fp32_reference"] = {"paired": g["paired"], "of": g["ref_dets"], "iou_deficit": round(1.0 - g["min_iou"], 6), "max_dscore": g["max_dscore"]}
@@ -366,7 +367,7 @@ def fp32_mode_throughput(args, dev, images_cpu, steps=12):
     """throughput of the mode that meets the north-star box tolerance (fp32 storage + exact fp32 MFMA arithmetic, csrc/conv_f32.hip) on the benchmark workload itself:
     what the tolerance costs (`only the un-benchmarked fp32 parity mode meets 1 - 1e-3`)"""
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_weights
+    from workloads.synth import synth_weights
 
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     m = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300, **kw)
@@ -465,7 +466,7 @@ def main_fp32(args):
     dev = torch.device("cuda", int(os.environ.get("YOLORT_AMD_BENCH_DEVICE", "0")))
     torch.cuda.set_device(dev)
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
 
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     model = YOLOv5(arch=args.arch, size=(args.size, args.size), score_thresh=args.score_thresh, nms_thresh=0.45, detections_per_img=300, **kw)
@@ -506,7 +507,8 @@ def main_fp32(args):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, host["enqueue"] / args.steps * 1e3, d
 
-    reps = [timed_region() for _ in range(max(1, args.repeats))]
+    reps = [timed_region()]
+    reps += [timed_region() for _ in range(min(400, max(1, args.repeats, int(args.min_seconds / max(reps[0][0], 1e-6)) + 1)) - 1)]
     order = sorted(range(len(reps)), key=lambda i: reps[i][0])
     elapsed, host_enqueue_ms, dets = reps[order[len(order) // 2]]
     rep_ips = [round(args.batch * args.steps / r[0], 1) for r in reps]
@@ -533,13 +535,13 @@ def main_fp32(args):
     out = {
         "metric": ("images/sec at 640x640 (bs=32) yolov5s" if args.config == "c2" else f"images/sec at {args.size}x{args.size} (bs={args.batch}) {args.arch}") + " -- fp32 mode",
         "value": round(ips, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
-        "repeats": {"n": len(reps), "images_per_s": rep_ips, "median": round(ips, 2), "min": min(rep_ips), "max": max(rep_ips),
-                    "spread_pct": round(100.0 * (max(rep_ips) - min(rep_ips)) / max(ips, 1e-9), 2)},
+        "repeats": {"n": len(reps), "images_per_s": rep_ips if len(rep_ips) <= 12 else rep_ips[:4] + ["..."] + rep_ips[-4:], "median": round(ips, 2), "min": min(rep_ips), "max": max(rep_ips),
+                    "spread_pct": round(100.0 * (max(rep_ips) - min(rep_ips)) / max(ips, 1e-9), 2), "timed_seconds_total": round(sum(r[0] for r in reps), 3)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.arch} fp32 mode (fp32 storage, exact fp32 arithmetic on the f32-input MFMA) bs={args.batch}/GPU {args.size}x{args.size} "
                                + ("dynamic-shape letterbox (8 cycled sizes, SURVEY 8d)" if args.shapes == "dynamic" else "fixed-size stream (letterbox kernel: planar fp32 -> NHWC4 canvas)")
                                + " -> backbone+PAN+head -> decode+NMS HIP path", "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
-                   "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "batches_in_flight": depth, "plan_instances": yolo.pipeline_depth,
+                   "weights": f"seeded synthetic (workloads/synth.py, head_gain {args.head_gain})", "batches_in_flight": depth, "plan_instances": yolo.pipeline_depth,
                    "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4), "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                    "conv_tiles": tiles, "plan_activation_bytes": e.plan.bytes_allocated},
         "roofline": {"bound": "mfma", "achieved": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
@@ -591,7 +593,7 @@ def main():
 
     from yolort_amd import dist as ydist
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
@@ -673,11 +675,28 @@ def main():
 
     # the region is run `repeats` times back to back (a 20-step region is 26 ms: one sample says little on a pool whose boxes and clocks wander by +-5 %);
     # value / ms_per_step / host_enqueue are the MEDIAN repeat's, every repeat is in the line
-    reps = [timed_region() for _ in range(max(1, args.repeats))]
+    # The region (EXACTLY --steps steps) is repeated back to back: at least --repeats times and until the regions hold >= --min-seconds of GPU work (a 60-step region of the
+    # headline is 73 ms: five of them say little on a pool whose clocks settle over seconds, and the driver's gpu_busy sampler sees nothing -- VERDICT r4 weak 10).
+    # value / ms_per_step / host_enqueue are the MEDIAN region's; the spread over all regions is in the line.  The number of regions is agreed across ranks.
+    reps = [timed_region()]
+    n_reg = max(1, args.repeats, int(args.min_seconds / max(reps[0][0], 1e-6)) + 1)
+    n_reg = min(n_reg, 400)
+    if world > 1:
+        t_n = torch.tensor([n_reg], device=dev, dtype=torch.int64)
+        dist.all_reduce(t_n, op=dist.ReduceOp.MAX)
+        n_reg = int(t_n.item())
+    reps += [timed_region() for _ in range(n_reg - 1)]
     order = sorted(range(len(reps)), key=lambda i: reps[i][0])
     elapsed, host_enqueue_ms, dets = reps[order[len(order) // 2]]
     rep_ips = [round(world * args.batch * args.steps / r[0], 1) for r in reps]
     region = {k: _elapsed(v) for k, v in yolo.bracket.items()}
+    # the SERIAL regime as a throughput: one batch in flight, every batch collected before the next is submitted (what a latency-bound caller sees)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        collect(model.forward_async(images_gpu))
+    torch.cuda.synchronize()
+    serial_ips = world * args.batch * args.steps / (time.perf_counter() - t0)
     # the same launches with ONE batch in flight (no overlap with other batches' kernels), right after the timed region:
     # per-launch durations as rocprofv3 sees them.  The in-region brackets above include the time a batch's kernels share
     # the GPU with the neighbouring batches' conv / post-process kernels.
@@ -809,16 +828,19 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 4),
-            "repeats": {"n": len(reps), "images_per_s": rep_ips, "median": round(ips, 2), "min": min(rep_ips), "max": max(rep_ips),
+            "repeats": {"n": len(reps), "images_per_s": rep_ips if len(rep_ips) <= 12 else rep_ips[:4] + ["..."] + rep_ips[-4:], "median": round(ips, 2), "min": min(rep_ips), "max": max(rep_ips),
                         "spread_pct": round(100.0 * (max(rep_ips) - min(rep_ips)) / max(ips, 1e-9), 2),
-                        "note": "the timed region (exactly `steps` steps, barrier + synchronize on both sides) run back to back; value / ms_per_step are the median repeat"},
+                        "p10_p90": [sorted(rep_ips)[len(rep_ips) // 10], sorted(rep_ips)[(9 * len(rep_ips)) // 10 - (1 if len(rep_ips) >= 10 else 0)]],
+                        "timed_seconds_total": round(sum(r[0] for r in reps), 3),
+                        "note": "the timed region (exactly `steps` steps, barrier + synchronize on both sides) run back to back until >= --min-seconds of work; value / ms_per_step are the median region"},
+            "serial_images_per_s": round(serial_ips, 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": workload, "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
-                       "weights": f"seeded synthetic (yolort_amd/utils/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
+                       "weights": f"seeded synthetic (workloads/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
                        "gather_second_rounds_rank0": second_rounds[0], "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4), "serving_mode_rank0": serving,
                        "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                        "candidates_per_step_rank0": n_cand, "records_sorted_per_step_rank0": n_cand_sorted, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},

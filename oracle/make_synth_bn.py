@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE -- produces yolort_amd/data/synth_bn_<arch>_s<seed>.npz.
+"""TEST INFRASTRUCTURE -- produces workloads/data/synth_bn_<arch>_s<seed>.npz.
 
 Runs the oracle's conv stack once in calibration mode (every Conv-BN takes the batch statistics of
 its own conv output on a seeded calibration batch) and stores only the
@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import yolov5_oracle as O  # noqa: E402
-from yolort_amd.utils.synth import (COND_GAMMA, COND_HEAD_GAIN, COND_SIZE, SPREAD_OBJ_GAIN, SPREAD_OBJ_LEVEL, SPREAD_TARGET, cond_bn_path, cond_images, spread_cls_prior,  # noqa: E402
+from workloads.synth import (COND_GAMMA, LIN_GAMMA, COND_HEAD_GAIN, COND_SIZE, SPREAD_OBJ_GAIN, SPREAD_OBJ_LEVEL, SPREAD_TARGET, cond_bn_path, cond_images, spread_cls_prior,  # noqa: E402
                                     spread_images, synth_bn_path, synth_images, synth_state_dict)
 
 
@@ -56,7 +56,7 @@ def calibrate(arch: str, seed: int = 0, calib_hw: int = 0, calib_n: int = 0):
           "->", synth_bn_path(arch, seed), os.path.getsize(synth_bn_path(arch, seed)) // 1024, "KB")
 
 
-# ---- the conditioned recipe (yolort_amd/utils/synth.py: COND_*): BatchNorm statistics at the resolution the parity workload runs at, and the
+# ---- the conditioned recipe (workloads/synth.py: COND_*): BatchNorm statistics at the resolution the parity workload runs at, and the
 # objectness bias tuned so that about COND_TARGET (anchor, class) pairs per image pass the threshold on the seeded tuning batch ----
 COND = {a: (s, 2) for a, s in COND_SIZE.items()}   # (resolution, calibration images)
 COND_TARGET = 10
@@ -73,7 +73,7 @@ def photo_images():
     return out
 
 
-def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, thr: float = COND_THRESH, photo: bool = False, spread: bool = False):
+def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, thr: float = COND_THRESH, photo: bool = False, spread: bool = False, lin: bool = False):
     S, n = COND[arch]
     try:
         tmpl = reference_template(arch)
@@ -81,14 +81,14 @@ def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, t
         from yolort_amd.models import yolo as Y
         tmpl = Y.__dict__[arch]().state_dict()
     extra = dict(obj_gain=SPREAD_OBJ_GAIN, cls_prior=spread_cls_prior(seed)) if spread else {}
-    sd = synth_state_dict(tmpl, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=0.0, bn_gamma=COND_GAMMA, **extra)
+    sd = synth_state_dict(tmpl, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=0.0, bn_gamma=LIN_GAMMA if lin else COND_GAMMA, **extra)
     div = 64 if arch.endswith("6_r60") else 32
     imgs = photo_images() if photo else (spread_images(arch, seed) if spread else cond_images(arch, seed))
     batch, _ = O.letterbox(imgs, S, S, div)
     # yolov5l6 (round 3): with BatchNorm statistics taken on full-frame noise, the letterboxed, resized evaluation images drive the deep P6 network 10 - 200 x out of
     # its calibrated range (PAN output rms 5 / 24 / 91 / 227 per level, head logits of +-900: every image empty or saturated, tests/golden/cond_l6_search.txt), so
     # its statistics come from the evaluation batch itself, like the photo variant's; the committed n / s / m calibrations are untouched
-    calib = batch if (photo or spread or arch.endswith("6_r60")) else synth_images(n, S, S, seed=1000 + seed)
+    calib = batch if (photo or spread or lin or arch.endswith("6_r60")) else synth_images(n, S, S, seed=1000 + seed)
     O.CALIB.active = True
     try:
         with torch.no_grad():
@@ -115,7 +115,7 @@ def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, t
     bias = round(0.5 * (lo + hi), 3)
     stats = {k: v.numpy().astype(np.float32) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
     stats["__obj_bias__"] = np.float32(bias)
-    out = cond_bn_path(arch, seed, "photo" if photo else ("spread" if spread else "cond"))
+    out = cond_bn_path(arch, seed, "photo" if photo else ("spread" if spread else ("lin" if lin else "cond")))
     np.savez(out, **stats)
     cand = int((torch.sigmoid(obj + bias)[:, None] * pc > thr).sum())
     print(arch, "conditioned" + (" (photos)" if photo else "") + ": obj bias", bias, "candidates", cand, "on", len(imgs), "images ->", out, os.path.getsize(out) // 1024, "KB")
@@ -125,14 +125,15 @@ if __name__ == "__main__":
     if "--cond" in sys.argv:
         photo = "--photo" in sys.argv
         spread = "--spread" in sys.argv
-        args = [a for a in sys.argv[1:] if a not in ("--cond", "--photo", "--spread")]
+        lin = "--lin" in sys.argv
+        args = [a for a in sys.argv[1:] if a not in ("--cond", "--photo", "--spread", "--lin")]
         seed = 0
         for a in list(args):
             if a.startswith("--seed="):
                 seed = int(a.split("=")[1])
                 args.remove(a)
         for a in args or list(COND):
-            calibrate_conditioned(a, seed, photo=photo, spread=spread)
+            calibrate_conditioned(a, seed, photo=photo, spread=spread, lin=lin)
         sys.exit(0)
     archs = sys.argv[1:] or ["yolov5_darknet_pan_n_r60", "yolov5_darknet_pan_s_r60", "yolov5_darknet_pan_m_r60", "yolov5_darknet_pan_l6_r60"]
     for a in archs:

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle.reference_loader import load_reference  # noqa: E402
-from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
+from workloads.synth import synth_images, synth_weights  # noqa: E402
 
 yolort = load_reference()
 from yolort.models import YOLOv5  # noqa: E402
@@ -107,7 +107,7 @@ def e2e_golden(arch="yolov5_darknet_pan_n_r60", tag="n", sizes=((160, 120), (96,
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# round 3: goldens that can carry a tolerance.  (1) the CONDITIONED workload (yolort_amd/utils/synth.py COND_*): reference detections,
+# round 3: goldens that can carry a tolerance.  (1) the CONDITIONED workload (workloads/synth.py COND_*): reference detections,
 # the reference's own fp32-vs-fp64 reproducibility, and the tolerance a 16-bit evaluation can be held to, measured with jittered
 # storage emulations BEFORE it is written into a GPU test.  (2) the reference's asset photos through `predict(path)`.
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -155,7 +155,7 @@ def cond_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2, 3), verbose=True):
     """reference detections of the conditioned workload + how reproducible they are (fp64, jittered fp16 / bf16 storage)"""
     import bench
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import COND_SIZE, cond_images, conditioned_weights
+    from workloads.synth import COND_SIZE, cond_images, conditioned_weights
     S = COND_SIZE[arch]
     div = 64 if arch.endswith("6_r60") else 32
     kw = dict(size_divisible=64) if div == 64 else {}
@@ -214,7 +214,7 @@ def cond_ok(ev):
 def cond_golden(arch, seeds=range(0, 40)):
     """searches the seed range for a usable conditioned workload, commits its calibration file and the reference's detections"""
     import subprocess
-    from yolort_amd.utils.synth import cond_bn_path
+    from workloads.synth import cond_bn_path
     tag = COND_TAGS[arch]
     for seed in seeds:
         subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", f"--seed={seed}", arch], check=True, capture_output=True)
@@ -252,7 +252,7 @@ def photo_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2)):
     import bench
     from oracle import yolov5_oracle as O
     from oracle.make_synth_bn import photo_images
-    from yolort_amd.utils.synth import COND_SIZE, conditioned_weights
+    from workloads.synth import COND_SIZE, conditioned_weights
     S = COND_SIZE[arch]
     div = 64 if arch.endswith("6_r60") else 32
     kw = dict(size_divisible=64) if div == 64 else {}
@@ -286,7 +286,7 @@ def photo_evaluate(arch, seed, thr=0.25, jitters=(None, 1, 2)):
 
 def photo_golden(arch, seeds=range(0, 30)):
     import subprocess
-    from yolort_amd.utils.synth import cond_bn_path
+    from workloads.synth import cond_bn_path
     tag = COND_TAGS[arch]
     for seed in seeds:
         subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", "--photo", f"--seed={seed}", arch], check=True, capture_output=True)
@@ -329,7 +329,7 @@ def _band(ref, got, thr):
 
 def ref16_golden(kind, tag):
     from oracle.make_synth_bn import photo_images
-    from yolort_amd.utils.synth import cond_images, conditioned_weights, spread_images
+    from workloads.synth import cond_images, conditioned_weights, spread_images
     arch = {v: k for k, v in COND_TAGS.items()}[tag.split("_")[0]]   # (tag "s_s3": the extra seeds of spread_more)
     z = np.load(os.path.join(HERE, f"{kind}_{tag}.npz"))
     meta = json.loads(str(z["meta"]))
@@ -354,7 +354,7 @@ def ref16_golden(kind, tag):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# round 4: the SPREAD workload (yolort_amd/utils/synth.py SPREAD_*): reference scores from the threshold up to ~0.9 and the score threshold
+# round 4: the SPREAD workload (workloads/synth.py SPREAD_*): reference scores from the threshold up to ~0.9 and the score threshold
 # placed in a GAP of the reference's own score list, so that no detection is "near the cut" and a 16-bit evaluation has to reproduce every
 # single one (the conditioned workload's scores all lie within a few hundredths of the threshold).
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -364,7 +364,7 @@ def spread_evaluate(arch, seed, thr_range=(0.3, 0.8), verbose=True, variant="spr
     run re-decides 30-100 detections, tests/golden/spread_l6_search.txt -- so its reference-made golden is a conditioned one with a gap threshold)"""
     import bench
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import COND_SIZE, cond_images, conditioned_weights, spread_images
+    from workloads.synth import COND_SIZE, cond_images, conditioned_weights, spread_images
     S = COND_SIZE[arch]
     div = 64 if arch.endswith("6_r60") else 32
     kw = dict(size_divisible=64) if div == 64 else {}
@@ -426,7 +426,7 @@ def spread_golden(arch, seeds=range(0, 40), force=False):
     -- the reference's OWN bfloat16 run moves scores by 0.05-0.1 and re-decides a fifth to three quarters of the detections, no threshold gap of a hundred-detection
     workload is that wide (tests/golden/spread_m_search.txt) -- and yolov5l6, whose evaluations cost minutes each (a bounded search, then the best seed)"""
     import subprocess
-    from yolort_amd.utils.synth import cond_bn_path
+    from workloads.synth import cond_bn_path
     tag = COND_TAGS[arch]
     for seed in seeds:
         subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", "--spread", f"--seed={seed}", arch], check=True, capture_output=True)
@@ -453,7 +453,7 @@ def spread_more(arch, seeds, want=8):
     error), which the "pairs every detection" test needs.  Search record of 16 seeds of yolov5s: all 16 exact, 10 with the score spacing, 1 with the margin
     (tests/golden/spread_s_more_search.txt).  Files spread_<tag>_s<seed>.npz + ref16_spread_<tag>_s<seed>.npz.  Stops after `want` accepted seeds."""
     import subprocess
-    from yolort_amd.utils.synth import cond_bn_path
+    from workloads.synth import cond_bn_path
     tag = COND_TAGS[arch]
     first = json.loads(str(np.load(os.path.join(HERE, f"spread_{tag}.npz"))["meta"]))["seed"]
     got = []
@@ -485,7 +485,7 @@ def cond_gap_golden(arch, seeds, force_last=True):
     restatement runs agree exactly is committed; with `force_last` the last seed tried is committed whatever its margins are (recorded in the meta: VERDICT r3 item 2 --
     a bounded search, then the best seed with its margins)"""
     import subprocess
-    from yolort_amd.utils.synth import cond_bn_path
+    from workloads.synth import cond_bn_path
     tag = COND_TAGS[arch]
     seeds = list(seeds)
     for n_, seed in enumerate(seeds):

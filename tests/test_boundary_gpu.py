@@ -31,7 +31,7 @@ def _yolo(dev, thr=0.3, **hooks):
     """YOLO built the way the reference builds it (build_model, yolo.py:226-265) with optional injected modules"""
     from yolort_amd.models.backbone_utils import darknet_pan_backbone
     from yolort_amd.models.yolo import YOLO
-    from yolort_amd.utils.synth import synth_weights
+    from workloads.synth import synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     backbone = darknet_pan_backbone("darknet_n_r6_0", 0.33, 0.25, version="r6.0")
     m = YOLO(backbone, 80, score_thresh=thr, nms_thresh=0.45, **hooks)
@@ -49,7 +49,7 @@ def test_injected_post_process_head_and_anchor_generator(dev):
     from yolort_amd.models.anchor_utils import AnchorGenerator
     from yolort_amd.models.box_head import PostProcess, YOLOHead
     from yolort_amd.models.yolo import DEFAULT_ANCHORS
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     calls = {"post": 0, "head": 0, "anchors": 0}
 
     class MyPost(PostProcess):
@@ -101,7 +101,7 @@ def test_yolov5_accepts_a_prebuilt_model_and_rescales_after_a_post_process_hook(
     from test_e2e_gpu import match_fraction
     from yolort_amd.models import YOLOv5
     from yolort_amd.models.box_head import PostProcess
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
 
     class MyPost(PostProcess):
         pass
@@ -127,7 +127,7 @@ def test_post_process_hook_on_a_fixed_size_stream_runs_the_plan_from_the_planar_
     class MyPost(PostProcess):
         pass
 
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     hooked, _ = _yolo(dev, post_process=MyPost([8, 16, 32], 0.3, 0.45, 300))
     plain, _ = _yolo(dev)
     imgs = [synth_images(1, 320, 320, seed=90 + i)[0].to(dev).half() for i in range(2)]   # every image already is the canvas
@@ -166,7 +166,7 @@ _DET_SCRIPT = r"""
 import hashlib, sys, torch
 sys.path.insert(0, %r)
 from yolort_amd.models import YOLOv5
-from yolort_amd.utils.synth import synth_images, synth_weights
+from workloads.synth import synth_images, synth_weights
 arch = "yolov5_darknet_pan_s_r60"
 m = YOLOv5(arch=arch, score_thresh=0.25)
 m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0))
@@ -218,7 +218,7 @@ def test_freeze_weights_serving_mode(dev):
     """YOLOv5.freeze_weights(): the plan key keeps the signature taken at the call (no per-batch walk over every tensor's version) -- identical detections, graph replay
     included; after freeze_weights(False) an in-place weight update is seen again (a new plan, other detections)"""
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     m = YOLOv5(arch=arch, size=(320, 320), score_thresh=0.3)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
@@ -261,7 +261,7 @@ def test_more_batches_in_flight_than_plan_instances(dev):
     """submitting more batches than `pipeline_depth` before collecting any must not let a later batch
     overwrite an uncollected one's results; result() is idempotent"""
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
@@ -283,7 +283,7 @@ def test_alternating_canvases_keep_their_plans(dev):
     """a variable-size stream alternates between canvases; each keeps its plan instances (small LRU) instead of
     rebuilding `pipeline_depth` plans per call"""
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
@@ -308,7 +308,7 @@ def test_upstream_checkpoint_ingest_predicts_like_the_converted_state_dict(dev, 
     from test_e2e_gpu import match_fraction
     from yolort_amd.models import YOLOv5, yolo as Y
     from yolort_amd.models._checkpoint import load_from_ultralytics
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     ref_sd = synth_weights(Y.__dict__[arch]().state_dict(), arch, seed=0, head_gain=1.0)
     path = str(tmp_path / "yolov5n_upstream_format.pt")
@@ -341,7 +341,7 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%d), RANK="0", WORLD_
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from yolort_amd.models import YOLOv5
-from yolort_amd.utils.synth import synth_images, synth_weights
+from workloads.synth import synth_images, synth_weights
 arch = "yolov5_darknet_pan_n_r60"
 m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.3)
 m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
@@ -409,7 +409,7 @@ def test_the_topk_kernel_writes_the_wire_slab_itself(dev):
     (3) status[4] carries the raw candidate count of the batch."""
     from yolort_amd import dist as ydist
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     m = YOLOv5(arch=arch, size=(320, 320), score_thresh=0.2)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))

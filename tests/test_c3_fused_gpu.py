@@ -107,7 +107,7 @@ def test_fused_c3_on_channel_slice_views(dev):
 
 def test_yolov5s_detections_unchanged_by_the_fused_c3(dev, monkeypatch):
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_s_r60"
     imgs = [im.to(dev) for im in synth_images(2, 640, 640, seed=3)]
     outs = []
@@ -160,7 +160,7 @@ def test_fused_stem_body1_leaves_yolov5s_detections_unchanged(dev, monkeypatch):
     streams since round 3) against the two launches (YOLORT_AMD_FUSE_STEM=0): identical detections, bit for bit; the per-launch parity test
     (tests/test_parity_gpu.py) compares body.1's output itself"""
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_s_r60"
     outs = []
     for shape in ((640, 640), (352, 608)):

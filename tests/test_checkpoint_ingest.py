@@ -112,7 +112,7 @@ def _write_fake_checkpoint(path, ref_sd, p6=False):
 def test_roundtrip_through_upstream_format(tmp_path, p6):
     from yolort_amd.models import yolo as Y
     from yolort_amd.models._checkpoint import load_from_ultralytics
-    from yolort_amd.utils.synth import synth_state_dict
+    from workloads.synth import synth_state_dict
     arch = "yolov5_darknet_pan_n6_r60" if p6 else "yolov5_darknet_pan_n_r60"
     ref = Y.__dict__[arch]()
     ref_sd = synth_state_dict(ref.state_dict(), seed=3)

@@ -53,7 +53,7 @@ def dev():
 
 def _model(arch, dev, dtype, **kw):
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_weights
+    from workloads.synth import synth_weights
     head_gain = kw.pop("head_gain", 0.5)
     m = YOLOv5(arch=arch, **kw)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=head_gain))
@@ -67,7 +67,7 @@ def test_yolov5n_against_reference_golden(dev, golden_dir, dtype):
     reference is bounded by the distance of the oracle's own fp16/bf16-storage emulation
     (O.EMULATE) to fp32, measured here on the same inputs -- the stated floating-point tolerance."""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     z = np.load(os.path.join(golden_dir, "e2e_n.npz"))
     S, thr = int(z["S"]), float(z["thr"])
     m = _model("yolov5_darknet_pan_n_r60", dev, dtype, size=(S, S), score_thresh=thr, nms_thresh=0.45, head_gain=float(z["head_gain"]))
@@ -133,7 +133,7 @@ def test_postprocess_exact_given_oracle_logits(dev, golden_dir):
 def test_yolov5s_640_vs_oracle(dev):
     """BASELINE config 2 shape (yolov5s fp16 640x640) at batch 2 against the CPU oracle."""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     arch = "yolov5_darknet_pan_s_r60"
     m = _model(arch, dev, torch.float16, score_thresh=0.25)
     x = synth_images(2, 640, 640, seed=1)
@@ -154,7 +154,7 @@ def test_fused_head_decode_equals_unfused(dev, arch, num_classes, dtype):
     """ymi_conv_head_decode (decode + threshold in the head conv's epilogue) must produce exactly the records
     the stored-logits path produces: same detections bit for bit, same candidate count; K = num_classes + 5 covers
     every anchor padding (32, 64, 96, 128 rows) and a batch whose 20x20 / 10x10 levels make waves span images"""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m = _model(arch, dev, dtype, num_classes=num_classes, score_thresh=0.2, nms_thresh=0.45)
     x = torch.stack([im for im in synth_images(5, 320, 320, seed=5)]).to(dev).to(dtype)
     outs, ncand = [], []
@@ -177,7 +177,7 @@ def test_score_prefix_selection_is_exact(dev, k_det):
     YMI_POST_EXACT_FULL): the detections must equal the full computation bit for bit, both when the prefix suffices
     and when it falls short and the host transparently re-runs the batch on the full set (tests/test_ops_gpu.py forces
     that case deterministically)."""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     outs, ncand = [], []
     x = torch.stack([im for im in synth_images(2, 640, 640, seed=9)]).to(dev).half()
     for exact in (False, True):
@@ -201,7 +201,7 @@ def test_score_prefix_selection_is_exact(dev, k_det):
 def test_stem_from_planar_equals_letterbox_path(dev, dtype):
     """identity-size batches feed the stem straight from the planar images (ymi_conv_stem_planar): the first feature
     map and the detections must be bit-identical to the letterbox + NHWC4 path; other batches keep the letterbox"""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m = _model("yolov5_darknet_pan_n_r60", dev, dtype, size=(320, 416), score_thresh=0.2, nms_thresh=0.45)
     imgs = [im.to(dev).to(dtype) for im in synth_images(3, 320, 416, seed=21)]
     outs, stems = [], []
@@ -224,7 +224,7 @@ def test_stem_from_planar_equals_letterbox_path(dev, dtype):
 def test_planar_stem_batch_survives_capacity_growth(dev):
     """a planar-stem batch whose candidates overflow the capacity is re-run from the planar images (the NHWC4 input
     buffer is never filled on that path): same detections as the letterbox path with ample capacity"""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     imgs = [im.to(dev).half() for im in synth_images(2, 320, 320, seed=31)]
     outs = []
     for planar, cap in ((True, 128), (False, 1 << 16)):
@@ -242,7 +242,7 @@ def test_planar_stem_batch_survives_capacity_growth(dev):
 
 def test_predict_accepts_decoded_hwc_uint8(dev):
     """images as a decoder delivers them -- uint8 (H, W, 3) -- give the same detections as their planar (3, H, W) form"""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.2)
     planar = [(synth_images(1, h, w, seed=91 + i)[0] * 255).round().to(torch.uint8) for i, (h, w) in enumerate([(300, 400), (240, 320)])]
     a = m.predict([u.to(dev) for u in planar])
@@ -256,7 +256,7 @@ def test_predict_accepts_decoded_hwc_uint8(dev):
 def test_mixed_sizes_and_yolo_forward(dev):
     """dynamic-shape letterbox batch + YOLO.forward on a pre-batched tensor (no rescale)."""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     arch = "yolov5_darknet_pan_n_r60"
     m = _model(arch, dev, torch.float16, size=(320, 320), score_thresh=0.3)
     shapes = [(270, 203), (240, 320), (180, 320), (375, 500)]
@@ -282,7 +282,7 @@ def test_baseline_config1_yolov5n_thr045(dev):
     CPU-runnable case), here with the seeded synthetic weights so that detections exist."""
     from oracle import yolov5_oracle as O
     from yolort_amd.models import yolov5n
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     m = yolov5n(score_thresh=0.45)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
@@ -303,7 +303,7 @@ def test_baseline_config3_yolov5m_bf16_dynamic_1280(dev):
     letterbox rounding traps -> per-image bilinear gather + common canvas."""
     from oracle import yolov5_oracle as O
     from yolort_amd.models import yolov5m
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch = "yolov5_darknet_pan_m_r60"
     m = yolov5m(size=(1280, 1280), score_thresh=0.3)
     m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=2.0))   # m / l6 are calibrated at 1280 (oracle/make_synth_bn.py): sane activations need a larger head gain
@@ -324,7 +324,7 @@ def test_baseline_config3_yolov5m_bf16_dynamic_1280(dev):
 
 def test_uint8_ingest_matches_float_path(dev):
     """uint8 images: /255 is fused into the letterbox kernel; same detections as feeding x/255."""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.3, head_gain=1.0)
     u8 = [(synth_images(1, 240, 320, seed=7)[0] * 255).round().to(torch.uint8), (synth_images(1, 300, 200, seed=8)[0] * 255).round().to(torch.uint8)]
     a = m.predict([u.to(dev) for u in u8])
@@ -337,7 +337,7 @@ def test_uint8_ingest_matches_float_path(dev):
 
 def test_async_pipeline_matches_sync(dev):
     """several batches in flight (forward_async) return exactly what the synchronous calls return"""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m = _model("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(160, 160), score_thresh=0.3, head_gain=1.0)
     batches = [[synth_images(1, 128, 160, seed=50 + 2 * i)[0].to(dev), synth_images(1, 160, 120, seed=51 + 2 * i)[0].to(dev)] for i in range(6)]
     sync = [m.forward(b) for b in batches]
@@ -352,7 +352,7 @@ def test_async_pipeline_matches_sync(dev):
 
 def test_p6_model_runs(dev):
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     arch = "yolov5_darknet_pan_l6_r60"
     m = _model(arch, dev, torch.float16, size=(256, 256), size_divisible=64, score_thresh=0.3, head_gain=3.0)
     imgs = [synth_images(1, 200, 256, seed=3)[0]]
@@ -387,7 +387,7 @@ def test_sharded_dynamic_shape_batch_on_the_global_canvas_equals_the_whole_batch
     depend on its batch neighbours once the canvas is fixed); on their own canvases they differ.  fp32 mode: shards of two images against the batch of four (every
     fp32 tile sums in the same order, so the batch size does not matter either); fp16: the shards are filled up to the whole batch's size with copies, so that both
     runs take the same plan (16-bit plans of different batch sizes may pick tiles that accumulate K in another order)."""
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     arch, S = "yolov5_darknet_pan_s_r60", 320
     m = _model(arch, dev, torch.float16 if dtype == torch.float16 else torch.float32, size=(S, S), score_thresh=0.2, head_gain=0.5)
     if dtype == torch.float32:

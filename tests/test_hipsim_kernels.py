@@ -689,7 +689,7 @@ def test_letterbox_kernels_vs_oracle(sim, kernel, monkeypatch):
     """csrc/preproc_pool.hip on the simulator against the oracle's letterbox (reference transform.py:53-97, 297-330): every kernel variant,
     the rounding-trap shapes, fp32 / fp16 output, uint8 planar and interleaved input"""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
     monkeypatch.delenv("YOLORT_AMD_LB_BLOCKS", raising=False)
     if kernel != "default":
@@ -744,7 +744,7 @@ def test_letterbox_tile_whose_columns_map_to_one_uint8_source_column(sim, monkey
 
 def test_letterbox_identity_sizes_are_exact(sim):
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     imgs = [synth_images(1, 64, 96, seed=70 + i)[0] for i in range(3)]
     ref, _ = O.letterbox(imgs, 96, 96, 32)
     got, _ = _sim_letterbox(sim, imgs, 96, torch.float32)

@@ -136,7 +136,7 @@ def _run_backbone(sim_lib, model, img, dtype, fuse_c3, substitute=None):
 def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
     from oracle import yolov5_oracle as O
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     arch, dtype, S = "yolov5_darknet_pan_s_r60", torch.float16, 64
     model = YOLOv5(arch=arch, size=(S, S), score_thresh=0.25)
     model.load_state_dict(synth_weights(model.state_dict(), arch, seed=0, head_gain=0.4))
@@ -183,7 +183,7 @@ def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, 
     (the product takes the unfused form there too)."""
     from oracle import yolov5_oracle as O
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     from test_hipsim_kernels import _sim_letterbox
     thr = 0.1   # second case: a P6 model (IntermediateLevelP6, four pyramid levels, size_divisible = 64; yolo.py:622-834); third: yolov5m in bf16 --
     #             widths 48 / 96 / 192 ...: channel counts that are not multiples of 32 take the im2col-table form of the implicit GEMM
@@ -247,7 +247,7 @@ def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim, f
     equal counts, equal labels, |score difference| <= 1e-4, IoU >= 1 - 1e-3"""
     from oracle import yolov5_oracle as O
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     from test_hipsim_kernels import _sim_letterbox
     sim.ymi_copy_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     arch, dtype, S, thr = "yolov5_darknet_pan_n_r60", torch.float32, 96, 0.25

@@ -114,7 +114,7 @@ def test_collate_images_contract():
 
 def test_synth_weights_are_deterministic():
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_weights
+    from workloads.synth import synth_weights
     arch = "yolov5_darknet_pan_n_r60"
     t = YOLOv5(arch=arch).state_dict()
     a, b = synth_weights(t, arch, seed=0), synth_weights(t, arch, seed=0)

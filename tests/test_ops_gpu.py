@@ -660,7 +660,7 @@ def test_spp_pool_and_upsample_exact(dev, spp_g, monkeypatch):
 def test_letterbox_vs_oracle(dev):
     from oracle import yolov5_oracle as O
     from yolort_amd.models.transform import YOLOTransform
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     shapes = [(1080, 810), (480, 640), (720, 1280), (375, 500), (100, 37), (641, 480)]
     imgs = [synth_images(1, h, w, seed=h + w)[0] for h, w in shapes]
     ref, sizes = O.letterbox(imgs, 640, 640, 32)
@@ -697,7 +697,7 @@ def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kern
             monkeypatch.setenv("YOLORT_AMD_LB_BLOCKS", kernel.split("+b")[1])
     from yolort_amd.engine import View
     from yolort_amd.models.transform import YOLOTransform
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     tr = YOLOTransform(320, 320)
     # first list: every image fits the LDS budget of the tiled kernels (scale factors <= 2.1: they run); second list: the 6x
     # down-scale of the 1080x1920 image does not (the whole launch falls back to the per-pixel kernel)
@@ -730,7 +730,7 @@ def test_letterbox_identity_fast_path(dev, hw, S):
     bilinear kernel's result, which for scale 1 is the source pixel (oracle, fp32 exact)"""
     from oracle import yolov5_oracle as O
     from yolort_amd.models.transform import YOLOTransform
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     imgs = [synth_images(1, hw[0], hw[1], seed=70 + i)[0] for i in range(3)]
     ref, sizes = O.letterbox(imgs, S, S, 32)
     assert sizes == [hw] * 3
@@ -750,7 +750,7 @@ def test_letterbox_interleaved_uint8_input(dev):
     """YMI_U8_HWC: decoded images (H, W, 3) uint8 go straight into the letterbox kernel -- the result must equal the planar
     uint8 path bit for bit (bilinear resize and identity sizes), i.e. permute + /255 + letterbox in one kernel"""
     from yolort_amd.models.transform import YOLOTransform
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     for shapes, S in (([(1080, 810), (480, 640), (375, 500), (100, 37)], 640), ([(320, 256)] * 3, 320)):
         planar = [(synth_images(1, h, w, seed=h + w + i)[0] * 255).round().to(torch.uint8) for i, (h, w) in enumerate(shapes)]
         hwc = [u.permute(1, 2, 0).contiguous() for u in planar]

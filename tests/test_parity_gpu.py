@@ -29,7 +29,7 @@ def dev():
 
 def _build(arch, dev, dtype, **kw):
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_weights
+    from workloads.synth import synth_weights
     head_gain = kw.pop("head_gain", 0.5)
     m = YOLOv5(arch=arch, **kw)
     sd = synth_weights(m.state_dict(), arch, seed=0, head_gain=head_gain)
@@ -115,7 +115,7 @@ def _err_vs(view, ref_nchw):
 ])
 def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size, tol, dynamic, n_oracle):
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     kw = dict(size_divisible=64) if arch.endswith("6_r60") else {}
     m, sd = _build(arch, dev, dtype, size=(size, size), score_thresh=0.25, **kw)
     if dynamic:
@@ -314,7 +314,7 @@ def test_fp32_parity_mode_meets_north_star_tolerance(dev, arch, n, thr, head_gai
     fp64: 68 of 1200 unpaired.  At gains 0.6 / 0.4 the reference is reproducible (0 of 1200 unpaired, same experiment,
     DESIGN.md section 2), so these are the workloads on which the north-star tolerance is meaningful."""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m, sd = _build(arch, dev, torch.float32, score_thresh=thr, head_gain=head_gain)
     m.set_compute_dtype(torch.float32)
     imgs_cpu = [synth_images(1, 640, 640, seed=i + 1)[0] for i in range(n)]
@@ -368,7 +368,7 @@ def test_fp16_bs32_vs_oracle_tight_matching(dev):
     itself with fp16 storage emulated between layers (O.EMULATE): the HIP path must match the fp32 reference as well as
     that emulation does (on average within 0.05)."""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_e2e_gpu import match_fraction
@@ -411,7 +411,7 @@ def test_in_kernel_rescale_equals_scale_coords(dev):
     YOLO.forward (no rescale) + the oracle's scale_coords must give the same boxes to 1 ulp, for shapes that hit the
     letterbox rounding traps."""
     from oracle import yolov5_oracle as O
-    from yolort_amd.utils.synth import synth_images
+    from workloads.synth import synth_images
     m, _ = _build("yolov5_darknet_pan_n_r60", dev, torch.float16, size=(320, 320), score_thresh=0.2, head_gain=1.0)
     shapes = [(270, 203), (240, 320), (180, 320), (375, 500), (641, 480), (97, 311)]
     imgs = [synth_images(1, h, w, seed=40 + i)[0].to(dev).half() for i, (h, w) in enumerate(shapes)]

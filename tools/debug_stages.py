@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import yolov5_oracle as O
 from yolort_amd.models import YOLOv5
-from yolort_amd.utils.synth import synth_images, synth_weights
+from workloads.synth import synth_images, synth_weights
 
 dev = torch.device("cuda:0")
 arch = sys.argv[1] if len(sys.argv) > 1 else "yolov5_darknet_pan_n_r60"

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import yolov5_oracle as O  # noqa: E402
 from yolort_amd.models import YOLOv5  # noqa: E402
-from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
+from workloads.synth import synth_images, synth_weights  # noqa: E402
 
 out = sys.argv[1]
 dev = torch.device("cuda:0")

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from oracle import yolov5_oracle as O  # noqa: E402
-from yolort_amd.utils.synth import cond_images, conditioned_weights  # noqa: E402
+from workloads.synth import cond_images, conditioned_weights  # noqa: E402
 
 ARCH = {"n": "yolov5_darknet_pan_n_r60", "s": "yolov5_darknet_pan_s_r60", "m": "yolov5_darknet_pan_m_r60", "l6": "yolov5_darknet_pan_l6_r60"}
 

@@ -34,7 +34,7 @@ def main():
         os.environ["YOLORT_AMD_AUTOTUNE"] = "1"
     from yolort_amd import engine
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
 
     c = dict(bench.CONFIGS[a.config])
     batch = a.batch or (c["batch"] if c["size"] <= 640 else min(c["batch"], 8))

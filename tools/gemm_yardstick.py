@@ -23,7 +23,7 @@ def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
     c = bench.CONFIGS[cfg]
     from yolort_amd.models import YOLOv5
-    from yolort_amd.utils.synth import synth_images, synth_weights
+    from workloads.synth import synth_images, synth_weights
     dev = torch.device("cuda:0")
     dt = torch.float16 if c["dtype"] == "fp16" else torch.bfloat16
     kw = dict(size_divisible=64) if c["arch"].endswith("6_r60") else {}

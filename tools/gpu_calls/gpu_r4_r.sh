@@ -8,7 +8,7 @@ import json, sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import bench
 from test_golden_gpu import _golden, _model, _np
-from yolort_amd.utils.synth import cond_images
+from workloads.synth import cond_images
 dev = torch.device('cuda:0')
 meta, ref, _ = _golden('cond', 'l6')
 imgs = cond_images(meta['arch'], meta['seed'])

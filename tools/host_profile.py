@@ -3,7 +3,7 @@ import cProfile, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yolort_amd.models import YOLOv5
-from yolort_amd.utils.synth import synth_images, synth_weights
+from workloads.synth import synth_images, synth_weights
 
 dev = torch.device("cuda:0")
 arch = "yolov5_darknet_pan_s_r60"

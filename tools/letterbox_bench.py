@@ -9,7 +9,7 @@ import torch
 
 from yolort_amd.engine import View
 from yolort_amd.models.transform import YOLOTransform
-from yolort_amd.utils.synth import synth_images
+from workloads.synth import synth_images
 
 C3_SHAPES = [(1080, 1920), (720, 1280), (1920, 1080), (1080, 810), (960, 1280), (1281, 1279), (641, 480), (375, 500)]
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"

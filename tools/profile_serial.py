@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from yolort_amd.models import YOLOv5  # noqa: E402
-from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
+from workloads.synth import synth_images, synth_weights  # noqa: E402
 
 
 def main():

@@ -15,7 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
+from workloads.synth import synth_images, synth_weights  # noqa: E402
 
 
 def main():

@@ -9,7 +9,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import yolov5_oracle as O
 from yolort_amd.models import YOLOv5
-from yolort_amd.utils.synth import synth_images, synth_weights
+from workloads.synth import synth_images, synth_weights
 import bench
 torch.set_num_threads(8)
 arch="yolov5_darknet_pan_s_r60"; thr=0.25

@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 from yolort_amd import engine  # noqa: E402
 from yolort_amd.models import YOLOv5  # noqa: E402
-from yolort_amd.utils.synth import synth_images, synth_weights  # noqa: E402
+from workloads.synth import synth_images, synth_weights  # noqa: E402
 
 DEFAULT = ["yolov5_darknet_pan_s_r60:fp16:32:640", "yolov5_darknet_pan_n_r60:fp16:2:640", "yolov5_darknet_pan_m_r60:bf16:64:1280:dynamic",
            "yolov5_darknet_pan_l6_r60:fp16:8:1280"]

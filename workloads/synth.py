@@ -6,7 +6,7 @@ vanish, so benchmarks and parity tests use a s
   * conv weights        ~ N(0, 1/fan_in), rounded to fp16-representable values
   * BatchNorm affine    weight = 0.75 + 0.5 U, bias = 0.2 N
   * BatchNorm statistics loaded from a committed calibration file
-    ``yolort_amd/data/synth_bn_<arch>_s<seed>.npz`` (produced once, on CPU, by
+    ``workloads/data/synth_bn_<arch>_s<seed>.npz`` (produced once, on CPU, by
     ``oracle/make_synth_bn.py`` -- batch statistics of a seeded calibration batch)
   * head convs          weight ~ N(0, (g/sqrt(Cin))^2) for the obj/cls outputs and a quarter of that for
                         the 4 box outputs (keeps boxes anchor-sized instead of degenerate),
@@ -23,7 +23,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
 def _fp16_round(a: np.ndarray) -> np.ndarray:
@@ -157,6 +157,14 @@ def spread_images(arch: str, seed: int = 0):
     return [synth_images(1, h, w, seed=9000 + 10 * seed + i)[0] for i, (h, w) in enumerate(shapes)]
 
 
+# ---- the LINEAR-REGIME recipe (round 5): the conditioned network with BatchNorm weights in [0.08, 0.16] ------------------------------------------------
+# chi -> 1 as the pre-activation spread shrinks (silu is locally affine around each channel's BatchNorm bias): with gamma ~ 0.1 a rounding is no longer amplified
+# on its way through the 80 (yolov5m) / 135 (yolov5l6) layers, so what a 16-bit evaluation of the DEEP networks loses is the plain sum of its roundings.  This is the
+# workload on which the 16-bit production path of BASELINE configs[2] / [4] is held to an ABSOLUTE tolerance (tests/test_golden_gpu.py): with the
+# conditioned recipe's gamma in [0.3, 0.6] the reference's OWN .half() run of yolov5l6 pairs 6 of 27 detections with its fp32 run.
+LIN_GAMMA = (0.08, 0.16)
+
+
 def cond_bn_path(arch: str, seed: int, variant: str = "cond") -> str:
     return os.path.join(_DATA, f"synth_bn_{arch}_s{seed}_{variant}.npz")
 
@@ -170,7 +178,7 @@ def conditioned_weights(template: Dict[str, torch.Tensor], arch: str, seed: int 
         raise FileNotFoundError(f"no committed conditioned calibration for arch={arch} seed={seed}: {path} (run oracle/make_synth_bn.py --cond)")
     z = np.load(path)
     extra = dict(obj_gain=SPREAD_OBJ_GAIN, cls_prior=spread_cls_prior(seed)) if variant == "spread" else {}
-    sd = synth_state_dict(template, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=float(z["__obj_bias__"]), bn_gamma=COND_GAMMA, **extra)
+    sd = synth_state_dict(template, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=float(z["__obj_bias__"]), bn_gamma=LIN_GAMMA if variant == "lin" else COND_GAMMA, **extra)
     prefix = "model." if any(k.startswith("model.") for k in sd) else ""
     for k in z.files:
         if k.startswith("__"):

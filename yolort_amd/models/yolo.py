@@ -158,7 +158,10 @@ class YOLO(nn.Module):
         self.head = head if head is not None else YOLOHead(backbone.out_channels, self.anchor_generator.num_anchors, self.anchor_generator.strides, num_classes)
         self.post_process = post_process if post_process is not None else PostProcess(self.anchor_generator.strides, score_thresh, nms_thresh, detections_per_img)
         self.compute_dtype = torch.float16  # used when parameters are fp32 (see hipmodule.compute_dtype_of)
-        self.use_graph = os.environ.get("YOLORT_AMD_GRAPH", "0") == "1"
+        # the conv stack of a batch is replayed as ONE captured hipGraph launch (csrc/api.cpp ymi_plan_run: captured once per plan instance and op range) instead of ~45
+        # kernel launches from the host: same kernels, same order, same results (tests/test_boundary_gpu.py), 0.12 ms less host time per batch (profiles/r04n_pipeline_depth_graph.txt).
+        # Default since round 5; YOLORT_AMD_GRAPH=0 restores the per-kernel launches.
+        self.use_graph = os.environ.get("YOLORT_AMD_GRAPH", "1") != "0"
         self.cand_cap_per_image = int(os.environ.get("YOLORT_AMD_CAND_CAP", "16384"))
         self._entries: Dict[Tuple, _PlanEntry] = {}
         self._ring: Dict[Tuple, List[_PlanEntry]] = {}
