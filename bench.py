@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--per-op", default="", help="write a per-op profile (json) to this path after the timed run")
     ap.add_argument("--repeats", type=int, default=5, help="the timed region of --steps steps is run this many times back to back; value / ms_per_step are the MEDIAN repeat, all repeats are reported")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="keep repeating the timed region until the regions add up to this much wall time (>= --repeats regions)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("YOLORT_AMD_GRAPH", "0")), help="replay the conv stack as a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("YOLORT_AMD_GRAPH", "1")), help="replay the conv stack as a captured hipGraph (the package default since round 5; 0: per-kernel launches)")
     a = ap.parse_args()
     preset = CONFIGS[a.config]
     for k, v in preset.items():
@@ -363,7 +363,7 @@ def conditioned_parity(args, dev, fp32_only=False):
     return out
 
 
-def fp32_mode_throughput(args, dev, images_cpu, steps=12):
+def fp32_mode_throughput(args, dev, images_cpu, steps=30):
     """throughput of the mode that meets the north-star box tolerance (fp32 storage + exact fp32 MFMA arithmetic, csrc/conv_f32.hip) on the benchmark workload itself:
     what the tolerance costs (`only the un-benchmarked fp32 parity mode meets 1 - 1e-3`)"""
     from yolort_amd.models import YOLOv5
@@ -389,7 +389,7 @@ def fp32_mode_throughput(args, dev, images_cpu, steps=12):
         for p in pend:
             p.result()
 
-    run(depth + 1)
+    run(2 * depth + 2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(steps)

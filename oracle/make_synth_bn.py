@@ -96,7 +96,17 @@ def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, t
     finally:
         O.CALIB.active = False
     with torch.no_grad():
-        ho = O.head(O.backbone(batch, sd, "backbone"), sd, "head")
+        feats = O.backbone(batch, sd, "backbone")
+        ho = O.head(feats, sd, "head")
+    head_gain = COND_HEAD_GAIN
+    if lin:   # the linear-regime features are small (BatchNorm weights ~0.1): scale the head so that the objectness logit spreads like the conditioned recipe's (std 1)
+        head_gain = round(float(COND_HEAD_GAIN / torch.cat([h[..., 4].flatten() for h in ho]).std()), 3)
+        head = synth_state_dict(tmpl, seed=seed, head_gain=head_gain, obj_bias=0.0, bn_gamma=LIN_GAMMA)
+        for k in head:
+            if ".head." in k:
+                sd[k] = head[k]
+        with torch.no_grad():
+            ho = O.head(feats, sd, "head")
     obj = torch.cat([h[..., 4].flatten() for h in ho])
     pc = torch.sigmoid(torch.cat([h[..., 5:].flatten(0, -2) for h in ho]))
     lo, hi = -14.0, 6.0
@@ -115,6 +125,8 @@ def calibrate_conditioned(arch: str, seed: int = 0, target: int = COND_TARGET, t
     bias = round(0.5 * (lo + hi), 3)
     stats = {k: v.numpy().astype(np.float32) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
     stats["__obj_bias__"] = np.float32(bias)
+    if lin:
+        stats["__head_gain__"] = np.float32(head_gain)
     out = cond_bn_path(arch, seed, "photo" if photo else ("spread" if spread else ("lin" if lin else "cond")))
     np.savez(out, **stats)
     cand = int((torch.sigmoid(obj + bias)[:, None] * pc > thr).sum())

@@ -337,7 +337,7 @@ def ref16_golden(kind, tag):
     kw = dict(size_divisible=64) if arch.endswith("6_r60") else {}
     variant = meta.get("variant", "photo" if kind == "photo" else "cond")
     sd = conditioned_weights(YOLOv5(arch=arch, size=(S, S), **kw).state_dict(), arch, seed, variant=variant)
-    imgs = photo_images() if kind == "photo" else (cond_images(arch, seed) if variant == "cond" else spread_images(arch, seed))
+    imgs = photo_images() if kind == "photo" else (cond_images(arch, seed) if variant in ("cond", "lin") else spread_images(arch, seed))
     ref = [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(len(meta["dets"]))]
     out = {}
     info = {"arch": arch, "seed": seed, "S": S, "thr": thr, "kind": kind, "what": "detections of the UNMODIFIED reference with .half() / .bfloat16() parameters and inputs (CPU)"}
@@ -480,7 +480,7 @@ def spread_more(arch, seeds, want=8):
     return got
 
 
-def cond_gap_golden(arch, seeds, force_last=True):
+def cond_gap_golden(arch, seeds, force_last=True, variant="cond", min_dets=12):
     """the conditioned golden with its threshold in a gap of the reference's score list (`cond_<tag>.npz`, meta["thr"] instead of 0.25): the first seed whose fp32 / fp64 /
     restatement runs agree exactly is committed; with `force_last` the last seed tried is committed whatever its margins are (recorded in the meta: VERDICT r3 item 2 --
     a bounded search, then the best seed with its margins)"""
@@ -489,8 +489,8 @@ def cond_gap_golden(arch, seeds, force_last=True):
     tag = COND_TAGS[arch]
     seeds = list(seeds)
     for n_, seed in enumerate(seeds):
-        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", f"--seed={seed}", arch], check=True, capture_output=True)
-        ev, ref = spread_evaluate(arch, seed, thr_range=(0.22, 0.5), variant="cond", min_dets=12)
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_synth_bn.py"), "--cond", f"--seed={seed}", arch] + (["--lin"] if variant == "lin" else []), check=True, capture_output=True)
+        ev, ref = spread_evaluate(arch, seed, thr_range=(0.22, 0.5), variant=variant, min_dets=min_dets)
         n = len(ev.get("dets", []))
         exact = "fp64" in ev and all(ev[k]["unexplained"] == 0 and ev[k]["at_cut"] == 0 and ev[k]["images_labels_equal"] == n for k in ("fp64", "oracle"))
         if ref is not None and (exact or (force_last and n_ == len(seeds) - 1)):
@@ -499,17 +499,19 @@ def cond_gap_golden(arch, seeds, force_last=True):
             for i, r in enumerate(ref):
                 for k in ("boxes", "scores", "labels"):
                     out[f"det{i}_{k}"] = r[k]
-            np.savez_compressed(os.path.join(HERE, f"cond_{tag}.npz"), **out)
-            print("conditioned gap golden", tag, "seed", seed, "thr", ev["thr"], "dets", ev["dets"], ev["accepted_by"], flush=True)
-            ref16_golden("cond", tag)
+            np.savez_compressed(os.path.join(HERE, f"{variant}_{tag}.npz"), **out)
+            print(variant, "gap golden", tag, "seed", seed, "thr", ev["thr"], "dets", ev["dets"], ev["accepted_by"], flush=True)
+            ref16_golden(variant, tag)
             return seed
-        os.remove(cond_bn_path(arch, seed))
+        os.remove(cond_bn_path(arch, seed, variant))
     raise RuntimeError(f"no usable seed for {arch} in {seeds}")
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cond-gap":   # usage: cond-gap arch seed [seed ...]
         cond_gap_golden(sys.argv[2], [int(a) for a in sys.argv[3:]])
+    if len(sys.argv) > 1 and sys.argv[1] == "lin-gap":   # usage: lin-gap arch seed [seed ...]   (round 5: the LINEAR-REGIME recipe, workloads/synth.py LIN_GAMMA -> tests/golden/lin_<tag>.npz + ref16_lin_<tag>.npz)
+        cond_gap_golden(sys.argv[2], [int(a) for a in sys.argv[3:]], variant="lin", min_dets=16)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "photo":
         if not os.path.exists(os.path.join(HERE, "bus.png")):

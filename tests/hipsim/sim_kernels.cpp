@@ -62,7 +62,6 @@ extern "C" int sim_conv2d(const ymi_conv_desc* d) {
     if (d->tile == 133) return ymi::conv3x3_rw_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 134) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 1, nullptr);
     if (d->tile == 135) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 2, nullptr);
-    if (d->tile == 136) return ymi::conv3x3_rw2_launch(a, d->dtype, d->out_dtype, 3, nullptr);
     if (d->tile == 137 || d->tile == 138) return ymi::conv3x3_rs_launch(a, d->dtype, d->out_dtype, d->tile - 136, nullptr);
     if (d->tile == 41) return sim_conv2d_stem(a, d);
     if ((d->tile >= 11 && d->tile <= 120) || (d->tile >= 141 && d->tile <= 159)) return sim_conv2d_gemm(a, d);   // sim_kernels_gemm.cpp

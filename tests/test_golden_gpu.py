@@ -175,6 +175,44 @@ def test_conditioned_workload_16bit_path_meets_the_stated_tolerance(dev, tag, dt
     _assert_no_further_than_the_reference_itself(ref, got, meta["thr"], _ref16("cond", tag, dtype), f"cond_{tag}")
 
 
+# ---- the LINEAR-REGIME workload (round 5): the 16-bit production path of the DEEP networks under an ABSOLUTE tolerance ---------------------------------------
+# yolov5m in bf16 (BASELINE configs[2]) and yolov5l6 in fp16 (configs[4]) had no absolute end-to-end assertion at the configured dtype -- on the
+# conditioned / spread recipes the reference's OWN 16-bit run pairs 11 of 28 / 23 of 94 / 6 of 27 of its fp32 detections (a rounding is amplified ~1.05x per layer through
+# 80 / 135 layers).  With BatchNorm weights in [0.08, 0.16] (workloads/synth.py LIN_GAMMA) the activations stay in the locally affine range of SiLU, a rounding is no longer
+# amplified, and the reference's own 16-bit run pairs >= 90 % of its fp32 detections (tests/golden/ref16_lin_*.npz, meta).  Stated tolerances, CONSTANTS:
+LIN_TOL = {("s", torch.float16): (0.98, 1e-2), ("m", torch.bfloat16): (0.90, 4e-2), ("m", torch.float16): (0.98, 1e-2), ("l6", torch.float16): (0.98, 1e-2)}
+LIN_TAGS = sorted(os.path.basename(f)[len("lin_"):-len(".npz")] for f in __import__("glob").glob(os.path.join(GOLD, "lin_*.npz")))
+
+
+@pytest.mark.parametrize("tag", LIN_TAGS)
+def test_linear_regime_workload_fp32_mode_reproduces_the_reference_exactly(dev, tag):
+    from workloads.synth import cond_images
+    meta, ref, _ = _golden("lin", tag)
+    m = _model(meta, dev, torch.float32, "lin")
+    got = [_np(d) for d in m.predict([im.to(dev) for im in cond_images(meta["arch"], meta["seed"])])]
+    _assert_fp32(ref, got, meta["thr"], f"lin_{tag}")
+
+
+@pytest.mark.parametrize("tag,dtype", [(t, dt) for (t, dt) in LIN_TOL if t in LIN_TAGS])
+def test_linear_regime_workload_16bit_path_meets_an_absolute_tolerance(dev, tag, dtype):
+    """the production 16-bit path of yolov5m (bf16, the C3 plan's kernels on a 1280 dynamic canvas) and yolov5l6 (fp16, the C5 plan's) against detections of the
+    UNMODIFIED reference in fp32: at least 95 % of them paired at the stated IoU and |dscore| (constants, LIN_TOL), nothing unexplained, at most a tenth of all
+    detections within the score tolerance of the threshold -- on a workload where the reference's own run in that type pairs >= 90 % (asserted from the committed record)"""
+    from workloads.synth import cond_images
+    meta, ref, _ = _golden("lin", tag)
+    own = _ref16("lin", tag, dtype)
+    assert own["paired"] >= 0.9 * own["ref_dets"], own                      # the premise: the workload is 16-bit-stable for the reference itself
+    m = _model(meta, dev, dtype, "lin")
+    got = [_np(d) for d in m.predict([im.to(dev).to(dtype) for im in cond_images(meta["arch"], meta["seed"])])]
+    iou_min, ds = LIN_TOL[(tag, dtype)]
+    c = direct_checks(ref, got, meta["thr"], score_eps=ds, iou_min=iou_min)
+    print(f"lin_{tag} {dtype} path, stated tolerance IoU >= {iou_min}, |dscore| <= {ds}:", c, "| the reference's own run in that type:", own)
+    assert c["ref_dets"] >= 16 and c["unexplained"] == 0, c
+    assert c["paired"] >= 0.95 * c["ref_dets"], c
+    assert c["at_cut"] <= 0.1 * (c["ref_dets"] + c["hip_dets"]), c
+    assert c["min_iou"] >= iou_min and c["max_dscore"] <= ds, c
+
+
 # ---- the SPREAD workload (round 4): reference scores from the threshold up to ~0.9, the threshold in a gap of the reference's score list ------------------
 # the stated 16-bit tolerances of the spread workload: CONSTANTS (VERDICT r4 item 2: round 4 widened the score tolerance per seed to 1.5 x the reference's own fp16 error).
 # yolov5s fp16: boxes IoU >= 0.98 like the conditioned workload; scores |dscore| <= 1.5e-2 -- the recipe's objectness gain of 4 multiplies a logit error by four on its way

@@ -419,7 +419,7 @@ def test_register_weights_3x3_stride2_kernel_logic(sim, monkeypatch):
         ref = F.silu(F.conv2d(x, wt, bias, 2, 1))
         ho, wo = ref.shape[-2:]
         outs = []
-        for tile in (134, 111, 112, 136):   # 136: tile 134 with a DMA wave and three patch buffers (5 waves: every wave must meet the same number of barriers)
+        for tile in (134, 111, 112):
             wide = Buf(n, ho, wo, cout + 32, dtype)
             yv = wide.slice_c(16, cout)
             d = _conv_desc(xb, pc, yv, tile, k=3, pad=1, stride=2)
@@ -684,7 +684,7 @@ def _sim_letterbox(sim, imgs, size, out_dtype, c_out=4, div=32):
     return out, sizes
 
 
-@pytest.mark.parametrize("kernel", ["default", "pixel", "tile1", "1", "4", "dma8", "dma4", "dma8+3blocks", "dma4+1block", "d8", "d4"])
+@pytest.mark.parametrize("kernel", ["default", "pixel", "1", "2", "4"])
 def test_letterbox_kernels_vs_oracle(sim, kernel, monkeypatch):
     """csrc/preproc_pool.hip on the simulator against the oracle's letterbox (reference transform.py:53-97, 297-330): every kernel variant,
     the rounding-trap shapes, fp32 / fp16 output, uint8 planar and interleaved input"""
@@ -727,7 +727,7 @@ def test_letterbox_tile_whose_columns_map_to_one_uint8_source_column(sim, monkey
     from yolort_amd._lib import dtype_code
     g = torch.Generator().manual_seed(5)
     outs = {}
-    for knob in ("default", "pixel", "dma8"):
+    for knob in ("default", "pixel", "1"):
         monkeypatch.delenv("YOLORT_AMD_LETTERBOX", raising=False)
         if knob != "default":
             monkeypatch.setenv("YOLORT_AMD_LETTERBOX", knob)
@@ -738,7 +738,7 @@ def test_letterbox_tile_whose_columns_map_to_one_uint8_source_column(sim, monkey
             out = torch.full((1, hb, wb, 4), 7.0, dtype=torch.float32)
             _check(sim, sim.ymi_letterbox(ptrs, geom, 1, dtype_code(torch.uint8), out.data_ptr(), hb, wb, 4, dtype_code(torch.float32), C.c_float(114.0), None))
             outs.setdefault(knob, []).append(out)
-    for a, b, c in zip(outs["default"], outs["pixel"], outs["dma8"]):
+    for a, b, c in zip(outs["default"], outs["pixel"], outs["1"]):
         assert torch.equal(a, b) and torch.equal(c, b)
 
 

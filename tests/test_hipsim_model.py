@@ -116,7 +116,7 @@ def _sim_plan(sim_lib, dtype, fuse_c3, substitute=None, small_tiles=False, f32_v
     p.rw2 = not p.fp32                                    # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2), as in production
     p.rs = False
     p.rw3 = not p.fp32                                    # tile 135 (its K-split form for cin = 128): executed inside the whole-model runs here
-    p.chain128, p.chain_next = 0, False
+    p.chain_next = False
     if p.fp32:   # fp32 mode (engine.Plan.__init__): the pipelined fp32 tiles with the cv1 + cv2 pair and the folded upsample; f32_v1: one register-staged launch per reference conv
         p.use_v1, p.chain_1x1, p.chain_cv3, p.fuse_c3 = f32_v1, False, False, False
     return p

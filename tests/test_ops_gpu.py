@@ -445,7 +445,7 @@ def test_conv3x3_res_kernel(dev, cin, cout, shape):
 def test_conv3x3_rw2_kernel(dev, shape):
     """stride-2 register-weights 3x3 kernel, 64 -> 128 (conv3x3_rw2.hip, tile 134): ragged sizes against the 8 x 8 tiles (odd inputs), more tiles than resident
     blocks (12 x 100 = 1200 tiles on 512 blocks: the persistent loop and its double-buffered parity-split patch), channel-slice views on both sides"""
-    for tile in (134, 136):   # 136: the same tile with a DMA wave and three patch buffers
+    for tile in (134,):
         _run_conv(dev, torch.float16, cin=64, cout=128, k=3, s=2, p=1, tile=tile, x_cs_extra=32, y_cs_extra=64, seed=134, **shape)
         _run_conv(dev, torch.bfloat16, cin=64, cout=128, k=3, s=2, p=1, tile=tile, seed=135, **shape)
 
@@ -500,7 +500,7 @@ def test_conv3x3_rw2_equals_the_implicit_gemm_bit_for_bit(dev):
         wt = torch.randn(128, 64, 3, 3, generator=g) / np.sqrt(64 * 9)
         bias = torch.randn(128, generator=g) * 0.1
         outs = []
-        for tile in (134, 111, 143, 136):
+        for tile in (134, 111, 143):
             plan = engine.Plan(dev, torch.float16)
             xv = plan.alloc(n, h, w, 64)
             xv.as_tensor().copy_(_nhwc(x).to(dev, torch.float16))
@@ -679,7 +679,7 @@ def test_letterbox_vs_oracle(dev):
     assert (nt8.nchw().float().cpu() - ref8).abs().max().item() <= 5e-5
 
 
-@pytest.mark.parametrize("kernel", ["default", "1", "2", "4", "tile1", "2+cg2", "4+cg2", "1+cg2", "dma8", "dma4", "dma8+b7", "dma4+b3", "d8", "d4"])
+@pytest.mark.parametrize("kernel", ["default", "1", "2", "4", "2+cg2", "4+cg2", "1+cg2"])
 @pytest.mark.parametrize("in_dtype,hwc", [(torch.float16, False), (torch.bfloat16, False), (torch.float32, False), (torch.uint8, False), (torch.uint8, True)])
 @pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16])   # (bf16: the tiled kernels round with v_cvt_pk_bf16_f32, the per-pixel kernel in software)
 def test_letterbox_tiled_kernel_equals_per_pixel_kernel(dev, in_dtype, hwc, kernel, out_dtype, monkeypatch):

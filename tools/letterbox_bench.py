@@ -1,6 +1,6 @@
 """Letterbox alone on the GPU (tuning aid): the C3 batch (64 images, the 8 cycled shapes of SURVEY 8d, bf16 -> 1280x1280 canvas)
 or the C2-like dynamic batch, HIP events around `reps` launches with nothing else on the device.
-usage: python tools/letterbox_bench.py [c3|c2dyn] [reps]     (YOLORT_AMD_LETTERBOX selects the kernel: pixel | tile1 | 1 | 2 | 4)"""
+usage: python tools/letterbox_bench.py [c3|c2dyn] [reps]     (YOLORT_AMD_LETTERBOX selects the kernel: pixel | 1 | 2 | 4)"""
 import os
 import sys
 

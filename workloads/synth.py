@@ -178,7 +178,8 @@ def conditioned_weights(template: Dict[str, torch.Tensor], arch: str, seed: int 
         raise FileNotFoundError(f"no committed conditioned calibration for arch={arch} seed={seed}: {path} (run oracle/make_synth_bn.py --cond)")
     z = np.load(path)
     extra = dict(obj_gain=SPREAD_OBJ_GAIN, cls_prior=spread_cls_prior(seed)) if variant == "spread" else {}
-    sd = synth_state_dict(template, seed=seed, head_gain=COND_HEAD_GAIN, obj_bias=float(z["__obj_bias__"]), bn_gamma=LIN_GAMMA if variant == "lin" else COND_GAMMA, **extra)
+    head_gain = float(z["__head_gain__"]) if "__head_gain__" in z.files else COND_HEAD_GAIN   # (linear-regime recipe: the head is scaled so that its logits spread like the conditioned recipe's)
+    sd = synth_state_dict(template, seed=seed, head_gain=head_gain, obj_bias=float(z["__obj_bias__"]), bn_gamma=LIN_GAMMA if variant == "lin" else COND_GAMMA, **extra)
     prefix = "model." if any(k.startswith("model.") for k in sd) else ""
     for k in z.files:
         if k.startswith("__"):

@@ -30,57 +30,19 @@ constexpr int R2_BIAS_BYTES = 512;                         // bias [4 cout group
 
 __device__ __forceinline__ int r2_swz(int pr, int ci) { return (((pr >> 1) & 3) << 1) | ((ci >> 1) & 1); }
 
-// Explicitly scheduled LDS fragment reads (round 4).  Left to the compiler, the unrolled (tap, k16) loop of these kernels came out as
-//   ds_read x2 -> s_waitcnt lgkmcnt(0) -> MFMA x2 -> ds_read x2 -> ...
-// whatever order the source asked for (the machine scheduler sinks the reads behind the MFMAs that free their registers): every unit paid the whole LDS
-// latency, 36 times per tile.  Here the reads are volatile inline assembly (their order is the source's), PF units ahead of their use, and the wait is counted:
-// LDS operations of a wave return in order, so `lgkmcnt(2 (PF - 1))` means "the oldest unit's two fragments have landed".  The scheduling fence after the wait
-// keeps the register-only MFMAs from being hoisted above it (cdna_hip_programming.md, pitfall 18).  The CPU simulator takes the plain C++ form.
-template <class F>
-__device__ __forceinline__ void lds_read16_asm(F& dst, const unsigned char* p, unsigned lds_addr) {
-#ifdef YMI_HIPSIM
-    (void)lds_addr;
-    dst = *reinterpret_cast<const F*>(p);
-#else
-    (void)p;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr));
-#endif
-}
-template <int N>
-__device__ __forceinline__ void lds_wait_counted() {
-#ifndef YMI_HIPSIM
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-__device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) {
-#ifdef YMI_HIPSIM
-    return 0u;
-#else
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
-#endif
-}
-
-// DMAW = false: the kernel described above (tile 134).
-// DMAW = true (tile 136, round 4): ONE 5-wave block per CU, THREE patch buffers, and a dedicated DMA wave.  Tile 134 measures 3.2 TB/s on yolov5s' body.3 where
-// the cin = 32 kernel streams 4.5: each of its blocks has one patch in flight for part of a tile's time, and every wave's loop-top `s_waitcnt vmcnt(0)` also waits
-// for the acknowledgement of the tile's OUTPUT STORES (loads and stores share the counter and may complete out of order with respect to each other, so a counted
-// wait is not safe while both are pending).  Here wave 4 issues every patch piece and nothing else: its counter holds loads only (in order), so it waits with
-// vmcnt(pieces of one patch) -- patch i has landed, patch i+1 may still be in flight -- and after the block barrier sends patch i+2 into the buffer the compute
-// waves have just left.  The four compute waves never wait for memory at all: barrier, 72 MFMAs, SiLU, stores, barrier.  Two patches (78 KiB) per CU are in
-// flight at any time.
-template <int DT, bool DMAW, int PF>
-__global__ __launch_bounds__(DMAW ? 320 : 256, DMAW ? 1 : 2) void conv3x3_rw2_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles) {
+// (Round 4 also built this kernel with a dedicated DMA wave and three patch buffers -- tile 136, compute waves that never wait for memory: 57 us against 50 on
+// yolov5s' body.3, profiles/r04e_tile136_first.txt; removed in round 5.)
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv3x3_rw2_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles) {
     typedef typename Mfma<DT>::frag frag;
     constexpr int CIN = 64, KC = CIN / 16, NU = 9 * KC;    // (tap, k16) units: one weight fragment, two activation fragments, two MFMAs each
-    constexpr int NBUF = DMAW ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char r2_sm[];
     f32x4* bl = reinterpret_cast<f32x4*>(r2_sm);
-    unsigned char* patch0 = r2_sm + R2_BIAS_BYTES;          // NBUF patch buffers
+    unsigned char* patch0 = r2_sm + R2_BIAS_BYTES;          // two patch buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = cout group (wave 4 of the DMAW form: the DMA wave)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = cout group
     const int hi = lane >> 5, frow = lane & 31;
 
     auto tile_origin = [&](int idx, int& img, int& oy0, int& ox0) {
@@ -92,58 +54,6 @@ __global__ __launch_bounds__(DMAW ? 320 : 256, DMAW ? 1 : 2) void conv3x3_rw2_ke
         oy0 = ty * R2_T;
         ox0 = tx * R2_T;
     };
-
-    if constexpr (DMAW) {
-        if (wave == 4) {   // ---- the DMA wave: all R2_PIECES pieces of every patch, geometry rebuilt per piece (it has the time) ----
-            int g_rc[R2_PIECES];     // pr << 16 | column, or -1: nothing to fetch        (the DMA wave has the registers: it holds no weights)
-            int g_off[R2_PIECES];    // source offset relative to the patch origin
-#pragma unroll
-            for (int pi = 0; pi < R2_PIECES; ++pi) {
-                const int e = pi * 64 + lane;
-                const int q = e >> 3;
-                const int qc = q < R2_SLOTS ? q : R2_SLOTS - 1;
-                const int pr = qc / R2_PITCH, sc = qc - pr * R2_PITCH;
-                const int odd = sc >= R2_HO ? 1 : 0;
-                const int ci = odd ? sc - R2_HO : sc;
-                const int col = 2 * ci + odd;
-                const int chunk = (e & 7) ^ r2_swz(pr, ci);
-                g_rc[pi] = (q < R2_SLOTS && col <= 2 * R2_T) ? ((pr << 16) | col) : -1;
-                g_off[pi] = (pr * a.w_in + col) * a.x_cs + chunk * 8;
-            }
-            auto issue_all = [&](int idx, unsigned char* dst) {
-                int img, oy0, ox0;
-                tile_origin(idx, img, oy0, ox0);
-                const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
-                const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + R2_PH <= a.h && ix0 + R2_PH <= a.w_in;   // wave-uniform: the patch lies inside the image
-                const int base = ((img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
-#pragma unroll
-                for (int pi = 0; pi < R2_PIECES; ++pi) {
-                    int off;
-                    if (interior) {
-                        off = g_rc[pi] >= 0 ? base + g_off[pi] : a.x_zero_off;
-                    } else {
-                        const int iy = iy0 + (g_rc[pi] >> 16), ix = ix0 + (g_rc[pi] & 0xff);
-                        const bool ok = g_rc[pi] >= 0 && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w_in);
-                        off = ok ? base + g_off[pi] : a.x_zero_off;
-                    }
-                    glds16(a.x + off, reinterpret_cast<uint16_t*>(dst + pi * 1024));
-                }
-            };
-            const int G = gridDim.x;
-            int idx = blockIdx.x, buf = 0;
-            if (idx < ntiles) issue_all(idx, patch0);
-            if (idx + G < ntiles) issue_all(idx + G, patch0 + R2_PATCH_BYTES);
-            for (; idx < ntiles; idx += G) {
-                if (idx + G < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R2_PIECES) : "memory");   // patch i has landed (loads return in order); patch i+1 may be in flight
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();   // the compute waves see patch i and have left patch i-1's buffer ...
-                const int nb = buf == 0 ? 2 : buf - 1;   // ... (i + 2) % 3 = (i - 1) % 3: refill it
-                if (idx + 2 * G < ntiles) issue_all(idx + 2 * G, patch0 + nb * R2_PATCH_BYTES);
-                buf = buf == 2 ? 0 : buf + 1;
-            }
-            return;
-        }
-    }
 
     // ---- this wave's weights: fragment (tap, kc) = rows wave*32 + frow, k = tap*64 + kc*16 + hi*8 .. +7 ----
     frag wf[NU];
@@ -169,58 +79,49 @@ __global__ __launch_bounds__(DMAW ? 320 : 256, DMAW ? 1 : 2) void conv3x3_rw2_ke
     }
 
     // the patch pieces of this wave (tile 134): entry e = piece*64 + lane -> slot e >> 3 = (pr, sc), position e & 7 holds chunk pos ^ v(pr, ci); fixed per lane
-    constexpr int PPWN = DMAW ? 1 : R2_PPW;
-    int p_rc[PPWN];       // pr << 16 | chunk << 8 | column (relative to the patch origin), or -1: nothing to fetch; the source offset is rebuilt from it per tile
+    int p_rc[R2_PPW];       // pr << 16 | chunk << 8 | column (relative to the patch origin), or -1: nothing to fetch; the source offset is rebuilt from it per tile
                           // (four vector instructions per piece: the explicitly scheduled fragment loop needs the ten registers a second array would take)
-    if constexpr (!DMAW) {
+#pragma unroll
+    for (int j = 0; j < R2_PPW; ++j) {
+        int pi = wave * R2_PPW + j;
+        pi = pi < R2_PIECES ? pi : R2_PIECES - 1;          // surplus slots re-send the last piece (identical bytes)
+        const int e = pi * 64 + lane;
+        const int q = e >> 3;
+        const int qc = q < R2_SLOTS ? q : R2_SLOTS - 1;
+        const int pr = qc / R2_PITCH, sc = qc - pr * R2_PITCH;
+        const int odd = sc >= R2_HO ? 1 : 0;
+        const int ci = odd ? sc - R2_HO : sc;
+        const int col = 2 * ci + odd;                      // 0 .. 16 (slot 9: ci = 9 -> col 18, past the patch)
+        const int chunk = (e & 7) ^ r2_swz(pr, ci);
+        p_rc[j] = (q < R2_SLOTS && col <= 2 * R2_T) ? ((pr << 16) | (chunk << 8) | col) : -1;
+    }
+    auto issue_patch = [&](int idx, unsigned char* dst) {
+        int img, oy0, ox0;
+        tile_origin(idx, img, oy0, ox0);
+        const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+        const int base = ((img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
 #pragma unroll
         for (int j = 0; j < R2_PPW; ++j) {
             int pi = wave * R2_PPW + j;
-            pi = pi < R2_PIECES ? pi : R2_PIECES - 1;          // surplus slots re-send the last piece (identical bytes)
-            const int e = pi * 64 + lane;
-            const int q = e >> 3;
-            const int qc = q < R2_SLOTS ? q : R2_SLOTS - 1;
-            const int pr = qc / R2_PITCH, sc = qc - pr * R2_PITCH;
-            const int odd = sc >= R2_HO ? 1 : 0;
-            const int ci = odd ? sc - R2_HO : sc;
-            const int col = 2 * ci + odd;                      // 0 .. 16 (slot 9: ci = 9 -> col 18, past the patch)
-            const int chunk = (e & 7) ^ r2_swz(pr, ci);
-            p_rc[j] = (q < R2_SLOTS && col <= 2 * R2_T) ? ((pr << 16) | (chunk << 8) | col) : -1;
-        }
-    }
-    auto issue_patch = [&](int idx, unsigned char* dst) {
-        if constexpr (!DMAW) {
-            int img, oy0, ox0;
-            tile_origin(idx, img, oy0, ox0);
-            const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
-            const int base = ((img * a.h + iy0) * a.w_in + ix0) * a.x_cs;
-#pragma unroll
-            for (int j = 0; j < R2_PPW; ++j) {
-                int pi = wave * R2_PPW + j;
-                pi = pi < R2_PIECES ? pi : R2_PIECES - 1;
-                const int pr = p_rc[j] >> 16, col = p_rc[j] & 0xff;
-                const bool ok = p_rc[j] >= 0 && ((unsigned)(iy0 + pr) < (unsigned)a.h) && ((unsigned)(ix0 + col) < (unsigned)a.w_in);
-                const int off = ok ? base + (pr * a.w_in + col) * a.x_cs + ((p_rc[j] >> 8) & 0xff) * 8 : a.x_zero_off;
-                glds16(a.x + off, reinterpret_cast<uint16_t*>(dst + pi * 1024));
-            }
+            pi = pi < R2_PIECES ? pi : R2_PIECES - 1;
+            const int pr = p_rc[j] >> 16, col = p_rc[j] & 0xff;
+            const bool ok = p_rc[j] >= 0 && ((unsigned)(iy0 + pr) < (unsigned)a.h) && ((unsigned)(ix0 + col) < (unsigned)a.w_in);
+            const int off = ok ? base + (pr * a.w_in + col) * a.x_cs + ((p_rc[j] >> 8) & 0xff) * 8 : a.x_zero_off;
+            glds16(a.x + off, reinterpret_cast<uint16_t*>(dst + pi * 1024));
         }
     };
 
     int idx = blockIdx.x;
     int buf = 0;
-    if (!DMAW && idx < ntiles) issue_patch(idx, patch0);
+    if (idx < ntiles) issue_patch(idx, patch0);
     for (; idx < ntiles; idx += gridDim.x) {
         int img, oy0, ox0;
         tile_origin(idx, img, oy0, ox0);
-        if constexpr (!DMAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // patch i has landed; everyone is done reading patch i-1 (first pass: the bias is written)
         const unsigned char* pb = patch0 + buf * R2_PATCH_BYTES;
-        if constexpr (!DMAW) {
-            if (idx + (int)gridDim.x < ntiles && !(a.debug & 2)) issue_patch(idx + gridDim.x, patch0 + (buf ^ 1) * R2_PATCH_BYTES);   // (debug & 2, tile id + 0x200: ablation without the patch loads)
-            buf ^= 1;
-        } else {
-            buf = buf == NBUF - 1 ? 0 : buf + 1;
-        }
+        if (idx + (int)gridDim.x < ntiles && !(a.debug & 2)) issue_patch(idx + gridDim.x, patch0 + (buf ^ 1) * R2_PATCH_BYTES);   // (debug & 2, tile id + 0x200: ablation without the patch loads)
+        buf ^= 1;
 
         if (a.debug & 16) continue;   // ablation (tile id + 0x1000): the patch traffic alone -- no fragment reads, no MFMAs, no stores
         f32x16 acc[1][2];
@@ -232,11 +133,10 @@ __global__ __launch_bounds__(DMAW ? 320 : 256, DMAW ? 1 : 2) void conv3x3_rw2_ke
         }
         // unit = (tap, k16): its two activation fragments are fetched under the previous unit's MFMAs; the tap's base address is laundered inside the loop (left alone,
         // the compiler hoists all 9 * KC addresses out of the tile loop: 36 registers this kernel does not have)
-        // PF units of activation fragments in flight ahead of the MFMAs (round 4, call e: with ONE compute wave per SIMD the loop took 14 k cycles per tile for 2.3 k
-        // cycles of MFMA work -- a unit's two ds_read_b128 were issued one unit = 64 MFMA cycles ahead of their use, against an LDS latency of 128+ cycles)
-        frag fa[PF > 0 ? PF : 2][2];
-        const unsigned pb_lds = lds_addr_of(pb);
-        if constexpr (PF == 0) {   // the loop as the compiler schedules it (the first version of this kernel; A/B)
+        // (Explicitly scheduled fragment reads -- inline-assembly ds_read_b128 two to four units ahead of their MFMAs with counted lgkmcnt -- were measured in round 4:
+        // neither the compute-only time nor the kernel moved, two waves per SIMD already cover each other's LDS round trips; profiles/r04g_*, r04i_*.  Removed in round 5.)
+        frag fa[2][2];
+        {
             auto read_plain = [&](auto ut, auto bt) {
                 constexpr int u = decltype(ut)::value, b = decltype(bt)::value;
                 constexpr int t = u / KC, kc = u % KC;
@@ -253,24 +153,6 @@ __global__ __launch_bounds__(DMAW ? 320 : 256, DMAW ? 1 : 2) void conv3x3_rw2_ke
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[0][j] = Mfma<DT>::run(wf[u], fa[u & 1][j], acc[0][j]);
             });
-        } else {
-        constexpr int PFX = PF > 0 ? PF : 2;
-        auto read_unit = [&](auto ut) {
-            constexpr int u = decltype(ut)::value, b = u % PFX;
-            constexpr int t = u / KC, kc = u % KC;
-            const int eo = ea[t] ^ (kc << 5);
-            lds_read16_asm(fa[b][0], pb + eo, pb_lds + (unsigned)eo);
-            lds_read16_asm(fa[b][1], pb + eo + R2_J1, pb_lds + (unsigned)(eo + R2_J1));
-        };
-        static_for<0, PFX - 1>([&](auto ut) { read_unit(ut); });
-        static_for<0, NU>([&](auto ut) {
-            constexpr int u = decltype(ut)::value;
-            if constexpr (u + PFX - 1 < NU) read_unit(std::integral_constant<int, u + PFX - 1>{});
-            constexpr int younger = (u + PFX - 1 < NU ? PFX - 1 : NU - 1 - u);   // units issued after unit u and not yet awaited
-            lds_wait_counted<2 * younger>();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][j] = Mfma<DT>::run(wf[u], fa[u % PFX][j], acc[0][j]);
-        });
         }
         // the lean epilogue only (the launcher admits nothing else: SiLU, cout = 128, tensors below 2^31 elements)
         auto pix = [&](int j, int64_t& m, bool& ok) {
@@ -286,22 +168,22 @@ __global__ __launch_bounds__(DMAW ? 320 : 256, DMAW ? 1 : 2) void conv3x3_rw2_ke
     }
 }
 
-template <int DT, bool DMAW, int PF>
+template <int DT>
 static int launch_rw2(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     const int tiles_x = cdiv(a.wo, R2_T), tiles_y = cdiv(a.ho, R2_T);
     const int ntiles = a.n * tiles_x * tiles_y;
-    const size_t lds = R2_BIAS_BYTES + (size_t)(DMAW ? 3 : 2) * R2_PATCH_BYTES;
-    auto kfn = conv3x3_rw2_kernel<DT, DMAW, PF>;
+    const size_t lds = R2_BIAS_BYTES + (size_t)2 * R2_PATCH_BYTES;
+    auto kfn = conv3x3_rw2_kernel<DT>;
     if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; }
-    int resident = DMAW ? 256 : 512;   // two 4-wave blocks per CU / one 5-wave block
+    int resident = 512;   // two 4-wave blocks per CU
     if (const char* e = getenv("YOLORT_AMD_RES3X3_BLOCKS")) {   // test aid: few blocks walk many tiles (the persistent loop on small inputs)
         const int v = atoi(e);
         if (v >= 1 && v <= 1024) resident = v;
     }
     a.nblk_m = ntiles;
     a.nblk_n = 1;
-    hipLaunchKernelGGL(kfn, dim3(ntiles < resident ? ntiles : resident), dim3(DMAW ? 320 : 256), lds, s, a, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL(kfn, dim3(ntiles < resident ? ntiles : resident), dim3(256), lds, s, a, tiles_x, tiles_y, ntiles);
     return check_launch("conv3x3_rw2_kernel");
 }
 
@@ -487,9 +369,9 @@ static int launch_rw3(const ConvArgs& a0, hipStream_t s) {
     return check_launch("conv3x3_rw3_kernel");
 }
 
-// variant 1: cin = 64 -> cout = 128 (tile 134); variant 3: the same with a DMA wave and three patch buffers (tile 136); variant 2: cin = 128 -> cout = 128 / 256, K split over two waves (tile 135)
+// variant 1: cin = 64 -> cout = 128 (tile 134); variant 2: cin = 128 -> cout = 128 / 256, K split over two waves (tile 135)
 int conv3x3_rw2_launch(const ConvArgs& a, int dtype, int out_dtype, int variant, hipStream_t s) {
-    YMI_REQUIRE(variant >= 1 && variant <= 3, "ymi_conv2d: unknown stride-2 register-weights 3x3 variant %d", variant);
+    YMI_REQUIRE(variant >= 1 && variant <= 2, "ymi_conv2d: unknown stride-2 register-weights 3x3 variant %d", variant);
     if (variant == 2) {
         YMI_REQUIRE(a.kh == 3 && a.kw == 3 && a.ph == 1 && a.pw == 1 && a.sh == 2 && a.sw == 2 && a.cin == 128 && a.k_pad >= 9 * a.cin && (a.cout == 128 || a.cout == 256) &&
                         a.cout_pad >= a.cout && a.zeros != nullptr && a.up2 == 0 && a.split == 0 && a.chain_w == nullptr && a.res == nullptr && out_dtype == dtype && a.act == YMI_ACT_SILU,
@@ -502,16 +384,7 @@ int conv3x3_rw2_launch(const ConvArgs& a, int dtype, int out_dtype, int variant,
                 "ymi_conv2d: the stride-2 register-weights 3x3 kernel (tile 134) handles cin = 64, cout = 128, stride 2, pad 1, SiLU, 16-bit output, no shortcut / chained conv (and needs desc.zeros)");
     YMI_REQUIRE(((int64_t)a.M + 1) * a.y_cs < ((int64_t)1 << 31), "ymi_conv2d: tile 134: output tensor too large for 32-bit offsets");
     YMI_REQUIRE((int64_t)a.n * a.h * a.w_in * a.x_cs < ((int64_t)1 << 31), "ymi_conv2d: input tensor too large for 32-bit offsets");
-    static const int pf = [] { const char* e = getenv("YOLORT_AMD_RW2_PF"); return e ? atoi(e) : -1; }();   // A/B knob: fragment units in flight, explicitly scheduled (0: the compiler's schedule; -1: the variant's default)
-    if (variant == 3) {   // tile 136: DMA wave, three patch buffers
-        if (pf == 0) return dtype == YMI_F16 ? launch_rw2<YMI_F16, true, 0>(a, s) : launch_rw2<YMI_BF16, true, 0>(a, s);
-        if (pf == 2) return dtype == YMI_F16 ? launch_rw2<YMI_F16, true, 2>(a, s) : launch_rw2<YMI_BF16, true, 2>(a, s);
-        return dtype == YMI_F16 ? launch_rw2<YMI_F16, true, 4>(a, s) : launch_rw2<YMI_BF16, true, 4>(a, s);
-    }
-    if (pf == 2) return dtype == YMI_F16 ? launch_rw2<YMI_F16, false, 2>(a, s) : launch_rw2<YMI_BF16, false, 2>(a, s);
-    if (pf == 3) return dtype == YMI_F16 ? launch_rw2<YMI_F16, false, 3>(a, s) : launch_rw2<YMI_BF16, false, 3>(a, s);
-    if (pf == 4) return dtype == YMI_F16 ? launch_rw2<YMI_F16, false, 4>(a, s) : launch_rw2<YMI_BF16, false, 4>(a, s);
-    return dtype == YMI_F16 ? launch_rw2<YMI_F16, false, 0>(a, s) : launch_rw2<YMI_BF16, false, 0>(a, s);
+    return dtype == YMI_F16 ? launch_rw2<YMI_F16>(a, s) : launch_rw2<YMI_BF16>(a, s);
 }
 
 }  // namespace ymi

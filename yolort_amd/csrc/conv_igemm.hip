@@ -103,7 +103,6 @@ static int launch_dtype(const ConvArgs& a0, bool is1x1, int tile, hipStream_t s)
     if (tile == 133) return conv3x3_rw_launch(a, DT, ODT, 1, s);                               // ... weights in registers (opt-in)
     if (tile == 135) return conv3x3_rw2_launch(a, DT, ODT, 2, s);                              // ... stride 2, cin = 128 -> cout = 128 / 256, K split over two waves (round 4)
     if (tile == 137 || tile == 138) return conv3x3_rs_launch(a, DT, ODT, tile - 136, s);       // row-streaming 3x3, cin = 64: stride 1 -> 64 / stride 2 -> 128 (round 4)
-    if (tile == 136) return conv3x3_rw2_launch(a, DT, ODT, 3, s);                              // ... tile 134 with a DMA wave and three patch buffers, one block per CU (round 4)
     if (tile == 134) return conv3x3_rw2_launch(a, DT, ODT, 1, s);                              // ... stride 2, cin = 64 -> cout = 128, weights in registers (round 4)
     switch (tile_group_of(tile)) {
         case 0: return launch_tile_group<0, DT, ODT>(a, is1x1, tile, s);

@@ -176,125 +176,8 @@ __device__ __forceinline__ float lds_elem(const unsigned char* p) {
     else return (float)(*p) / 255.0f;
 }
 
-template <int IDT, int ODT>
-__global__ __launch_bounds__(256) void letterbox_tile_kernel(const LetterboxTileArgs t) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lb_sm[];
-    const LetterboxArgs& a = t.base;
-    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
-    constexpr bool HWC = IDT == YMI_U8_HWC;
-    constexpr int BPP = HWC ? 3 : ESZ;              // bytes per pixel within one source row of one plane
-    constexpr int PLANES = HWC ? 1 : 3;
-    const int img = blockIdx.y;
-    const int ty = blockIdx.x / t.tiles_x, tx = blockIdx.x - ty * t.tiles_x;
-    const int y0t = ty * LB_TH, x0t = tx * LB_TW;
-    const int hin = a.geom[img][0], win = a.geom[img][1], hr = a.geom[img][2], wr = a.geom[img][3];
-    const int pt = a.geom[img][4], pl = a.geom[img][5];
-    const float sy = (float)hin / (float)hr, sx = (float)win / (float)wr;
-    // source coordinate of an output row / column inside the resized region (exactly the arithmetic of letterbox_kernel)
-    auto src = [](float s, int d, int n_in, int& i0, int& i1, float& l1) {
-        float f = __fsub_rn(__fmul_rn(s, (float)d + 0.5f), 0.5f);
-        f = f < 0.f ? 0.f : f;
-        i0 = (int)f;
-        i0 = i0 > n_in - 1 ? n_in - 1 : i0;
-        i1 = i0 + 1 > n_in - 1 ? n_in - 1 : i0 + 1;
-        l1 = f - (float)i0;
-        l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
-    };
-    // tile ^ resized region
-    const int ya = max(y0t, pt), yb = min(y0t + LB_TH, min(pt + hr, a.hb));       // output rows [ya, yb) resample the image
-    const int xa = max(x0t, pl), xb = min(x0t + LB_TW, min(pl + wr, a.wb));
-    const bool any = ya < yb && xa < xb;
-    int ry0 = 0, ry1 = -1, cx0 = 0, cx1 = -1;
-    if (any) {
-        int i0, i1;
-        float l;
-        src(sy, ya - pt, hin, ry0, i1, l);
-        src(sy, yb - 1 - pt, hin, i0, ry1, l);
-        src(sx, xa - pl, win, cx0, i1, l);
-        src(sx, xb - 1 - pl, win, i0, cx1, l);
-    }
-    const int nrows = ry1 - ry0 + 1;
-    const int span = (cx1 - cx0 + 1) * BPP;                      // bytes of one staged source row
-    const int pitch = ((span + 15 + 15) >> 4) << 4;              // + up to 15 bytes of alignment slack, rounded to 16
-    const unsigned char* base = (const unsigned char*)a.img[img];
-    const int64_t plane_b = (int64_t)hin * win * ESZ;
-    const int64_t row_b = (int64_t)win * BPP;
-    if (any) {
-        const int cpr = pitch >> 4;                              // 16-byte chunks per staged row
-        const int total = PLANES * nrows * cpr;
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const int k = i % cpr;
-            const int rr = (i / cpr) % nrows;
-            const int c = i / (cpr * nrows);
-            const uintptr_t g = (uintptr_t)(base + c * plane_b + (int64_t)(ry0 + rr) * row_b + (int64_t)cx0 * BPP);
-            const uintptr_t g_al = g & ~(uintptr_t)15;
-            // aligned 16-byte requests, only chunks that hold at least one needed byte: a chunk may run < 16 bytes past the
-            // row's last byte, but an aligned 16-byte chunk never crosses a page, so the over-read cannot fault
-            if (g_al + (uintptr_t)k * 16 < g + (uintptr_t)span) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(g_al + (uintptr_t)k * 16);
-                *reinterpret_cast<u32x4*>(lb_sm + ((size_t)(c * nrows + rr) * pitch + k * 16)) = v;
-            }
-        }
-    }
-    __syncthreads();
-    const int y = y0t + (threadIdx.x >> 6);
-    const int x = x0t + (threadIdx.x & 63) * 2;
-    if (y >= a.hb || x >= a.wb) return;
-    float v[2][3];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        v[p][0] = v[p][1] = v[p][2] = a.fill;
-        const int yy = y - pt, xx = x + p - pl;
-        if ((unsigned)yy < (unsigned)hr && (unsigned)xx < (unsigned)wr && x + p < a.wb) {
-            int sy0, sy1, sx0, sx1;
-            float ly1, lx1;
-            src(sy, yy, hin, sy0, sy1, ly1);
-            src(sx, xx, win, sx0, sx1, lx1);
-            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int pc = HWC ? 0 : c;
-                const int sub = HWC ? c : 0;
-                // alignment shift of the staged rows (recomputed, cheaper than a table): (address of row start) & 15
-                const int sh0 = (int)(((uintptr_t)(base + pc * plane_b + (int64_t)sy0 * row_b + (int64_t)cx0 * BPP)) & 15);
-                const int sh1 = (int)(((uintptr_t)(base + pc * plane_b + (int64_t)sy1 * row_b + (int64_t)cx0 * BPP)) & 15);
-                const unsigned char* r0 = lb_sm + (size_t)(pc * nrows + (sy0 - ry0)) * pitch + sh0 + sub;
-                const unsigned char* r1 = lb_sm + (size_t)(pc * nrows + (sy1 - ry0)) * pitch + sh1 + sub;
-                const float p00 = lds_elem<IDT>(r0 + (sx0 - cx0) * BPP), p01 = lds_elem<IDT>(r0 + (sx1 - cx0) * BPP);
-                const float p10 = lds_elem<IDT>(r1 + (sx0 - cx0) * BPP), p11 = lds_elem<IDT>(r1 + (sx1 - cx0) * BPP);
-                const float top = __fadd_rn(__fmul_rn(p00, lx0), __fmul_rn(p01, lx1));
-                const float bot = __fadd_rn(__fmul_rn(p10, lx0), __fmul_rn(p11, lx1));
-                v[p][c] = __fadd_rn(__fmul_rn(top, ly0), __fmul_rn(bot, ly1));
-            }
-        }
-    }
-    const int64_t o = (((int64_t)img * a.hb + y) * a.wb + x) * 4;
-    const bool two = x + 1 < a.wb;
-    if constexpr (ODT == YMI_F32) {
-        float* op = (float*)a.out + o;
-        f32x4 q0 = {v[0][0], v[0][1], v[0][2], 0.f};
-        *reinterpret_cast<f32x4*>(op) = q0;
-        if (two) {
-            f32x4 q1 = {v[1][0], v[1][1], v[1][2], 0.f};
-            *reinterpret_cast<f32x4*>(op + 4) = q1;
-        }
-    } else {
-        uint16_t* op = (uint16_t*)a.out + o;
-        u32x4 q;
-        q[0] = (uint32_t)to16<ODT>(v[0][0]) | ((uint32_t)to16<ODT>(v[0][1]) << 16);
-        q[1] = (uint32_t)to16<ODT>(v[0][2]);
-        q[2] = (uint32_t)to16<ODT>(v[1][0]) | ((uint32_t)to16<ODT>(v[1][1]) << 16);
-        q[3] = (uint32_t)to16<ODT>(v[1][2]);
-        if (two && (a.wb & 1) == 0) *reinterpret_cast<u32x4*>(op) = q;   // even canvas width: pixel pairs are 16-byte aligned
-        else {
-            u32x2 h0 = {q[0], q[1]};
-            *reinterpret_cast<u32x2*>(op) = h0;
-            if (two) { u32x2 h1 = {q[2], q[3]}; *reinterpret_cast<u32x2*>(op + 4) = h1; }
-        }
-    }
-}
 
-// Lean form of the tiled letterbox (round 2, second pass).  letterbox_tile_kernel issues ~560 vector instructions per thread for
+// Tiled letterbox (round 2, second pass).  The first tiled kernel (removed in round 5) issued ~560 vector instructions per thread for
 // 16 output bytes (ISA count: ~100 per staged 16-byte chunk -- three runtime divisions in the chunk -> (plane, row, column)
 // mapping and 64-bit address chains --, ~275 for the two pixels: the row alignment of each of the twelve taps recomputed with
 // 64-bit multiplies).  Same data flow, same arithmetic, bit-identical results (tests/test_ops_gpu.py, every variant):
@@ -473,298 +356,9 @@ __global__ __launch_bounds__(256) void letterbox_tile2_kernel(const LetterboxTil
     }   // column groups
 }
 
-// Persistent, DMA-staged form of the tiled letterbox (round 4).  letterbox_tile2_kernel is load -> barrier -> resample -> store per block, and what it keeps in
-// flight is four 16-byte register loads per thread: ~48 KiB per CU with three resident blocks, i.e. ~3 TB/s at the ~4 us loaded memory latency of this part
-// (Little's law; measured 2.9-3.4 TB/s).  Here
-//   * the staged source rows of a tile travel global -> LDS with `global_load_lds_dwordx4` (no registers, no ds_write): ALL chunks of a tile are in flight at once
-//     (the flat chunk order of tile2 is exactly the lane-linear LDS image a wave-wide DMA writes; a chunk that is not needed reads the image's first 16 bytes into a
-//     slot nobody reads);
-//   * a block is persistent and double-buffered: it walks tiles k, k + gridDim.x, ... and issues the DMA of its NEXT tile before it resamples the current one -- the
-//     load latency of tile k+1 hides under the arithmetic and the stores of tile k inside the block, not only under its neighbours;
-//   * one barrier per tile.  A wave waits for its own pieces of tile k with a COUNTED vmcnt: the only younger vector-memory operations are the stores of tile k-1, at
-//     least one per output row the wave wrote (vector-memory operations of a wave retire in order on gfx9: the count may under-estimate, never over-estimate).
-// Same arithmetic as letterbox_kernel, operation for operation: results are bit-identical (tests/test_ops_gpu.py, tests/test_hipsim_kernels.py).
-struct LbTileGeom {   // one tile of one image; everything wave-uniform
-    int img, y0t, x0t;
-    int hin, win, hr, wr, pt, pl;
-    float sy, sx;
-    bool any;                    // the tile overlaps the resized region
-    int ry0, nrows, cx0, span, pitch;
-    const unsigned char* base;
-    int64_t plane_b, row_b;
-    int al_a, al_p, al_r;        // 16-byte alignment of the first needed byte of (plane c, source row r): (al_a + c * al_p + r * al_r) & 15
-};
-__device__ __forceinline__ void lb_src(float s, int d, int n_in, int& i0, int& i1, float& l1) {   // exactly the arithmetic of letterbox_kernel
-    float f = __fsub_rn(__fmul_rn(s, (float)d + 0.5f), 0.5f);
-    f = f < 0.f ? 0.f : f;
-    i0 = (int)f;
-    i0 = i0 > n_in - 1 ? n_in - 1 : i0;
-    i1 = i0 + 1 > n_in - 1 ? n_in - 1 : i0 + 1;
-    l1 = f - (float)i0;
-    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
-}
-template <int IDT>
-__device__ __forceinline__ LbTileGeom lb_tile_geom(const LetterboxArgs& a, int img, int y0t, int x0t, int th, int tw) {
-    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
-    constexpr int BPP = IDT == YMI_U8_HWC ? 3 : ESZ;
-    LbTileGeom g;
-    g.img = img; g.y0t = y0t; g.x0t = x0t;
-    g.hin = a.geom[img][0]; g.win = a.geom[img][1]; g.hr = a.geom[img][2]; g.wr = a.geom[img][3];
-    g.pt = a.geom[img][4]; g.pl = a.geom[img][5];
-    g.sy = (float)g.hin / (float)g.hr; g.sx = (float)g.win / (float)g.wr;
-    const int ya = max(y0t, g.pt), yb = min(y0t + th, min(g.pt + g.hr, a.hb));
-    const int xa = max(x0t, g.pl), xb = min(x0t + tw, min(g.pl + g.wr, a.wb));
-    g.any = ya < yb && xa < xb;
-    g.ry0 = 0; g.cx0 = 0;
-    int ry1 = -1, cx1 = -1;
-    if (g.any) {
-        int i0, i1;
-        float l;
-        lb_src(g.sy, ya - g.pt, g.hin, g.ry0, i1, l);
-        lb_src(g.sy, yb - 1 - g.pt, g.hin, i0, ry1, l);
-        lb_src(g.sx, xa - g.pl, g.win, g.cx0, i1, l);
-        lb_src(g.sx, xb - 1 - g.pl, g.win, i0, cx1, l);
-    }
-    g.nrows = ry1 - g.ry0 + 1;
-    g.span = (cx1 - g.cx0 + 1) * BPP;
-    g.pitch = ((g.span + 15 + 15) >> 4) << 4;
-    g.base = (const unsigned char*)a.img[img];
-    g.plane_b = (int64_t)g.hin * g.win * ESZ;
-    g.row_b = (int64_t)g.win * BPP;
-    g.al_a = (int)(((uintptr_t)g.base + (uintptr_t)((int64_t)g.cx0 * BPP)) & 15);
-    g.al_p = (int)(g.plane_b & 15);
-    g.al_r = (int)(g.row_b & 15);
-    return g;
-}
-// all staged chunks of a tile, global -> LDS by DMA: chunk i (tile2's flat order) lands at buf + 16 * i; whole waves issue (the DMA writes lane l's 16 bytes at the
-// wave-uniform base + 16 * l), so up to 63 slots past the tile's last chunk are written too: every staging buffer carries LB_DMA_SLACK bytes behind it
-constexpr int LB_DMA_SLACK = 1024;
-template <int IDT, int NT>
-__device__ __forceinline__ void lb_stage_dma(const LbTileGeom& g, unsigned char* buf) {
-    constexpr bool HWC = IDT == YMI_U8_HWC;
-    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
-    constexpr int BPP = HWC ? 3 : ESZ;
-    constexpr int PLANES = HWC ? 1 : 3;
-    if (!g.any) return;
-    const unsigned cpr = (unsigned)g.pitch >> 4;
-    const unsigned total = (unsigned)(PLANES * g.nrows) * cpr;
-    const unsigned magic = cpr == 1 ? 0u : 0xffffffffu / cpr + 1u;   // i / cpr == mulhi(i, magic) for i < 2^16 (see letterbox_tile2_kernel)
-    const unsigned char* gb = g.base + (int64_t)g.cx0 * BPP;
-    const unsigned char* safe = (const unsigned char*)((uintptr_t)g.base & ~(uintptr_t)15);
-    const unsigned lane = threadIdx.x & 63;
-    for (unsigned w0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u); w0 < total; w0 += NT) {   // wave-uniform: all 64 lanes issue
-        const unsigned i = w0 + lane;
-        const unsigned job = cpr == 1 ? i : __umulhi(i, magic), k = i - job * cpr;
-        const int c = PLANES == 1 ? 0 : ((int)job >= 2 * g.nrows ? 2 : ((int)job >= g.nrows ? 1 : 0));
-        const int r = g.ry0 + (int)job - c * g.nrows;
-        const int sh = (g.al_a + c * g.al_p + r * g.al_r) & 15;
-        const bool need = i < total && (int)(k << 4) < sh + g.span;
-        const unsigned char* gp = gb + c * g.plane_b + (int64_t)r * g.row_b + (int64_t)((int)(k << 4) - sh);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(need ? gp : safe),
-                                         (__attribute__((address_space(3))) void*)(buf + (size_t)w0 * 16), 16, 0, 0);
-    }
-}
-// the output rows of one tile from its staged source rows: wave wv of NW writes rows y0t + wv, y0t + wv + NW, ...; returns the number of rows this wave wrote
-// (>= one vector store instruction each)
-// The twelve taps of a pixel pair (three channels x four corners x two pixels = 24 elements) read by volatile inline assembly, one counted wait behind them.
-// Left to the compiler, every LDS read that follows a `global_load_lds` is preceded by `s_waitcnt vmcnt(0)` (the waitcnt pass cannot tell the staging buffer the DMA
-// of the NEXT tile writes from the one these reads come from): the block would wait for the tile it has just requested.  The reads below are invisible to that
-// pass; the buffer hand-over is ordered by the counted wait + barrier at the top of the tile loop.  The wait carries the 24 registers as read-write operands, so
-// no use of them can be scheduled above it.  (The CPU simulator takes the plain C++ form.)
-// (bfloat16 taps through `ds_read_u16_d16_hi` into registers whose low halves stay zero -- no shift per element -- were tried: the in-out operands cost more register
-// copies than the shifts they save, 247 v_mov against 96 v_lshlrev per tile.)
-template <int IDT>
-__device__ __forceinline__ void lb_read24(const unsigned char* sm, const int (&off)[24], float (&val)[24]) {
-#ifdef YMI_HIPSIM
-#pragma unroll
-    for (int i = 0; i < 24; ++i) val[i] = lds_elem<IDT>(sm + off[i]);
-#else
-    (void)sm;   // (the offsets already carry the buffer's LDS address: lb_lds_base, folded into the scalar row bases by the caller)
-    uint32_t r[24];
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        const unsigned ad = (unsigned)off[i];
-        if constexpr (IDT == YMI_F32) asm volatile("ds_read_b32 %0, %1" : "=v"(r[i]) : "v"(ad));
-        else if constexpr (IDT == YMI_F16 || IDT == YMI_BF16) asm volatile("ds_read_u16 %0, %1" : "=v"(r[i]) : "v"(ad));
-        else asm volatile("ds_read_u8 %0, %1" : "=v"(r[i]) : "v"(ad));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]),
-                   "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]), "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23])
-                 :
-                 : "memory");
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        if constexpr (IDT == YMI_F32) val[i] = __builtin_bit_cast(float, r[i]);
-        else if constexpr (IDT == YMI_F16) val[i] = h2f((uint16_t)r[i]);
-        else if constexpr (IDT == YMI_BF16) val[i] = bf2f((uint16_t)r[i]);
-        else val[i] = (float)r[i] / 255.0f;
-    }
-#endif
-}
-__device__ __forceinline__ int lb_lds_base(const unsigned char* sm) {   // LDS byte address of a staging buffer (the inline-assembly reads take absolute addresses); simulator: 0
-#ifdef YMI_HIPSIM
-    (void)sm;
-    return 0;
-#else
-    return (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sm;
-#endif
-}
-template <int IDT, int ODT, int NW, int RPW>
-__device__ __forceinline__ int lb_tile_rows(const LetterboxArgs& a, const LbTileGeom& g, const unsigned char* sm, int debug) {
-    constexpr bool HWC = IDT == YMI_U8_HWC;
-    constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
-    constexpr int BPP = HWC ? 3 : ESZ;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x = g.x0t + (threadIdx.x & 63) * 2;
-    int rows = 0;
-    if (x >= a.wb) {   // (lane-level; the wave still counts its rows: lane 0 of a tile is always inside the canvas)
-#pragma unroll
-        for (int j = 0; j < RPW; ++j) rows += (g.y0t + NW * j + wv < a.hb) ? 1 : 0;
-        return rows;
-    }
-    bool inx[2];
-    int ox0[2], ox1[2];
-    float lx0[2], lx1[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int xx = x + p - g.pl;
-        inx[p] = (unsigned)xx < (unsigned)g.wr && x + p < a.wb;
-        ox0[p] = ox1[p] = 0;
-        lx0[p] = lx1[p] = 0.f;
-        if (inx[p]) {
-            int sx0, sx1;
-            lb_src(g.sx, xx, g.win, sx0, sx1, lx1[p]);
-            lx0[p] = 1.f - lx1[p];
-            ox0[p] = (sx0 - g.cx0) * BPP;
-            ox1[p] = (sx1 - g.cx0) * BPP;
-        }
-    }
-    const bool two = x + 1 < a.wb;
-    const int sm_lds = lb_lds_base(sm);
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int y = g.y0t + NW * j + wv;
-        if (y >= a.hb) break;   // wave-uniform
-        ++rows;
-        float v[2][3];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) v[p][0] = v[p][1] = v[p][2] = a.fill;
-        const int yy = y - g.pt;
-        if ((unsigned)yy < (unsigned)g.hr && (inx[0] || inx[1]) && !(debug & 2)) {
-            int sy0, sy1;
-            float ly1;
-            lb_src(g.sy, yy, g.hin, sy0, sy1, ly1);
-            const float ly0 = 1.f - ly1;
-            int off[24];
-            float e[24];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int pc = HWC ? 0 : c;
-                const int sub = HWC ? c : 0;
-                const int r0 = sm_lds + (pc * g.nrows + (sy0 - g.ry0)) * g.pitch + ((g.al_a + pc * g.al_p + sy0 * g.al_r) & 15) + sub;   // wave-uniform (scalar) row bases
-                const int r1 = sm_lds + (pc * g.nrows + (sy1 - g.ry0)) * g.pitch + ((g.al_a + pc * g.al_p + sy1 * g.al_r) & 15) + sub;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {   // branch-free: a pixel outside the resized region reads offset 0 of the rows and keeps the fill value
-                    off[c * 8 + p * 4 + 0] = r0 + ox0[p];
-                    off[c * 8 + p * 4 + 1] = r0 + ox1[p];
-                    off[c * 8 + p * 4 + 2] = r1 + ox0[p];
-                    off[c * 8 + p * 4 + 3] = r1 + ox1[p];
-                }
-            }
-            lb_read24<IDT>(sm, off, e);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const float p00 = e[c * 8 + p * 4 + 0], p01 = e[c * 8 + p * 4 + 1], p10 = e[c * 8 + p * 4 + 2], p11 = e[c * 8 + p * 4 + 3];
-                    const float top = __fadd_rn(__fmul_rn(p00, lx0[p]), __fmul_rn(p01, lx1[p]));
-                    const float bot = __fadd_rn(__fmul_rn(p10, lx0[p]), __fmul_rn(p11, lx1[p]));
-                    const float val = __fadd_rn(__fmul_rn(top, ly0), __fmul_rn(bot, ly1));
-                    v[p][c] = inx[p] ? val : a.fill;
-                }
-        }
-        const int64_t o = (((int64_t)g.img * a.hb + y) * a.wb + x) * 4;
-        if constexpr (ODT == YMI_F32) {
-            float* op = (float*)a.out + o;
-            f32x4 q0 = {v[0][0], v[0][1], v[0][2], 0.f};
-            *reinterpret_cast<f32x4*>(op) = q0;
-            if (two) {
-                f32x4 q1 = {v[1][0], v[1][1], v[1][2], 0.f};
-                *reinterpret_cast<f32x4*>(op + 4) = q1;
-            }
-        } else {
-            uint16_t* op = (uint16_t*)a.out + o;
-            u32x4 q;
-            q[0] = cvt_pk16<ODT>(f32x2{v[0][0], v[0][1]});   // hardware pair conversions (round 4; same rounding as to16: bf16 output was ~40 VALU per pixel pair in software)
-            q[1] = cvt_pk16<ODT>(f32x2{v[0][2], 0.f});
-            q[2] = cvt_pk16<ODT>(f32x2{v[1][0], v[1][1]});
-            q[3] = cvt_pk16<ODT>(f32x2{v[1][2], 0.f});
-            if (two && (a.wb & 1) == 0) *reinterpret_cast<u32x4*>(op) = q;
-            else {
-                u32x2 h0 = {q[0], q[1]};
-                *reinterpret_cast<u32x2*>(op) = h0;
-                if (two) { u32x2 h1 = {q[2], q[3]}; *reinterpret_cast<u32x2*>(op + 4) = h1; }
-            }
-        }
-    }
-    return rows;
-}
-__device__ __forceinline__ void lb_wait_younger(int n) {   // wait until at most n (<= 4) of this wave's vector-memory operations are outstanding
-    switch (__builtin_amdgcn_readfirstlane(n)) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    }
-}
-template <int IDT, int ODT, int NW, int RPW>
-__global__ __launch_bounds__(NW * 64) void letterbox_tile3_kernel(const LetterboxTileArgs t, int buf_bytes, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lb_sm[];   // [staging buffer 0 + slack][staging buffer 1 + slack]
-    const LetterboxArgs& a = t.base;
-    constexpr int TH = NW * RPW;
-    const int per_img = t.tiles_x * t.tiles_y;
-    auto geom_of = [&](int k) {
-        const int img = k / per_img, r = k - img * per_img;
-        const int ty = r / t.tiles_x, tx = r - ty * t.tiles_x;
-        return lb_tile_geom<IDT>(a, img, ty * TH, tx * LB_TW, TH, LB_TW);
-    };
-    int k = blockIdx.x, b = 0, younger = 0;
-    LbTileGeom g = geom_of(k);
-    if (!(t.debug & 1)) lb_stage_dma<IDT, NW * 64>(g, lb_sm);
-    for (; k < ntiles; k += gridDim.x) {
-        lb_wait_younger(younger);              // this wave's pieces of tile k landed: only the stores of tile k-1 are younger
-        __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone is done reading the other buffer (tile k-1)
-        const int kn = k + (int)gridDim.x;
-        LbTileGeom gn = g;
-        if (kn < ntiles) {
-            gn = geom_of(kn);
-            if (!(t.debug & 1)) lb_stage_dma<IDT, NW * 64>(gn, lb_sm + (size_t)(b ^ 1) * buf_bytes);
-        }
-        younger = lb_tile_rows<IDT, ODT, NW, RPW>(a, g, lb_sm + (size_t)b * buf_bytes, t.debug);
-        g = gn;
-        b ^= 1;
-    }
-}
+// (Round 4 also built DMA-staged forms of this kernel -- every chunk of a tile in flight at once, and a persistent double-buffered one with counted vmcnt: 355 / 460 us
+// against 360 us on the C3 batch, profiles/r04u_letterbox_variants.txt.  The kernel is instruction-issue-bound, not load-bound; they were removed in round 5.)
 
-// One tile per block (as letterbox_tile2_kernel: the hardware's block scheduler does the overlapping) with the DMA staging and the batched tap reads of the
-// persistent kernel: every chunk of the tile is in flight at once, no staging registers, no ds_write.
-template <int IDT, int ODT, int NW, int RPW>
-__global__ __launch_bounds__(NW * 64) void letterbox_tile2d_kernel(const LetterboxTileArgs t) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lb_sm[];
-    const LetterboxArgs& a = t.base;
-    constexpr int TH = NW * RPW;
-    const int img = blockIdx.y, tile = blockIdx.x;
-    const int ty = tile / t.tiles_x, tx = tile - ty * t.tiles_x;
-    const LbTileGeom g = lb_tile_geom<IDT>(a, img, ty * TH, tx * LB_TW, TH, LB_TW);
-    if (!(t.debug & 1)) lb_stage_dma<IDT, NW * 64>(g, lb_sm);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    (void)lb_tile_rows<IDT, ODT, NW, RPW>(a, g, lb_sm, t.debug);
-}
-
-// LDS bytes a tiled kernel with th-row tiles needs for this launch (max over its images); 0 = some image does not fit (huge down-scale)
 template <int IDT>
 static size_t letterbox_tile_lds(const LetterboxArgs& a, int th = LB_TH, int tw = LB_TW, size_t cap = 64 * 1024) {
     constexpr int ESZ = (IDT == YMI_F32) ? 4 : ((IDT == YMI_F16 || IDT == YMI_BF16) ? 2 : 1);
@@ -801,82 +395,12 @@ static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t
 #undef YMI_LBC
         return check_launch("letterbox_copy_kernel");
     }
-    // tuning aid: YOLORT_AMD_LETTERBOX = "pixel" (per-pixel kernel), "tile1" (first tiled kernel), "1" / "2" / "4" (rows per wave
-    // of the lean tiled kernel; default: the largest of 4, 2, 1 whose staged rows fit the LDS budget)
+    // tuning aid: YOLORT_AMD_LETTERBOX = "pixel" (per-pixel kernel), "1" / "2" / "4" (rows per wave of the tiled kernel; default: the largest
+    // of 4, 2, 1 whose staged rows fit the LDS budget)
     const char* lb_env = getenv("YOLORT_AMD_LETTERBOX");   // read per call (one launch per batch): tests switch kernels in-process
-    const bool lb_pixel = lb_env && !strcmp(lb_env, "pixel"), lb_tile1 = lb_env && !strcmp(lb_env, "tile1");
+    const bool lb_pixel = lb_env && !strcmp(lb_env, "pixel");
     const int rpw_max = (lb_env && (lb_env[0] == '1' || lb_env[0] == '2' || lb_env[0] == '4') && lb_env[1] == 0) ? lb_env[0] - '0' : LB_RPW_DEFAULT;
-    // "dma8" / "dma4": the persistent DMA-staged kernel with 8 waves x 2 rows / 4 waves x 4 rows per 16-row tile
-    const int lb_dma = lb_env && !strcmp(lb_env, "dma8") ? 8 : (lb_env && !strcmp(lb_env, "dma4") ? 4 : 0);
-    if (a.c_out == 4 && lb_dma) {
-        const char* dbg = getenv("YOLORT_AMD_LB_DEBUG");
-        const size_t need = letterbox_tile_lds<IDT>(a, 16, LB_TW, (size_t)78 * 1024);
-        if (need > 0) {
-            const int buf = (int)((need + 15) / 16 * 16) + LB_DMA_SLACK;
-            const size_t lds = (size_t)2 * buf;
-            LetterboxTileArgs t;
-            t.base = a;
-            t.tiles_x = cdiv(a.wb, LB_TW);
-            t.tiles_y = cdiv(a.hb, 16);
-            t.debug = dbg ? atoi(dbg) : 0;
-            const int ntiles = t.tiles_x * t.tiles_y * a.n;
-            int per_cu = (int)((size_t)160 * 1024 / lds);
-            per_cu = per_cu < 1 ? 1 : (per_cu > 32 / lb_dma ? 32 / lb_dma : per_cu);
-            int resident = 256 * per_cu;
-            if (const char* e = getenv("YOLORT_AMD_LB_BLOCKS")) {   // test aid: few blocks walk many tiles (the persistent loop on small inputs)
-                const int v = atoi(e);
-                if (v >= 1 && v <= 8192) resident = v;
-            }
-            const dim3 gt((unsigned)(ntiles < resident ? ntiles : resident));
-#define YMI_LBT3(ODT_)                                                                                                        \
-    {                                                                                                                         \
-        if (lb_dma == 8) {                                                                                                    \
-            auto kfn = letterbox_tile3_kernel<IDT, ODT_, 8, 2>;                                                               \
-            if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; } \
-            hipLaunchKernelGGL(kfn, gt, dim3(512), lds, s, t, buf, ntiles);                                                   \
-        } else {                                                                                                              \
-            auto kfn = letterbox_tile3_kernel<IDT, ODT_, 4, 4>;                                                               \
-            if (lds > 64 * 1024) { const int rc_lds = allow_big_lds((const void*)kfn, (int)lds); if (rc_lds != YMI_OK) return rc_lds; } \
-            hipLaunchKernelGGL(kfn, gt, dim3(256), lds, s, t, buf, ntiles);                                                   \
-        }                                                                                                                     \
-    }
-            switch (out_dtype) {
-                case YMI_F16: YMI_LBT3(YMI_F16) break;
-                case YMI_BF16: YMI_LBT3(YMI_BF16) break;
-                case YMI_F32: YMI_LBT3(YMI_F32) break;
-                default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
-            }
-#undef YMI_LBT3
-            return check_launch("letterbox_tile3_kernel");
-        }
-    }
-    // "d8" / "d4": one tile per block, DMA staging, 8 waves x 2 rows / 4 waves x 4 rows
-    const int lb_d = lb_env && !strcmp(lb_env, "d8") ? 8 : (lb_env && !strcmp(lb_env, "d4") ? 4 : 0);
-    if (a.c_out == 4 && lb_d) {
-        const char* dbg = getenv("YOLORT_AMD_LB_DEBUG");
-        const size_t need = letterbox_tile_lds<IDT>(a, 16, LB_TW);
-        if (need > 0) {
-            const size_t lds = (need + 15) / 16 * 16 + LB_DMA_SLACK;
-            LetterboxTileArgs t;
-            t.base = a;
-            t.tiles_x = cdiv(a.wb, LB_TW);
-            t.tiles_y = cdiv(a.hb, 16);
-            t.debug = dbg ? atoi(dbg) : 0;
-            const dim3 gt((unsigned)(t.tiles_x * t.tiles_y), (unsigned)a.n);
-#define YMI_LBT2D(ODT_)                                                                                                \
-    if (lb_d == 8) hipLaunchKernelGGL((letterbox_tile2d_kernel<IDT, ODT_, 8, 2>), gt, dim3(512), lds, s, t);            \
-    else hipLaunchKernelGGL((letterbox_tile2d_kernel<IDT, ODT_, 4, 4>), gt, dim3(256), lds, s, t);
-            switch (out_dtype) {
-                case YMI_F16: YMI_LBT2D(YMI_F16) break;
-                case YMI_BF16: YMI_LBT2D(YMI_BF16) break;
-                case YMI_F32: YMI_LBT2D(YMI_F32) break;
-                default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
-            }
-#undef YMI_LBT2D
-            return check_launch("letterbox_tile2d_kernel");
-        }
-    }
-    if (a.c_out == 4 && !lb_pixel && !lb_tile1) {
+    if (a.c_out == 4 && !lb_pixel) {
         const char* dbg = getenv("YOLORT_AMD_LB_DEBUG");
         const char* cge = getenv("YOLORT_AMD_LB_CG");
         const int cg_max = cge ? (atoi(cge) >= 2 ? 2 : 1) : LB_CG_DEFAULT;
@@ -907,22 +431,6 @@ static int letterbox_dispatch(const LetterboxArgs& a, int out_dtype, hipStream_t
 #undef YMI_LBT2C
             return check_launch("letterbox_tile2_kernel");
         }
-    }
-    const size_t tile_lds = (a.c_out == 4 && lb_tile1) ? letterbox_tile_lds<IDT>(a) : 0;
-    if (tile_lds > 0) {   // first tiled kernel (kept for A/B)
-        LetterboxTileArgs t;
-        t.base = a;
-        t.tiles_x = cdiv(a.wb, LB_TW);
-        t.tiles_y = cdiv(a.hb, LB_TH);
-        t.debug = 0;
-        dim3 gt((unsigned)(t.tiles_x * t.tiles_y), (unsigned)a.n), bt(256);
-        switch (out_dtype) {
-            case YMI_F16: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_F16>), gt, bt, tile_lds, s, t); break;
-            case YMI_BF16: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_BF16>), gt, bt, tile_lds, s, t); break;
-            case YMI_F32: hipLaunchKernelGGL((letterbox_tile_kernel<IDT, YMI_F32>), gt, bt, tile_lds, s, t); break;
-            default: set_error("ymi_letterbox: bad out_dtype %d", out_dtype); return YMI_EINVAL;
-        }
-        return check_launch("letterbox_tile_kernel");
     }
     const int64_t total = (int64_t)a.n * a.hb * a.wb;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);

@@ -171,9 +171,8 @@ class Plan:
         self.chain_cv3 = os.environ.get("YOLORT_AMD_CHAIN_CV3", "0") == "1"
         # Bottleneck j's 3x3 carries Bottleneck j+1's 1x1 in its epilogue (8-wave halo kernel, 8 x 1 waves: the outputs a wave holds are the 1x1's
         # activation fragments): one launch less per Bottleneck after the first
-        # opt-in: the same chain at hidden width 128 (the 40x40 C3s of yolov5s); value = the tile that carries it: 116 (8 x 1 waves of 32 px x 128 couts), 78 / 79 (4-wave
-        # pixel-major tiles).  Measured equal or slower than the two launches (profiles/r03*, r04t_chain128.txt): the chained epilogue reads the 32 KiB of weights per wave from L2
-        self.chain128 = int(os.environ.get("YOLORT_AMD_CHAIN128", "0"))
+        # (the same chain at hidden width 128 -- the 40 x 40 C3s of yolov5s -- was measured equal or slower than the two launches, profiles/r04t_setprio_chain128.txt: the chained
+        # epilogue reads its 32 KiB of weights per wave from L2 with nothing to overlap; the opt-in was removed in round 5)
         self.chain_next = os.environ.get("YOLORT_AMD_CHAIN_NEXT", "0")   # opt-in: C2 0 ... +2.5 % depending on the box, C5 -0.7 % (profiles/r03u, r03w); "0" off, "1" every hidden width the kernel takes (32 / 64 / 128), "128": only that width
         self.chain_next = False if self.chain_next == "0" else (True if self.chain_next == "1" else int(self.chain_next))
         self.use_v1 = os.environ.get("YOLORT_AMD_CONV_V1", "0") == "1"   # register-staged kernel (debug / A-B)
@@ -195,7 +194,7 @@ class Plan:
         self.fp32 = dtype == torch.float32
         self.fuse_stem = False   # set_fuse_stem()
         self.res3x3 = {"0": 0, "1": 1}.get(os.environ.get("YOLORT_AMD_RES3X3", "2"), 2)   # tile 132 wherever it fits: 109 -> 86 us at 320^2 (bs 8), 878 -> 572 us for yolov5m's 64 -> 48 (profiles/r03z3_res3x3_*.txt)
-        self.rw2 = {"0": 0, "2": 2}.get(os.environ.get("YOLORT_AMD_RW2", "1"), 1)   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2); 2: tile 136
+        self.rw2 = 0 if os.environ.get("YOLORT_AMD_RW2", "1") == "0" else 1   # tile 134 (conv3x3_rw2.hip) for Conv(64, 128, 3, 2)
         self.rw3 = os.environ.get("YOLORT_AMD_RW3", "0") == "1"   # tile 135 (its K-split form, cin = 128): opt-in until measured
         self.rs = os.environ.get("YOLORT_AMD_RS", "0") == "1"     # tiles 137 / 138 (row-streaming 3x3, conv3x3_rs.hip): opt-in until measured
         if self.fp32:
@@ -209,7 +208,6 @@ class Plan:
             self.chain_1x1, self.chain_cv3 = False, False
             self.fuse_c3 = False
             self.chain_next = False
-            self.chain128 = 0
 
     def __del__(self):
         try:
@@ -341,13 +339,11 @@ class Plan:
                 # register-weights variant (conv3x3_rw.hip, bit-identical, 9-10 % faster: profiles/r03z14_rw3x3.txt) where that one fits; YOLORT_AMD_RES3X3=1: tile 132 only
                 d.tile = 133 if (self.res3x3 == 2 and d.cout == 64 and d.act == ACT_SILU and not d.chain_w) else 132
             elif self.rw2 and self._rw2_ok(d):
-                d.tile = 136 if self.rw2 == 2 else 134   # stride-2 register-weights 3x3 (conv3x3_rw2.hip): ahead of the table for Conv(64, 128, 3, 2); YOLORT_AMD_RW2=0 keeps the table's tile, =2: its DMA-wave form (tile 136)
+                d.tile = 134   # stride-2 register-weights 3x3 (conv3x3_rw2.hip): ahead of the table for Conv(64, 128, 3, 2); YOLORT_AMD_RW2=0 keeps the table's tile
             elif self.rw3 and self._rw3_ok(d):
                 d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
                 d.tile = pinned
-        if d.tile == 0 and chain is not None and getattr(self, "chain128", 0) and (split if out2 is not None else pc.cout) == 128 and (len(chain) < 3 or chain[2] is None):
-            d.tile = int(self.chain128)
         esz = 4 if self.fp32 else 2
         if self.fp32 and d.tile == 0 and d.zeros:
             d.tile = int(self.lib.ymi_conv_f32_pick_tile(x.n * ho * wo, pc.cout_pad))   # what the library would choose itself: recorded so that the layer tables name the tile
@@ -376,7 +372,7 @@ class Plan:
             return bool(self.res3x3) and self._res3x3_ok(d)
         if tile == 133:
             return self.res3x3 == 2 and self._res3x3_ok(d) and d.cout == 64 and d.act == ACT_SILU and not d.chain_w
-        if tile in (134, 136):
+        if tile == 134:
             return bool(self.rw2) and self._rw2_ok(d)
         if tile == 135:
             return env("YOLORT_AMD_RW3", "1") != "0" and self._rw3_ok(d)
@@ -467,7 +463,7 @@ class Plan:
                 d.out_dtype == d.dtype and d.y2_mode != 2 and chain is None:
             cands = cands + [131]   # resident-weights persistent 3x3 (conv3x3_c32.hip)
         if self._rw2_ok(d):
-            cands = cands + [134, 136]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip); 136: with a DMA wave
+            cands = cands + [134]   # stride-2 register-weights 3x3 (conv3x3_rw2.hip)
         if self._rw3_ok(d):
             cands = cands + [135]   # ... K split over two waves, cin = 128
         if self._rs_ok(d):

@@ -153,7 +153,7 @@ class C3(HipModule):
             y = plan.alloc(x.n, x.h, x.w, c_)
             b0 = self.m[0]
             # the first Bottleneck's 1x1 (cv1) rides in the same launch: its input is this conv's freshly rounded output
-            chain_ok = (plan.chain_1x1 and (c_ in (32, 64) or (c_ == 128 and getattr(plan, "chain128", 0))) and   # K = 128 works (tiles 78 / 79 / 116) but costs the main conv more than the saved launch: opt-in (YOLORT_AMD_CHAIN128)
+            chain_ok = (plan.chain_1x1 and c_ in (32, 64) and   # (K = 128 works in the kernels but costs the main conv more than the saved launch: measured in round 4, not emitted)
                          isinstance(b0, Bottleneck) and isinstance(b0.cv1.act, nn.SiLU) and b0.cv1.conv.kernel_size == (1, 1)
                         and b0.cv1.conv.out_channels % 32 == 0 and b0.cv1.conv.out_channels <= 128)
             chain = None
