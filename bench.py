@@ -47,7 +47,7 @@ MFMA_PEAK = 2.5e15  # FLOP/s dense fp16/bf16
 MFMA_MEASURED = 1.0e15
 HBM_MEASURED = 5.0e12
 F32_MFMA_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact fp32) -- MI355X_MICROARCH.md "Matrix cores": 64 FLOP/clk/SIMD = 1/16 of the bf16 rate
-F32_DEPTH = int(os.environ.get("YOLORT_AMD_F32_PIPELINE", "3"))   # plan instances (batches in flight) of the fp32 mode at 640 x 640
+F32_DEPTH = int(os.environ.get("YOLORT_AMD_F32_PIPELINE", "4"))   # plan instances of the fp32 mode at 640 x 640 (three batches in flight; 7.8 GB of fp32 activations per instance for yolov5s bs 32)
 
 C3_SHAPES = [(1080, 1920), (720, 1280), (1920, 1080), (1080, 810), (960, 1280), (1281, 1279), (641, 480), (375, 500)]
 CONFIGS = {   # BASELINE.json `configs`

@@ -263,6 +263,43 @@ def test_conv_v1_v2_agree_at_scale(dev, k, s, p, cin, cout, hw):
         _run_conv(dev, torch.float16, n=2, cin=cin, cout=cout, h=hw, w=hw, k=k, s=s, p=p, tile=tile, seed=k + cin)
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_row_streaming_3x3_counted_wait_equals_the_full_drain_over_many_launches(dev, stride, monkeypatch):
+    """conv3x3_rs.hip (tiles 137 / 138, both in the pinned yolov5s plan): the counted `s_waitcnt vmcnt(N)` that keeps D - 1 row groups in flight across the step barrier
+    against YOLORT_AMD_RS_COUNTED=0 (every step drains the counter): 200 back-to-back launches on a batch-32 layer while a second stream saturates the memory system with
+    copies -- every launch bit-identical to the drained form (the round-4 count assumed stores never overtake older loads; the count now relies on load
+    order only)"""
+    from yolort_amd import engine
+    g = torch.Generator().manual_seed(137 + stride)
+    n, cin, h, w = 32, 64, 80 if stride == 1 else 160, 80 if stride == 1 else 160
+    cout = 64 if stride == 1 else 128
+    x = torch.randn(n, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)).half()
+    bias = torch.randn(cout, generator=g) * 0.1
+    plan = engine.Plan(dev, torch.float16)
+    xv = plan.alloc(n, h, w, cin)
+    xv.as_tensor().copy_(_nhwc(x.float()).to(dev, torch.float16))
+    pc = engine.PackedConv(wt.float(), bias, None, torch.float16, dev)
+    y = plan.conv(xv, pc, stride, 1, tile=136 + stride)
+    monkeypatch.setenv("YOLORT_AMD_RS_COUNTED", "0")
+    plan.run()
+    torch.cuda.synchronize()
+    ref = y.as_tensor().clone()
+    assert float(ref.float().abs().max()) > 0
+    monkeypatch.delenv("YOLORT_AMD_RS_COUNTED")
+    noise_a, noise_b = torch.empty(64 << 20, device=dev, dtype=torch.uint8), torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+    side = torch.cuda.Stream(device=dev)
+    bad = 0
+    for it in range(200):
+        with torch.cuda.stream(side):
+            noise_b.copy_(noise_a, non_blocking=True)      # memory traffic from another queue while the kernel's row groups are in flight
+        y.as_tensor().zero_()
+        plan.run()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(y.as_tensor(), ref))
+    assert bad == 0, f"{bad} of 200 launches differ from the fully drained form"
+
+
 @pytest.mark.parametrize("tile", [201, 202, 203, 204, 205, 206, 0, -100])
 @pytest.mark.parametrize("shape", [dict(n=2, cin=64, cout=32, h=160, w=160, k=1, s=1, p=0), dict(n=2, cin=32, cout=32, h=96, w=96, k=3, s=1, p=1), dict(n=2, cin=32, cout=64, h=128, w=128, k=3, s=2, p=1),
                                    dict(n=2, cin=128, cout=128, h=40, w=40, k=3, s=1, p=1), dict(n=2, cin=512, cout=256, h=20, w=20, k=1, s=1, p=0), dict(n=1, cin=48, cout=96, h=33, w=21, k=3, s=2, p=1),
@@ -783,6 +820,27 @@ def test_batched_nms_bit_exact(dev, n, ncls, ties):
     ref = O.batched_nms(torch.from_numpy(boxes), torch.from_numpy(scores), torch.from_numpy(labels), 0.45).numpy()
     got = batched_nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(labels).to(dev), 0.45).cpu().numpy()
     np.testing.assert_array_equal(got, ref)
+
+
+def test_batched_nms_takes_arbitrary_int64_category_ids(dev):
+    """torchvision.ops.batched_nms accepts any int64 ids; the kernel's records hold 12 bits of class.  Ids >= 4096, negative ids and ids 2^40 apart must not alias:
+    they are renumbered densely before the call, and more than 4096 distinct ids are refused"""
+    from oracle import yolov5_oracle as O
+    from yolort_amd._lib import YmiError
+    from yolort_amd.ops import batched_nms
+    rng = np.random.default_rng(7)
+    n = 3000
+    boxes, scores = _rand_boxes(rng, n, span=200), rng.random(n, dtype=np.float32)
+    ids = np.array([-5, 0, 4095, 4096, 8191, 8192, 1 << 40, (1 << 40) + 4096], np.int64)   # 4096 / 8192 / 0 alias under a 12-bit mask, as do the last two
+    labels = ids[rng.integers(0, len(ids), n)]
+    dense = np.searchsorted(np.sort(ids), labels).astype(np.int64)
+    ref = O.batched_nms(torch.from_numpy(boxes), torch.from_numpy(scores), torch.from_numpy(dense), 0.45).numpy()
+    got = batched_nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(labels).to(dev), 0.45).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    masked = O.batched_nms(torch.from_numpy(boxes), torch.from_numpy(scores), torch.from_numpy(labels & 4095), 0.45).numpy()
+    assert len(masked) != len(ref)    # what aliasing would have returned differs on this input: the case is not vacuous
+    with pytest.raises(YmiError):
+        batched_nms(torch.from_numpy(_rand_boxes(rng, 5000)).to(dev), torch.rand(5000, device=dev), torch.arange(5000, device=dev), 0.45)
 
 
 def test_postprocess_vs_oracle(dev):

@@ -10,10 +10,10 @@
 //     the pipeline never drains between images; the one or two output rows per image that straddle the padding are computed and not stored;
 //   * rows arrive in GROUPS of four by LDS-DMA, D groups ahead of the step that needs them, into a ring of R rows; no row is fetched twice vertically, the horizontal halo is
 //     two columns per strip (6 % at stride 2, 12 % at stride 1);
-//   * ONE barrier per step; each wave waits for its own DMA pieces with a COUNTED s_waitcnt -- "at most the pieces of the D - 1 younger groups and the stores issued since
-//     are outstanding" -- so the output stores of the last D steps and the row groups ahead stay in flight across the barrier (vector-memory operations of a wave complete in
-//     issue order on gfx9: the model LLVM's waitcnt insertion uses for targets without a separate store counter);
-//   * fragment reads are inline assembly, PF units ahead of their MFMA, with counted lgkmcnt (see conv3x3_rw2.hip): left to the compiler this loop pays the full LDS latency
+//   * ONE barrier per step; each wave waits for its own DMA pieces with a COUNTED s_waitcnt -- "at most as many operations as the D - 1 younger groups have pieces are
+//     outstanding" -- so the row groups ahead stay in flight across the barrier.  The output stores share the counter; the count does not rely on them (loads complete in
+//     order among loads, stores among stores, nothing is assumed between the two kinds -- see the comment at the wait);
+//   * fragment reads are inline assembly, PF units ahead of their MFMA, with counted lgkmcnt: left to the compiler this loop pays the full LDS latency
 //     before every MFMA.
 // Row slots are 128 bytes per pixel; at stride 2 a row keeps its columns split by parity ([even | odd]); chunk swizzle v = (column index >> 1) & 7 on top of the slot parity:
 // a ds_read_b128 lane group (lanes {0-3, 12-15} of one tile row and {20-27} of the next) touches 16 different 16-byte bank units.
@@ -165,14 +165,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rs_kernel(const ConvArgs a, in
     for (int g = s0; g <= s0 + C::D; ++g) issue_group(g);
 
     for (int s = s0; s < s1; ++s) {
-        // groups <= s + 1 must have landed; younger: the D - 1 groups s + 2 .. s + D and the stores of the last D steps (two per wave and step)
+        // groups <= s + 1 must have landed.  Younger LOADS: the D - 1 groups s + 2 .. s + D.  The wave's output STORES of the last steps sit on the same counter, and
+        // gfx9 orders vector-memory completions only within a kind (loads among loads, stores among stores; LLVM's waitcnt pass treats a counter holding both kinds as
+        // out of order for that reason).  So the count must not ASSUME pending stores: with N = (younger loads) the wait passes only when at most N operations of any
+        // kind are pending, hence at most N loads, hence -- loads retiring in order -- the group-(s + 1) pieces have landed whatever the stores did.  (Round 4 added
+        // 2 D for "the stores of the last D steps": correct only if stores never overtake older loads -- ADVICE r4; the strict count costs nothing measurable.)
         if (COUNTED) {
-            const int since = s - s0;   // steps of this block before this one
-            if (since >= C::D) {
-                if (npw == C::PPW) rs_vm_wait<(C::D - 1) * C::PPW + 2 * C::D>(); else rs_vm_wait<(C::D - 1) * (C::PPW - 1) + 2 * C::D>();
-            } else {   // warm-up: fewer stores have been issued, wait as if there were none (stricter)
-                if (npw == C::PPW) rs_vm_wait<(C::D - 1) * C::PPW>(); else rs_vm_wait<(C::D - 1) * (C::PPW - 1)>();
-            }
+            if (npw == C::PPW) rs_vm_wait<(C::D - 1) * C::PPW>(); else rs_vm_wait<(C::D - 1) * (C::PPW - 1)>();
         } else {
             rs_vm_wait<0>();
         }
@@ -245,7 +244,8 @@ static int launch_rs(const ConvArgs& a0, hipStream_t s) {
     const int chunk_steps = cdiv(steps_total, chunks_per_strip);
     chunks_per_strip = cdiv(steps_total, chunk_steps);                  // no empty chunks
     const size_t lds = RS_BIAS_BYTES + (size_t)C::R * C::ROWB;
-    static const bool counted = getenv("YOLORT_AMD_RS_COUNTED") == nullptr || atoi(getenv("YOLORT_AMD_RS_COUNTED")) != 0;   // A/B knob: 0 = drain everything at every step
+    const char* counted_env = getenv("YOLORT_AMD_RS_COUNTED");                  // A/B and stress-test knob, read per launch: 0 = drain everything at every step
+    const bool counted = counted_env == nullptr || atoi(counted_env) != 0;
     a.nblk_m = strips * chunks_per_strip;
     a.nblk_n = 1;
     if (counted) {

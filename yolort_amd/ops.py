@@ -23,7 +23,15 @@ def batched_nms(boxes: Tensor, scores: Tensor, labels: Tensor, iou_threshold: fl
     dev = boxes.device
     b = boxes.detach().to(torch.float32).contiguous()
     s = scores.detach().to(torch.float32).contiguous()
-    l = labels.detach().to(torch.int32).contiguous()
+    # torchvision accepts arbitrary int64 category ids; the kernel's records carry a 12-bit class field.  Only EQUALITY of ids matters to the suppression, so the ids are
+    # renumbered densely (sorted unique -> 0 .. u-1) first; more than 4096 distinct classes in one call are refused instead of aliased
+    if n > 0:
+        uniq, l = torch.unique(labels.detach().reshape(-1), sorted=True, return_inverse=True)
+        if uniq.numel() > 4096:
+            raise YmiError(f"batched_nms: {uniq.numel()} distinct category ids in one call (the kernel holds 4096)")
+        l = l.to(torch.int32).contiguous()
+    else:
+        l = labels.detach().to(torch.int32).contiguous()
     keep = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
     count = torch.zeros(1, device=dev, dtype=torch.int32)
     ws = torch.empty(lib.ymi_nms_ws_bytes(n), device=dev, dtype=torch.uint8)

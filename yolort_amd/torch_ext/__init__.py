@@ -30,6 +30,8 @@ def build(force: bool = False) -> str:
     inc = [f"-I{p}" for p in ce.include_paths(device_type="cuda")] + [f"-I{os.path.join(os.path.dirname(_PKG), 'include')}", "-I/opt/rocm/include"]
     libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
     cxx = shutil.which("g++") or shutil.which("c++")   # host code only (no kernels here): the system C++ compiler, HIP headers for the stream type
+    if cxx is None:
+        raise RuntimeError("building libyolort_amd_torch.so needs a host C++ compiler (g++ / c++ not found on PATH)")
     cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, src,
            "-o", LIB, f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip", f"-L{os.path.dirname(core)}", "-lyolort_amd",
            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,$ORIGIN"]

@@ -23,7 +23,11 @@ at::Tensor batched_nms(const at::Tensor& boxes, const at::Tensor& scores, const 
     const c10::hip::HIPGuard guard(boxes.device().index());
     const int64_t n = boxes.size(0);
     if (n == 0) return at::empty({0}, boxes.options().dtype(at::kLong));
-    const at::Tensor b = boxes.to(at::kFloat).contiguous(), s = scores.to(at::kFloat).contiguous(), l = idxs.to(at::kInt).contiguous();
+    // torchvision accepts arbitrary int64 category ids; the kernel's records carry a 12-bit class field and only EQUALITY of ids matters: renumber them densely
+    // (sorted unique -> 0 .. u-1) and refuse more than 4096 distinct classes in one call instead of aliasing them
+    const auto uniq = at::_unique(idxs.reshape({-1}), /*sorted=*/true, /*return_inverse=*/true);
+    TORCH_CHECK(std::get<0>(uniq).numel() <= 4096, "yolort_amd::batched_nms: ", std::get<0>(uniq).numel(), " distinct category ids in one call (the kernel holds 4096)");
+    const at::Tensor b = boxes.to(at::kFloat).contiguous(), s = scores.to(at::kFloat).contiguous(), l = std::get<1>(uniq).to(at::kInt).contiguous();
     at::Tensor keep = at::empty({n}, boxes.options().dtype(at::kInt));
     at::Tensor count = at::zeros({1}, boxes.options().dtype(at::kInt));
     at::Tensor ws = at::empty({ymi_nms_ws_bytes((int)n)}, boxes.options().dtype(at::kByte));
