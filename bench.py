@@ -532,6 +532,16 @@ def main_fp32(args):
     tiles = {}
     for m in conv_meta:
         tiles[str(m.get("tile"))] = tiles.get(str(m.get("tile")), 0) + 1
+    # HBM traffic of the fp32 conv launches from the committed PMC passes (rocprofv3 cannot run inside this process): per launch like `achieved`; only for the workload it was measured on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "conv_traffic_fp32.json")
+    if os.path.exists(tpath) and args.config == "c2" and args.arch == CONFIGS["c2"]["arch"] and args.batch == 32 and args.size == 640:
+        with open(tpath) as f:
+            tj = json.load(f)
+        if "fetch_mb_per_step_corrected" in tj:
+            tb = (tj["fetch_mb_per_step_corrected"] + tj["write_mb_per_step"]) * 1e6
+            traffic = {"bytes_per_launch": round(tb / max(n_conv, 1)), "bytes_per_step": round(tb), "vs_algorithmic": round(tb / max(bytes_step, 1), 3),
+                       "source": "profiles/conv_traffic_fp32.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_serial.py --config c2 --fp32)", "correction": tj.get("correction")}
     out = {
         "metric": ("images/sec at 640x640 (bs=32) yolov5s" if args.config == "c2" else f"images/sec at {args.size}x{args.size} (bs={args.batch}) {args.arch}") + " -- fp32 mode",
         "value": round(ips, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
@@ -547,7 +557,7 @@ def main_fp32(args):
         "roofline": {"bound": "mfma", "achieved": round(flops_step / conv_s / 1e12, 2) if conv_s > 0 else 0.0, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": round(bound_s / conv_s, 4) if conv_s > 0 else 0.0,
                      "frac_definition": f"per-launch bound sum_l max(flops_l / 157.3 TFLOP/s, bytes_l / 8 TB/s) at 4 bytes per element / measured serial conv time; {n_mfma_bound} of {n_conv} launches are MFMA-bound",
-                     "frac_mfma": round(flops_step / conv_s / F32_MFMA_PEAK, 4) if conv_s > 0 else 0.0, "traffic": None,
+                     "frac_mfma": round(flops_step / conv_s / F32_MFMA_PEAK, 4) if conv_s > 0 else 0.0, "traffic": traffic,
                      "kernel": "conv_f32_pipe_kernel (every conv launch of one step; csrc/conv_f32_pipe.hip)", "launches_per_step": n_conv,
                      "algorithmic_flops_per_step": flops_step, "algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_launch": round(flops_step / max(n_conv, 1)),
                      "per_layer_bound_ms": round(bound_s * 1e3, 4),

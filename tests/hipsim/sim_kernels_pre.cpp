@@ -10,6 +10,7 @@ namespace ymi {
 constexpr int SIM_LDS = 160 * 1024;
 alignas(16) unsigned char lb_sm[SIM_LDS];
 alignas(16) u32x4 spp_sm[SIM_LDS / 16];
+alignas(16) unsigned char spp32_sm[SIM_LDS];
 }
 
 #include "../../yolort_amd/csrc/preproc_pool.hip"

@@ -788,6 +788,18 @@ def test_spp_pool_and_upsample_exact(sim, spp_g, monkeypatch):
     assert torch.equal(gb[:, :32], xb.float()), "the input slice is left as it was"
     for i, k in enumerate((5, 9, 13)):
         assert torch.equal(gb[:, 32 * (i + 1): 32 * (i + 2)], F.max_pool2d(xb.float(), k, 1, k // 2)), f"bf16 maxpool{k} not exact"
+    # fp32 mode (round 5: the LDS cascade replaces the direct 169-tap kernel wherever the plane fits): fp32 buffers, same exactness incl. an all-negative plane and a 40 x 40 map
+    from yolort_amd._lib import YMI_F32
+    for (n_, c_, h_, w_) in ((2, 16, 13, 21), (1, 8, 40, 40)):
+        xf = torch.randn(n_, c_, h_, w_, generator=torch.Generator().manual_seed(10 + h_))
+        xf[0, 3] = -xf[0, 3].abs() - 1.0
+        bf = torch.zeros(n_, h_, w_, 4 * c_ + 8)
+        bf[..., :c_] = xf.permute(0, 2, 3, 1)
+        _check(sim, sim.ymi_spp_pool(bf.data_ptr(), n_, h_, w_, c_, 4 * c_ + 8, YMI_F32, None))
+        gf = bf.permute(0, 3, 1, 2)
+        assert torch.equal(gf[:, :c_], xf) and gf[:, 4 * c_:].abs().max().item() == 0
+        for i, k in enumerate((5, 9, 13)):
+            assert torch.equal(gf[:, c_ * (i + 1): c_ * (i + 2)], F.max_pool2d(xf, k, 1, k // 2)), f"fp32 maxpool{k} not exact"
     up = Buf(2, 40, 34, 96, torch.float16)
     _check(sim, sim.ymi_upsample2x(buf.ptr, 256, 2, 20, 17, 64, up.slice_c(32, 64).ptr, 96, YMI_F16, None))
     gu = up.view().float().permute(0, 3, 1, 2)

@@ -692,6 +692,19 @@ def test_spp_pool_and_upsample_exact(dev, spp_g, monkeypatch):
         assert torch.equal(gb[:, :c], xb.float())
         for i, k in enumerate((5, 9, 13)):
             assert torch.equal(gb[:, c * (i + 1): c * (i + 2)], F.max_pool2d(xb.float(), k, 1, k // 2)), f"bf16 maxpool{k} not exact ({h}x{w})"
+    # fp32 mode (round 5: LDS cascade; the 80 x 80 plane does not fit twice in LDS and takes the direct kernel)
+    for (n, c, h, w) in ((2, 64, 20, 20), (1, 96, 40, 40), (1, 8, 80, 80)):
+        xf32 = torch.randn(n, c, h, w, generator=g)
+        xf32[-1, 5] = -xf32[-1, 5].abs() - 1.0
+        pf = engine.Plan(dev, torch.float32)
+        bf = pf.alloc(n, h, w, 4 * c, zero=True)
+        bf.slice_c(0, c).as_tensor().copy_(_nhwc(xf32).to(dev))
+        pf.spp_pool(bf, c)
+        pf.run()
+        gf = bf.as_tensor().cpu().permute(0, 3, 1, 2)
+        assert torch.equal(gf[:, :c], xf32)
+        for i, k in enumerate((5, 9, 13)):
+            assert torch.equal(gf[:, c * (i + 1): c * (i + 2)], F.max_pool2d(xf32, k, 1, k // 2)), f"fp32 maxpool{k} not exact ({h}x{w})"
 
 
 def test_letterbox_vs_oracle(dev):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--ops", default="")
     ap.add_argument("--score-thresh", type=float, default=None, help="override the config's threshold (e.g. 0.999: a head without candidates)")
+    ap.add_argument("--fp32", action="store_true", help="the fp32 mode (fp32 storage, f32-input MFMA: csrc/conv_f32_pipe.hip) instead of the config's 16-bit type")
     a = ap.parse_args()
     c = dict(bench.CONFIGS[a.config])
     if a.score_thresh is not None:
@@ -32,7 +33,14 @@ def main():
     kw = dict(size_divisible=64) if c["arch"].endswith("6_r60") else {}
     m = YOLOv5(arch=c["arch"], size=(c["size"], c["size"]), score_thresh=c["score_thresh"], nms_thresh=0.45, detections_per_img=300, **kw)
     m.load_state_dict(synth_weights(m.state_dict(), c["arch"], seed=0, head_gain=c["head_gain"]))
-    m = m.to(dev).to(dtype).eval()
+    if a.fp32:
+        dtype = torch.float32
+        m = m.to(dev).eval().set_compute_dtype(torch.float32)
+        m.model.pipeline_depth = 1
+        if c["size"] > 640:
+            c["batch"] = min(c["batch"], 8)
+    else:
+        m = m.to(dev).to(dtype).eval()
     if c["shapes"] == "dynamic":
         imgs = [synth_images(1, *bench.C3_SHAPES[i % 8], seed=1 + i)[0].to(dev).to(dtype) for i in range(c["batch"])]
     else:
