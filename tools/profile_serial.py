@@ -41,6 +41,7 @@ def main():
             c["batch"] = min(c["batch"], 8)
     else:
         m = m.to(dev).to(dtype).eval()
+    m.model.use_graph = False   # per-kernel launches: the same kernels in the same order as the hipGraph replay, each a dispatch of its own for the tracer
     if c["shapes"] == "dynamic":
         imgs = [synth_images(1, *bench.C3_SHAPES[i % 8], seed=1 + i)[0].to(dev).to(dtype) for i in range(c["batch"])]
     else:
