@@ -300,8 +300,10 @@ def conditioned_parity(args, dev, fp32_only=False):
     # (tests/golden/ref16_*.npz: the unmodified reference with .half() / .bfloat16()), the like-for-like yardstick for the production path's distance from fp32.
     import glob
     more = sorted(glob.glob(os.path.join(gold, f"spread_{tag}_s*.npz")))[:5]   # further seeds of the spread workload (make_golden.py spread-more): aggregated below
-    for kind, images_of, path in [("cond", cond_images, os.path.join(gold, f"cond_{tag}.npz")), ("spread", spread_images, os.path.join(gold, f"spread_{tag}.npz"))] + \
-            [("spread", spread_images, f) for f in more]:
+    # ... and (round 5) the LINEAR-REGIME golden: the workload on which the deep networks' 16-bit paths carry an absolute tolerance (tests/test_golden_gpu.py LIN_TOL)
+    lin_tol = {("s", "fp16"): (0.98, 1e-2), ("m", "bf16"): (0.90, 2.5e-2), ("m", "fp16"): (0.98, 1e-2), ("l6", "fp16"): (0.98, 1e-2)}.get((tag, args.dtype))
+    for kind, images_of, path in [("cond", cond_images, os.path.join(gold, f"cond_{tag}.npz")), ("spread", spread_images, os.path.join(gold, f"spread_{tag}.npz")),
+                                  ("lin", cond_images, os.path.join(gold, f"lin_{tag}.npz"))] + [("spread", spread_images, f) for f in more]:
         if not os.path.exists(path):
             continue
         z = np.load(path)
@@ -324,9 +326,9 @@ def conditioned_parity(args, dev, fp32_only=False):
             else:
                 r16 = os.path.join(gold, "ref16_" + os.path.basename(path))
                 own = json.loads(str(np.load(r16)["meta"]))[args.dtype] if os.path.exists(r16) else None
-                tk = spread_tol if kind == "spread" else tol
+                tk = spread_tol if kind == "spread" else (lin_tol if (kind == "lin" and lin_tol is not None) else tol)
                 c = direct_checks(ref, got, thr, score_eps=tk[1], iou_min=tk[0])
-                c["stated_tolerance"] = {"min_iou": tk[0], "max_dscore": tk[1]} if tag != "l6" else None
+                c["stated_tolerance"] = {"min_iou": tk[0], "max_dscore": tk[1]} if (tag != "l6" or kind == "lin") else None
                 c["map_vs_ref_50_95"] = coco_ap(ref, got)
                 g = direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)   # the generous pairing the reference's own 16-bit band was measured with
                 c["distance_from_fp32_reference"] = {"paired": g["paired"], "of": g["ref_dets"], "iou_deficit": round(1.0 - g["min_iou"], 6), "max_dscore": g["max_dscore"]}
@@ -572,7 +574,7 @@ def main_fp32(args):
         cp = conditioned_parity(args, dev, fp32_only=True)
         out["parity"] = {} if cp is None else dict(cp)
         if cp is not None:
-            out["parity"]["unexplained"] = sum(cp[k]["fp32_parity_mode"]["unexplained"] for k in ("cond", "spread", "spread_more") if k in cp)
+            out["parity"]["unexplained"] = sum(cp[k]["fp32_parity_mode"]["unexplained"] for k in ("cond", "spread", "spread_more", "lin") if k in cp)
             out["parity"]["north_star_tolerance"] = "boxes within 1e-3 IoU, |dscore| <= 1e-4, identical label sequences against detections of the UNMODIFIED reference (tests/golden/*.npz)"
         out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
     print(json.dumps(out))
@@ -898,11 +900,12 @@ def main():
             if cp is not None:   # the headline of the block: nothing unexplained on any golden, in either mode
                 # (yolov5l6: no 16-bit tolerance is stated -- the reference's own fp16 run pairs 6 of the golden's 27 detections -- so only its fp32 mode counts here; bf16 on the
                 #  spread workload likewise: its own bf16 run pairs 23 of 94)
-                modes = lambda k: ("fp32_parity_mode",) if (args.arch.endswith("l6_r60") or (k == "spread" and args.dtype == "bf16")) else ("fp32_parity_mode", f"production_{args.dtype}")  # noqa: E731
-                out["parity"]["unexplained"] = sum(cp[k][m_]["unexplained"] for k in ("cond", "spread", "spread_more") if k in cp for m_ in modes("spread" if k == "spread_more" else k))
-                out["parity"]["north_star_tolerance"] = ("boxes within 1e-3 IoU: met by the fp32 parity mode on every golden; the production 16-bit path is reported against the "
-                                                         "reference's OWN 16-bit run (reference_own_*): a per-layer budget (profiles/r04_error_budget_*.csv) shows no 16-bit-storage "
-                                                         "path can meet 1e-3 -- the roundings of ~60 layers add in quadrature and the first 30 would have to stay in fp32")
+                #  spread workload likewise: its own bf16 run pairs 23 of 94.  On the LINEAR-REGIME golden both modes count for every architecture)
+                modes = lambda k: ("fp32_parity_mode",) if (k != "lin" and (args.arch.endswith("l6_r60") or (k == "spread" and args.dtype == "bf16"))) else ("fp32_parity_mode", f"production_{args.dtype}")  # noqa: E731
+                out["parity"]["unexplained"] = sum(cp[k][m_]["unexplained"] for k in ("cond", "spread", "spread_more", "lin") if k in cp for m_ in modes("spread" if k == "spread_more" else k))
+                out["parity"]["north_star_tolerance"] = ("boxes within 1e-3 IoU: met by the fp32 mode on every golden, at fp32_parity_mode_images_per_s (>= 4000 on C2); the production 16-bit "
+                                                         "path is held to stated constant tolerances (cond / spread / lin) and reported against the reference's OWN 16-bit run (reference_own_*): "
+                                                         "a per-layer budget (profiles/r04_error_budget_*.csv) shows no 16-bit-storage path can meet 1e-3")
                 out["parity"]["fp32_parity_mode_images_per_s"] = fp32_mode_throughput(args, dev, images_cpu)
             out["parity"]["benchmark_workload"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
