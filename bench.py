@@ -328,7 +328,8 @@ def conditioned_parity(args, dev, fp32_only=False):
                 own = json.loads(str(np.load(r16)["meta"]))[args.dtype] if os.path.exists(r16) else None
                 tk = spread_tol if kind == "spread" else (lin_tol if (kind == "lin" and lin_tol is not None) else tol)
                 c = direct_checks(ref, got, thr, score_eps=tk[1], iou_min=tk[0])
-                c["stated_tolerance"] = {"min_iou": tk[0], "max_dscore": tk[1]} if (tag != "l6" or kind == "lin") else None
+                relative_only = kind != "lin" and (tag == "l6" or (kind == "spread" and args.dtype == "bf16"))   # no absolute tolerance is stated there: held to the reference's OWN 16-bit run (tests/test_golden_gpu.py)
+                c["stated_tolerance"] = None if relative_only else {"min_iou": tk[0], "max_dscore": tk[1]}
                 c["map_vs_ref_50_95"] = coco_ap(ref, got)
                 g = direct_checks(ref, got, thr, score_eps=0.1, iou_min=0.5)   # the generous pairing the reference's own 16-bit band was measured with
                 c["distance_from_fp32_reference"] = {"paired": g["paired"], "of": g["ref_dets"], "iou_deficit": round(1.0 - g["min_iou"], 6), "max_dscore": g["max_dscore"]}
@@ -355,7 +356,7 @@ def conditioned_parity(args, dev, fp32_only=False):
         if not fp32_only and all("reference_own_" + args.dtype in b[p16] for b in per):
             agg[p16]["iou_deficit_vs_reference_own_per_seed"] = [b[p16]["iou_deficit_vs_reference_own"] for b in per]
             agg[p16]["dscore_vs_reference_own_per_seed"] = [b[p16]["dscore_vs_reference_own"] for b in per]
-            agg[p16]["score_tolerance_per_seed"] = [b[p16]["stated_tolerance"]["max_dscore"] for b in per]
+            agg[p16]["score_tolerance_per_seed"] = [(b[p16]["stated_tolerance"] or {}).get("max_dscore") for b in per]
             agg[p16]["reference_own_paired"] = [sum(b[p16]["reference_own_" + args.dtype]["paired"] for b in per), sum(b[p16]["reference_own_" + args.dtype]["of"] for b in per)]
         out["spread_more"] = agg
     torch.cuda.empty_cache()
@@ -899,10 +900,12 @@ def main():
             out["parity"] = {} if cp is None else dict(cp)
             if cp is not None:   # the headline of the block: nothing unexplained on any golden, in either mode
                 # (yolov5l6: no 16-bit tolerance is stated -- the reference's own fp16 run pairs 6 of the golden's 27 detections -- so only its fp32 mode counts here; bf16 on the
-                #  spread workload likewise: its own bf16 run pairs 23 of 94)
                 #  spread workload likewise: its own bf16 run pairs 23 of 94.  On the LINEAR-REGIME golden both modes count for every architecture)
                 modes = lambda k: ("fp32_parity_mode",) if (k != "lin" and (args.arch.endswith("l6_r60") or (k == "spread" and args.dtype == "bf16"))) else ("fp32_parity_mode", f"production_{args.dtype}")  # noqa: E731
                 out["parity"]["unexplained"] = sum(cp[k][m_]["unexplained"] for k in ("cond", "spread", "spread_more", "lin") if k in cp for m_ in modes("spread" if k == "spread_more" else k))
+                out["parity"]["unexplained_scope"] = ("fp32 mode on every golden + the 16-bit path wherever `stated_tolerance` is not null (cond / spread / lin); blocks with a null "
+                                                      "tolerance (yolov5l6 cond, bf16 spread) sit in the regime where the reference's own 16-bit run re-decides most detections "
+                                                      "(reference_own_*) and are compared with that run instead (tests/test_golden_gpu.py)")
                 out["parity"]["north_star_tolerance"] = ("boxes within 1e-3 IoU: met by the fp32 mode on every golden, at fp32_parity_mode_images_per_s (>= 4000 on C2); the production 16-bit "
                                                          "path is held to stated constant tolerances (cond / spread / lin) and reported against the reference's OWN 16-bit run (reference_own_*): "
                                                          "a per-layer budget (profiles/r04_error_budget_*.csv) shows no 16-bit-storage path can meet 1e-3")
