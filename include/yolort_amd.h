@@ -43,6 +43,11 @@ extern "C" {
 /* activation after conv */
 #define YMI_ACT_NONE 0
 #define YMI_ACT_SILU 1
+/* the activations of the legacy r3.1 blocks (common.py:64-65 `Conv(version="r3.1")`: Hardswish; common.py:140 `BottleneckCSP.act`: LeakyReLU(0.1)): carried by the general
+ * epilogues of the implicit-GEMM / LDS-halo families and by the fp32 mode; the kernels with a SiLU-only epilogue (streaming 1x1, resident-weights 3x3, fused C3 / stem,
+ * chained convs) refuse them */
+#define YMI_ACT_HARDSWISH 2
+#define YMI_ACT_LEAKY 3
 
 int ymi_abi_version(void);
 const char* ymi_last_error(void);
@@ -331,6 +336,18 @@ int ymi_plan_num_ops(const ymi_plan* p);
 int ymi_plan_set_fuse_stem(ymi_plan* p, int on);
 /* runs ops [first, last) on stream (last < 0 = all); use_graph != 0 replays a captured hipGraph */
 int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream);
+/* ---- one batch of a serving loop in two calls (the host side of yolo.py:141-183 per batch: YOLO._acquire / _submit_entry) ----
+ * ymi_plan_begin: the next batch's inputs were produced on `caller_stream`; `main_stream` (the stream this plan instance launches its conv stack on) waits for
+ *   them and for the plan's previous batch to have drained (its buffers are about to be overwritten).  No host synchronisation.
+ * ymi_plan_submit: ops [first, n_conv) on `main_stream` (hipGraph replay when use_graph != 0), then ops [n_conv, end) -- the post-process -- on `side_stream`
+ *   behind them, then `result_bytes` of `dev_result` copied to the PINNED `host_result` on `side_stream`, then the plan's completion event.  main_waits_done != 0
+ *   additionally makes `main_stream` wait for that event (one batch in flight).  Neither call synchronises the host or allocates after the first use.
+ * ymi_plan_done_query: 1 = the last submitted batch has completed (or none was submitted), 0 = still running.  ymi_plan_done_sync blocks the host on it. */
+int ymi_plan_begin(ymi_plan* p, void* caller_stream, void* main_stream);
+int ymi_plan_submit(ymi_plan* p, int first, int n_conv, int use_graph, void* main_stream, void* side_stream, const void* dev_result, void* host_result,
+                    size_t result_bytes, int main_waits_done);
+int ymi_plan_done_query(ymi_plan* p);
+int ymi_plan_done_sync(ymi_plan* p);
 /* per-op timing with HIP events on `stream`: ms_out[num_ops], averaged over iters */
 int ymi_plan_profile(ymi_plan* p, int iters, float* ms_out, void* stream);
 

@@ -311,16 +311,23 @@ def test_pinned_resident_weight_tiles_are_validated_against_the_launch():
     assert not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 133) and not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 132) and not p._pinned_ok(desc(64, 128, 2, ACT_SILU), 134)
 
 
-def test_weights_signature_sees_every_way_a_module_tree_can_change():
-    """hipmodule.weights_signature is the plan cache's key: it re-reads the live `_parameters` / `_buffers` / `_modules` dicts on every call (the round-4
+@pytest.mark.parametrize("walk", ["python", "c"])
+def test_weights_signature_sees_every_way_a_module_tree_can_change(walk, monkeypatch):
+    """(both forms of the walk: the interpreter-level one and torch_ext/sig_ext.cpp, skipped when `_ymi_sig.so` is not built)
+    hipmodule.weights_signature is the plan cache's key: it re-reads the live `_parameters` / `_buffers` / `_modules` dicts on every call (the round-4
     form cached the tensor objects behind process-wide registration hooks and missed `del`, `= None` and `_apply` with overwrite-on-conversion)"""
     import copy
 
     from torch import nn
 
+    from yolort_amd import hipmodule
     from yolort_amd.hipmodule import weights_signature
     from yolort_amd.models import yolo
 
+    if walk == "python":
+        monkeypatch.setattr(hipmodule, "_SIG_EXT", None)
+    elif hipmodule._SIG_EXT is None:
+        pytest.skip("yolort_amd/lib/_ymi_sig.so is not built (python -m yolort_amd.torch_ext)")
     base = yolo.yolov5_darknet_pan_n_r60().eval()
     s0 = weights_signature(base)
     assert weights_signature(base) == s0 and weights_signature(copy.deepcopy(base)) != s0    # stable; another set of tensors is another key

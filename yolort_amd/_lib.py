@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("YOLORT_AMD_LIB") or os.path.join(_HERE, "lib", "libyo
 
 YMI_F16, YMI_BF16, YMI_F32, YMI_U8 = 0, 1, 2, 3
 YMI_U8_HWC = 4   # ymi_letterbox input only: interleaved (h, w, 3) uint8
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_HARDSWISH, ACT_LEAKY = 0, 1, 2, 3   # include/yolort_amd.h YMI_ACT_*: the last two belong to the legacy r3.1 blocks
 MAX_LEVELS = 4
 
 
@@ -117,6 +117,10 @@ _SIGS = {
     "ymi_plan_set_fuse_stem": (C.c_int, [C.c_void_p, C.c_int]),
     "ymi_plan_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ymi_plan_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "ymi_plan_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ymi_plan_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "ymi_plan_done_query": (C.c_int, [C.c_void_p]),
+    "ymi_plan_done_sync": (C.c_int, [C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

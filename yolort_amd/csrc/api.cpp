@@ -100,6 +100,9 @@ struct ymi_plan {
     hipGraphExec_t exec = nullptr;
     int graph_first = -1, graph_last = -1;
     hipStream_t graph_stream = nullptr;
+    // ymi_plan_begin / ymi_plan_submit: inputs ready (caller's stream), conv stack done (main stream), batch done (side stream); created at first use
+    hipEvent_t ev_in = nullptr, ev_conv = nullptr, ev_done = nullptr;
+    bool submitted = false;
 };
 
 using namespace ymi;
@@ -154,6 +157,8 @@ static void drop_graph(ymi_plan* p) {
 extern "C" void ymi_plan_destroy(ymi_plan* p) {
     if (!p) return;
     drop_graph(p);
+    for (hipEvent_t e : {p->ev_in, p->ev_conv, p->ev_done})
+        if (e) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -323,6 +328,74 @@ extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, voi
         p->graph_last = last;
     }
     YMI_CHECK_HIP(hipGraphLaunch(p->exec, s));
+    return YMI_OK;
+}
+
+static int plan_events(ymi_plan* p) {
+    if (p->ev_done) return YMI_OK;
+    YMI_CHECK_HIP(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
+    YMI_CHECK_HIP(hipEventCreateWithFlags(&p->ev_conv, hipEventDisableTiming));
+    YMI_CHECK_HIP(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
+    return YMI_OK;
+}
+
+extern "C" int ymi_plan_begin(ymi_plan* p, void* caller_stream, void* main_stream) {
+    YMI_REQUIRE(p != nullptr, "ymi_plan_begin: null plan");
+    int rc = plan_events(p);
+    if (rc != YMI_OK) return rc;
+    hipStream_t cs = (hipStream_t)caller_stream, ms = (hipStream_t)main_stream;
+    if (cs != ms) {
+        YMI_CHECK_HIP(hipEventRecord(p->ev_in, cs));
+        YMI_CHECK_HIP(hipStreamWaitEvent(ms, p->ev_in, 0));
+    }
+    if (p->submitted) YMI_CHECK_HIP(hipStreamWaitEvent(ms, p->ev_done, 0));
+    return YMI_OK;
+}
+
+extern "C" int ymi_plan_submit(ymi_plan* p, int first, int n_conv, int use_graph, void* main_stream, void* side_stream, const void* dev_result, void* host_result,
+                               size_t result_bytes, int main_waits_done) {
+    YMI_REQUIRE(p != nullptr, "ymi_plan_submit: null plan");
+    const int nops = (int)p->ops.size();
+    YMI_REQUIRE(first >= 0 && first <= n_conv && n_conv <= nops, "ymi_plan_submit: need 0 <= first <= n_conv <= num_ops");
+    YMI_REQUIRE(result_bytes == 0 || (dev_result != nullptr && host_result != nullptr), "ymi_plan_submit: result_bytes without buffers");
+    int rc = plan_events(p);
+    if (rc != YMI_OK) return rc;
+    hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+    if (first < n_conv) {
+        rc = ymi_plan_run(p, first, n_conv, use_graph, main_stream);
+        if (rc != YMI_OK) return rc;
+    }
+    if (ss != ms) {
+        YMI_CHECK_HIP(hipEventRecord(p->ev_conv, ms));
+        YMI_CHECK_HIP(hipStreamWaitEvent(ss, p->ev_conv, 0));
+    }
+    if (n_conv < nops) {
+        rc = ymi_plan_run(p, n_conv, nops, 0, side_stream);
+        if (rc != YMI_OK) return rc;
+    }
+    if (result_bytes) YMI_CHECK_HIP(hipMemcpyAsync(host_result, dev_result, result_bytes, hipMemcpyDeviceToHost, ss));
+    YMI_CHECK_HIP(hipEventRecord(p->ev_done, ss));
+    p->submitted = true;
+    if (main_waits_done && ss != ms) YMI_CHECK_HIP(hipStreamWaitEvent(ms, p->ev_done, 0));
+    return YMI_OK;
+}
+
+extern "C" int ymi_plan_done_query(ymi_plan* p) {
+    YMI_REQUIRE(p != nullptr, "ymi_plan_done_query: null plan");
+    if (!p->submitted) return 1;
+    const hipError_t e = hipEventQuery(p->ev_done);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();   // not an error: clear the sticky code
+        return 0;
+    }
+    set_error("ymi_plan_done_query: hipEventQuery failed: %s", hipGetErrorString(e));
+    return YMI_EHIP;
+}
+
+extern "C" int ymi_plan_done_sync(ymi_plan* p) {
+    YMI_REQUIRE(p != nullptr, "ymi_plan_done_sync: null plan");
+    if (p->submitted) YMI_CHECK_HIP(hipEventSynchronize(p->ev_done));
     return YMI_OK;
 }
 

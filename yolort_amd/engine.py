@@ -328,6 +328,8 @@ class Plan:
                     # candidate tiles differ per kind, so a table entry must not be applied across kinds
                     0 if chain is None else (1 if len(chain) < 3 or chain[2] is None else 2 + chain[2].c))
             pinned = tile_table().get(tile_key_str(tkey, self.dtype), 0) if self.use_tile_table else 0
+            if act not in (ACT_NONE, ACT_SILU) and 121 <= pinned <= 124:
+                pinned = 0   # the table key does not carry the activation: the streaming 1x1 kernel has a SiLU / identity epilogue only (legacy r3.1 blocks take the general tiles)
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
             elif pinned >= 132 and os.environ.get("YOLORT_AMD_RULES_FIRST", "0") != "1" and self._pinned_ok(d, pinned):
@@ -629,14 +631,15 @@ class Plan:
     def post_finish(self, d: PostDesc, total_anchors: int) -> None:
         self._record(self.lib.ymi_plan_add_post_finish(self.handle, C.byref(d)), "postprocess", kind="post", flops=0.0, bytes=0.0, shape=f"A={total_anchors}")
 
-    def stem_from_planar(self, images: Sequence[Tensor], stream: Optional[torch.cuda.Stream] = None) -> int:
+    def stem_from_planar(self, images: Sequence[Tensor], stream: Optional[torch.cuda.Stream] = None, ptrs: Optional[bytes] = None) -> int:
         """op 0 (the stem conv in super-pixel form) computed straight from planar (3, H, W) images of the compute dtype:
         identity-size batches skip the letterbox pass and its NHWC4 round trip (ymi_conv_stem_planar).  When op 1 is
         Conv(32, 64, 3, 2, 1) over op 0's output (yolov5s: darknetv6.py:81, :85-86) both run as ONE launch and the stem's output
         never reaches memory (ymi_stem_body1_planar; YOLORT_AMD_FUSE_STEM=0 keeps them apart).  Returns the number of leading plan
         ops it has covered (1 or 2): the caller runs the plan from there."""
         d = self.conv_descs[0]
-        ptrs = (C.c_void_p * len(images))(*[im.data_ptr() for im in images])
+        # `ptrs`: the images' data pointers as packed 64-bit words (the C scan of the batch, YOLOv5.forward_async)
+        ptrs = (C.c_void_p * len(images)).from_buffer_copy(ptrs) if ptrs is not None else (C.c_void_p * len(images))(*[im.data_ptr() for im in images])
         if self.stem_body1_fusable():
             check(self.lib.ymi_stem_body1_planar(C.byref(d), C.byref(self.conv_descs[1]), ptrs, len(images), _lib.stream_ptr(stream)), "ymi_stem_body1_planar")
             return 2
@@ -661,13 +664,16 @@ class Plan:
         self.fuse_stem = on
         return on
 
-    def stem_planar_ok(self, images: Sequence[Tensor], canvas_hw: Tuple[int, int]) -> bool:
+    def stem_planar_ok(self, images: Sequence[Tensor], canvas_hw: Tuple[int, int], scan=None) -> bool:
+        """`scan`: the C pass over the image list (torch_ext/sig_ext.cpp images(): one device, one dtype; uniform shape, contiguity, 16-byte alignment) in place of the per-image reads"""
         d = self.conv_descs.get(0)
         if self.fp32 or d is None or not d.zeros or not (d.cin == 8 and d.kh == 6 and d.kw == 3 and d.sh == 2 and d.sw == 1 and d.cout_pad <= 64 and not d.res):
             return False
         hb, wb = canvas_hw
         if wb % 8 or d.h != hb or d.w_in * 2 != wb or len(images) != d.n:
             return False
+        if scan is not None:
+            return scan[3] == (3, hb, wb) and scan[5] and scan[6] and scan[1] == self.device.index and images[0].dtype == self.dtype
         return all(im.device == self.device and im.dtype == self.dtype and tuple(im.shape) == (3, hb, wb) and im.is_contiguous() and im.data_ptr() % 16 == 0
                    for im in images)
 

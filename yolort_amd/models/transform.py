@@ -121,21 +121,31 @@ class YOLOTransform(nn.Module):
     def image_hw(im: Tensor) -> Tuple[int, int]:
         return (int(im.shape[0]), int(im.shape[1])) if YOLOTransform.is_hwc(im) else (int(im.shape[-2]), int(im.shape[-1]))
 
-    def letterbox_into(self, images: Sequence[Tensor], out: View, sizes, pads) -> None:
+    def letterbox_into(self, images: Sequence[Tensor], out: View, sizes, pads, stream=None, ptrs: Optional[bytes] = None, uniform_kind: bool = False) -> None:
+        """`ptrs` / `uniform_kind`: from the C pass over the image list (YOLOv5.forward_async): the data pointers of contiguous images as packed 64-bit words, and the promise
+        that the images share dtype and layout"""
         lib = _lib.load(require_gpu=True)
         n = len(images)
-        kinds = {(im.dtype, self.is_hwc(im)) for im in images}
-        if len(kinds) != 1:
-            raise YmiError("all images of a batch must share one dtype and layout")
+        if not uniform_kind:
+            kinds = {(im.dtype, self.is_hwc(im)) for im in images}
+            if len(kinds) != 1:
+                raise YmiError("all images of a batch must share one dtype and layout")
         hwc = self.is_hwc(images[0])
-        imgs = [im if im.is_contiguous() else im.contiguous() for im in images]
-        ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in imgs])
-        geom = (C.c_int32 * (6 * n))()
+        imgs = images
+        if ptrs is not None:
+            ptrs = (C.c_void_p * n).from_buffer_copy(ptrs)
+        else:
+            if not all(im.is_contiguous() for im in images):   # the copies are torch work: they run on (and their memory belongs to) the stream of the launch below
+                with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+                    imgs = [im if im.is_contiguous() else im.contiguous() for im in images]
+            ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in imgs])
+        flat = []
         for i, im in enumerate(imgs):
-            h_in, w_in = self.image_hw(im)
-            geom[6 * i: 6 * i + 6] = [h_in, w_in, sizes[i][0], sizes[i][1], pads[i][0], pads[i][1]]
+            sh = im.shape
+            flat += [sh[0], sh[1], sizes[i][0], sizes[i][1], pads[i][0], pads[i][1]] if hwc else [sh[-2], sh[-1], sizes[i][0], sizes[i][1], pads[i][0], pads[i][1]]
+        geom = (C.c_int32 * (6 * n))(*flat)
         check(lib.ymi_letterbox(ptrs, geom, n, _lib.YMI_U8_HWC if hwc else dtype_code(imgs[0].dtype), out.ptr, out.h, out.w, out.c, dtype_code(out.dtype),
-                                C.c_float(self.fill_color), _lib.stream_ptr()), "ymi_letterbox")
+                                C.c_float(self.fill_color), _lib.stream_ptr(stream)), "ymi_letterbox")
 
     def forward(self, images: Sequence[Tensor], targets=None, dtype: Optional[torch.dtype] = None, out: Optional[View] = None):
         if targets is not None:

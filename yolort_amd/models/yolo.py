@@ -14,7 +14,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
-from .._lib import POST_EXACT_FULL, YmiError
+from .._lib import POST_EXACT_FULL, YmiError, check
 from ..engine import Plan, View
 from ..hipmodule import compute_dtype_of, nchw_to_view, view_to_nchw, weights_signature
 from ..ops import slab_to_list
@@ -31,8 +31,28 @@ __all__ = [
     "yolov5_darknet_pan_s_r40", "yolov5_darknet_pan_m_r40", "yolov5_darknet_pan_l_r40", "yolov5_darknet_tan_s_r40",
 ]
 
+_SKIP_POST = os.environ.get("YOLORT_AMD_DEBUG_SKIP_POST", "0") == "1"   # tuning aid (read at import): submit without the post-process
+
 DEFAULT_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # yolo.py:94-99
 P6_ANCHORS = [[19, 27, 44, 40, 38, 94], [96, 68, 86, 152, 180, 137], [140, 301, 303, 264, 238, 542], [436, 615, 739, 380, 925, 792]]  # yolo.py:642-647
+
+
+class _PlanDone:
+    """The plan's own completion event (csrc/api.cpp ymi_plan_submit) behind the two calls the ring and PendingDetections make on a torch.cuda.Event.  One per plan
+    instance: an instance is never resubmitted while the handle of its previous batch is uncollected (YOLO._entry), so the event always belongs to the handle that reads it."""
+    __slots__ = ("lib", "handle")
+
+    def __init__(self, plan: Plan):
+        self.lib, self.handle = plan.lib, plan.handle
+
+    def query(self) -> bool:
+        rc = self.lib.ymi_plan_done_query(self.handle)
+        if rc < 0:
+            check(rc, "ymi_plan_done_query")
+        return rc == 1
+
+    def synchronize(self) -> None:
+        check(self.lib.ymi_plan_done_sync(self.handle), "ymi_plan_done_sync")
 
 
 class _PlanEntry:
@@ -54,6 +74,14 @@ class _PlanEntry:
         # each plan instance runs its conv stack on its own stream: consecutive batches overlap on the GPU
         # (the tail of one batch's kernels is filled by the next batch's), measured +12 % on yolov5s bs 32
         self.main_stream = torch.cuda.Stream(device=x.base.device, priority=cp)
+        # the default serving path submits a batch in two C calls (ymi_plan_begin / ymi_plan_submit: stream dependencies, graph replay, post-process launches, the result
+        # copy and the completion event without a torch stream / event object in between); YOLORT_AMD_C_SUBMIT=0 keeps the torch-level sequence (the A/B partner, and the
+        # path of measurement brackets and the distributed gather)
+        self.c_submit = post is not None and os.environ.get("YOLORT_AMD_C_SUBMIT", "1") != "0"
+        self.c_done = _PlanDone(plan) if self.c_submit else None
+        self.main_ptr = self.main_stream.cuda_stream
+        self.side_ptr = self.post_stream.cuda_stream if post is not None else None
+        self.result_bytes = self.result_host.numel() * 4 if post is not None else 0
 
 
 class PendingDetections:
@@ -308,26 +336,36 @@ class YOLO(nn.Module):
                 post = plan.postprocess(logits, strides, ag.anchor_grids, *args, rescale=rescale, flags=flags)
         return _PlanEntry(plan, x, feats, logits, post, rescale, n_backbone)
 
-    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]], first_op: int = 0, ev0=None, planar=None) -> PendingDetections:
+    def _submit_entry(self, e: _PlanEntry, rescale_rows: Optional[List[Tuple[float, float, float]]], first_op: int = 0, ev0=None, planar=None, main=None) -> PendingDetections:
         """input view already filled on the current stream; enqueues the plan and returns a handle.
         Conv stack on the current stream, post-process + result copy on the entry's side stream, so
         the next batch's convolutions overlap this batch's sort/NMS (few, long-running waves)."""
         if e.post is None:  # custom hooks: HIP backbone, then the injected modules on torch tensors
             # from `first_op`: a planar-stem batch has already run ops 0 (and 1) from the images themselves and never filled the NHWC4 canvas (ADVICE r3)
-            e.plan.run(first_op, -1, graph=self.use_graph)
+            e.plan.run(first_op, -1, graph=self.use_graph)   # (current stream: the callers enter the instance's stream for this branch)
             feats = [view_to_nchw(v) for v in e.feats]
             head_outputs = self.head(feats)
             grids, shifts = self.anchor_generator(feats)
             return PendingDetections(self, e, None, hook_result=self.post_process(head_outputs, grids, shifts))
-        main = torch.cuda.current_stream()
+        if main is None:
+            main = torch.cuda.current_stream()
         if not e.rescale_set or e.rescale_rows is not rescale_rows:   # (the memoised geometry hands over the SAME list object for the same size list)
             if rescale_rows is None:
                 e.rescale_host.zero_()
             else:
                 e.rescale_host.copy_(torch.tensor(rescale_rows, dtype=torch.float32))
-            e.rescale.copy_(e.rescale_host, non_blocking=True)
+            with torch.cuda.stream(main):
+                e.rescale.copy_(e.rescale_host, non_blocking=True)
             e.rescale_rows, e.rescale_set = rescale_rows, True
         br = self.bracket
+        gather = self._gather_on and not self._in_redo
+        if e.c_submit and br is None and not gather and not _SKIP_POST:
+            check(e.plan.lib.ymi_plan_submit(e.plan.handle, first_op, e.n_conv_ops, 1 if self.use_graph else 0, main.cuda_stream, e.side_ptr, e.post.status_count.data_ptr(),
+                                             e.result_host.data_ptr(), e.result_bytes, 1 if self.pipeline_depth <= 1 else 0), "ymi_plan_submit")
+            e.done = e.c_done
+            pd = PendingDetections(self, e, rescale_rows, planar=planar)
+            e.outstanding = pd
+            return pd
         if br is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             if ev0 is None:   # the caller already started the bracket when it issued op 0 itself (stem from planar images)
@@ -341,7 +379,7 @@ class YOLO(nn.Module):
             e.plan.run(first_op, e.n_conv_ops, graph=self.use_graph, stream=main)
         side = e.post_stream
         side.wait_stream(main)
-        if os.environ.get("YOLORT_AMD_DEBUG_SKIP_POST", "0") != "1":   # tuning aid: upper bound without sort/NMS
+        if not _SKIP_POST:   # tuning aid: upper bound without sort/NMS
             if br is not None:
                 p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 p0.record(side)
@@ -353,7 +391,6 @@ class YOLO(nn.Module):
                 e.plan.run(e.n_conv_ops, -1, stream=side)
         with torch.cuda.stream(side):
             e.result_host.copy_(e.post.status_count, non_blocking=True)
-            gather = self._gather_on and not self._in_redo
             if gather:   # the collective waits for the post-process on `side`, and `side` then waits for it (no host sync)
                 import torch.distributed as dist
 
@@ -380,6 +417,12 @@ class YOLO(nn.Module):
         """next plan instance of the ring for this shape; waits (on the GPU, not the host) until the
         work previously submitted on it has drained before its buffers are overwritten"""
         e = self._entry(n, h, w, device)
+        if e.c_submit:
+            if e.done is not None and e.done is not e.c_done:   # the previous batch went the torch-level way (bracket / gather)
+                e.main_stream.wait_event(e.done)
+            # inputs were produced on the caller's stream; the instance's previous batch must have drained: both dependencies in one call
+            check(e.plan.lib.ymi_plan_begin(e.plan.handle, torch.cuda.current_stream().cuda_stream, e.main_ptr), "ymi_plan_begin")
+            return e
         e.main_stream.wait_stream(torch.cuda.current_stream())   # inputs were produced on the caller's stream
         if e.done is not None:
             e.main_stream.wait_event(e.done)

@@ -7,6 +7,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from .. import hipmodule
 from .._lib import YmiError
 from ..utils import contains_any_tensor
 from . import yolo
@@ -66,12 +67,29 @@ class YOLOv5(nn.Module):
         if targets is not None:
             raise NotImplementedError("targets belong to the training path (out of scope)")
         images = [inputs[i] for i in range(len(inputs))]
-        for im in images:
-            if im.dim() != 3:  # reference transform.py:185-189
-                raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], but got '{im.shape}'.")
-            if not im.is_cuda:
-                raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
-        original = [self.transform.image_hw(im) for im in images]   # (3, H, W) planar, or (H, W, 3) interleaved uint8
+        # the per-image checks (3-d, on the GPU, shape, dtype, contiguity, alignment, data_ptr) in ONE pass in C when yolort_amd/lib/_ymi_sig.so is built (torch_ext/sig_ext.cpp):
+        # (all_3d, device | -1, same_dtype, uniform_shape | None, shapes | None, all_contiguous, all_aligned, data_ptrs).  Lists it cannot vouch for take the per-image path below,
+        # which raises the reference's messages.
+        scan = None
+        if hipmodule._SIG_EXT is not None and images:
+            try:
+                scan = hipmodule._SIG_EXT.images(images)
+            except TypeError:
+                scan = None
+            if scan is not None and not (scan[0] and scan[1] >= 0 and scan[2] and (scan[3] is not None or images[0].dtype != torch.uint8)):
+                scan = None   # (uint8 images of different shapes may mix planar and interleaved layouts: checked one by one)
+        if scan is not None:
+            if scan[3] is not None:
+                original = [self.transform.image_hw(images[0])] * len(images)
+            else:
+                original = [(s_[1], s_[2]) for s_ in scan[4]]
+        else:
+            for im in images:
+                if im.dim() != 3:  # reference transform.py:185-189
+                    raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], but got '{im.shape}'.")
+                if not im.is_cuda:
+                    raise YmiError("yolort_amd runs on an MI355X only: move the model and inputs to 'cuda' (there is no CPU fallback)")
+            original = [self.transform.image_hw(im) for im in images]   # (3, H, W) planar, or (H, W, 3) interleaved uint8
         # host geometry (resize / pad / rescale rows) depends on the list of image sizes only: memoised, a serving loop sees
         # the same few size lists again and again
         gkey = (tuple(original), self.transform.min_size, self.transform.max_size, self.transform.size_divisible, self.transform.fixed_shape,
@@ -90,40 +108,49 @@ class YOLOv5(nn.Module):
         model = self.model
         if not isinstance(model, YOLO):
             raise YmiError("YOLOv5.model must be a yolort_amd YOLO")
-        with torch.cuda.device(images[0].device):   # plans, streams and launches belong to the images' device
-            return self._enqueue(model, images, (hb, wb), sizes, pads, rows_cached, identity, original)
+        dev = images[0].device
+        if dev.index == torch.cuda.current_device():
+            return self._enqueue(model, images, (hb, wb), sizes, pads, rows_cached, identity, original, scan)
+        with torch.cuda.device(dev):   # plans, streams and launches belong to the images' device
+            return self._enqueue(model, images, (hb, wb), sizes, pads, rows_cached, identity, original, scan)
 
-    def _enqueue(self, model: YOLO, images, canvas, sizes, pads, rows_cached, identity, original):
+    def _enqueue(self, model: YOLO, images, canvas, sizes, pads, rows_cached, identity, original, scan=None):
         hb, wb = canvas
         e = model._acquire(len(images), hb, wb, images[0].device)
-        with torch.cuda.stream(e.main_stream):
-            # fixed-size stream: every image already is the canvas (resize = identity, no padding) in the compute dtype ->
-            # the stem reads the planar images itself, the letterbox pass and its NHWC4 copy are skipped (bit-identical)
-            planar = model.stem_from_planar and identity and e.plan.stem_planar_ok(images, (hb, wb))
-            ev0 = None
-            first_op = 0
-            if planar:
-                for im in images:
-                    im.record_stream(e.main_stream)
-                if model.bracket is not None:   # measurement hook: the conv bracket starts with the stem
-                    ev0 = torch.cuda.Event(enable_timing=True)
-                    ev0.record(torch.cuda.current_stream())
-                first_op = e.plan.stem_from_planar(images)   # 1, or 2 when the stem and body.1 ran as one launch
-            elif model.bracket is not None:
-                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                l0.record(torch.cuda.current_stream())
-                self.transform.letterbox_into(images, e.x, sizes, pads)
-                l1.record(torch.cuda.current_stream())
-                model.bracket["pre"][0].append(l0)
-                model.bracket["pre"][1].append(l1)
-            else:
-                self.transform.letterbox_into(images, e.x, sizes, pads)
-            rows = rows_cached
-            if e.post is None:  # custom post_process hook: rescale afterwards like the reference (yolov5.py:181)
+        main = e.main_stream   # every launch below names its stream: no stream context is entered on the default path
+        # fixed-size stream: every image already is the canvas (resize = identity, no padding) in the compute dtype ->
+        # the stem reads the planar images itself, the letterbox pass and its NHWC4 copy are skipped (bit-identical)
+        planar = model.stem_from_planar and identity and e.plan.stem_planar_ok(images, (hb, wb), scan)
+        ev0 = None
+        first_op = 0
+        ptrs = None
+        if scan is not None:   # allocated on the caller's stream, read on the instance's
+            hipmodule._SIG_EXT.record_stream(images, main.stream_id, main.device_index, main.device_type)
+            ptrs = scan[7] if scan[5] else None
+        else:
+            for im in images:
+                im.record_stream(main)
+        if planar:
+            if model.bracket is not None:   # measurement hook: the conv bracket starts with the stem
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(main)
+            first_op = e.plan.stem_from_planar(images, stream=main, ptrs=ptrs)   # 1, or 2 when the stem and body.1 ran as one launch
+        elif model.bracket is not None:
+            l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            l0.record(main)
+            self.transform.letterbox_into(images, e.x, sizes, pads, stream=main, ptrs=ptrs, uniform_kind=scan is not None)
+            l1.record(main)
+            model.bracket["pre"][0].append(l0)
+            model.bracket["pre"][1].append(l1)
+        else:
+            self.transform.letterbox_into(images, e.x, sizes, pads, stream=main, ptrs=ptrs, uniform_kind=scan is not None)
+        rows = rows_cached
+        if e.post is None:  # custom post_process hook (torch modules: they run in the instance's stream context); rescale afterwards like the reference (yolov5.py:181)
+            with torch.cuda.stream(main):
                 pend = model._submit_entry(e, None, first_op, ev0, planar=images if planar else None)
                 pend.hook_result = self.transform.postprocess(pend.hook_result, (hb, wb), original)
-                return pend
-            return model._submit_entry(e, rows, first_op, ev0, planar=images if planar else None)
+            return pend
+        return model._submit_entry(e, rows, first_op, ev0, planar=images if planar else None, main=main)
 
     @torch.no_grad()
     def predict(self, x: Any, image_loader: Optional[Callable] = None, canvas: Optional[Tuple[int, int]] = None) -> List[Dict[str, Tensor]]:

@@ -41,6 +41,34 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+SIG_LIB = os.path.join(_PKG, "lib", "_ymi_sig.so")
+
+
+def build_sig(force: bool = False) -> str:
+    """yolort_amd/lib/_ymi_sig.so: hipmodule.weights_signature's per-batch walk as one C call (sig_ext.cpp; a CPython module linked against libtorch_python).
+    Optional -- hipmodule loads it when the file is there and walks the dicts in Python otherwise."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    src = os.path.join(_HERE, "sig_ext.cpp")
+    if not force and os.path.exists(SIG_LIB) and os.path.getmtime(SIG_LIB) >= os.path.getmtime(src):
+        return SIG_LIB
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("building _ymi_sig.so needs a host C++ compiler (g++ / c++ not found on PATH)")
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}"]
+    os.makedirs(os.path.dirname(SIG_LIB), exist_ok=True)
+    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, src, "-o", SIG_LIB,
+           f"-L{libdir}", "-ltorch_python", "-ltorch", "-ltorch_cpu", "-lc10", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building _ymi_sig.so failed:\n" + r.stderr[-3000:])
+    return SIG_LIB
+
+
 def load() -> str:
     import torch
 
@@ -51,3 +79,4 @@ def load() -> str:
 
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_sig(force=True))

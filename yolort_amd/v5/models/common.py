@@ -1,7 +1,7 @@
-"""YOLOv5 building blocks (r4.0/r6.0 forms) as HIP plan emitters.
+"""YOLOv5 building blocks (r3.1 / r4.0 / r6.0 forms) as HIP plan emitters.
 
 Same constructor signatures, attribute names and state_dict keys as the reference's blocks
-(yolort/v5/models/common.py: Conv :42, Bottleneck :94, C3 :149, SPP :176, SPPF :190) so that its
+(yolort/v5/models/common.py: Conv :42, Bottleneck :94, BottleneckCSP :119, C3 :149, SPP :176, SPPF :190, Focus :210) so that its
 checkpoints load unchanged; the arithmetic is the fused implicit-GEMM kernel (csrc/conv_igemm.hip)
 instead of conv2d -> BatchNorm2d -> SiLU -> cat.
 """
@@ -14,11 +14,11 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import nn
 
-from ..._lib import ACT_NONE, ACT_SILU, YmiError
+from ..._lib import ACT_HARDSWISH, ACT_LEAKY, ACT_NONE, ACT_SILU, YmiError
 from ...engine import PackedConv, Plan, View
 from ...hipmodule import HipModule
 
-__all__ = ["Conv", "Bottleneck", "C3", "SPP", "SPPF", "autopad"]
+__all__ = ["Conv", "Bottleneck", "BottleneckCSP", "C3", "SPP", "SPPF", "Focus", "autopad", "focus_transform", "space_to_depth"]
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03  # set after construction by the reference (darknetv6.py:110-112)
 
@@ -30,20 +30,33 @@ def autopad(k, p=None):
     return p
 
 
+def act_code(act: nn.Module) -> int:
+    """the epilogue's activation code (include/yolort_amd.h YMI_ACT_*) of the activation modules the reference's blocks use"""
+    if isinstance(act, nn.SiLU):
+        return ACT_SILU
+    if isinstance(act, nn.Identity):
+        return ACT_NONE
+    if isinstance(act, nn.Hardswish):
+        return ACT_HARDSWISH
+    if isinstance(act, nn.LeakyReLU) and abs(act.negative_slope - 0.1) < 1e-12:
+        return ACT_LEAKY
+    raise NotImplementedError(f"activation {act!r} is not fused (SiLU, Hardswish, LeakyReLU(0.1) and identity are)")
+
+
 class Conv(HipModule):
-    """conv2d (no bias) + BatchNorm2d + SiLU, fused (reference common.py:42-73)."""
+    """conv2d (no bias) + BatchNorm2d + SiLU (r4.0 / r6.0) or Hardswish (r3.1), fused (reference common.py:42-73)."""
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True, version="r4.0"):
         super().__init__()
         if g != 1:
-            raise NotImplementedError("grouped convolutions are not on the YOLOv5 r6.0 hot path")
-        if version != "r4.0":
+            raise NotImplementedError("grouped convolutions are not on the YOLOv5 hot path")
+        if version not in ("r4.0", "r3.1"):
             raise NotImplementedError(f"Currently doesn't support version {version}.")
         self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
         self.bn = nn.BatchNorm2d(c2, eps=BN_EPS, momentum=BN_MOMENTUM)
-        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
-        if not isinstance(self.act, (nn.SiLU, nn.Identity)):
-            raise NotImplementedError("only SiLU / identity activations are fused")
+        default = nn.SiLU() if version == "r4.0" else nn.Hardswish()   # reference :62-65
+        self.act = default if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+        act_code(self.act)   # refuses activations that no epilogue carries
         self._packed: Dict[Tuple, Tuple] = {}
 
     def _is_stem(self) -> bool:
@@ -67,8 +80,7 @@ class Conv(HipModule):
     def emit(self, plan: Plan, x: View, out: Optional[View] = None, res: Optional[View] = None, name: str = "conv", up2_out: Optional[View] = None,
              chain=None) -> View:
         pc = self.packed(plan.dtype, plan.device, x.c)
-        act = ACT_SILU if isinstance(self.act, nn.SiLU) else ACT_NONE
-        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act, out=out, res=res, name=name, up2_out=up2_out, chain=chain)
+        return plan.conv(x, pc, self.conv.stride, self.conv.padding, act_code(self.act), out=out, res=res, name=name, up2_out=up2_out, chain=chain)
 
 
 class Bottleneck(HipModule):
@@ -117,6 +129,10 @@ class C3(HipModule):
         self.cv3 = Conv(2 * c_, c2, 1, version=version)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, version=version) for _ in range(n)])
         self._pair: Dict[Tuple, Tuple] = {}
+
+    @property
+    def out_channels(self) -> int:
+        return self.cv3.conv.out_channels
 
     def packed_pair(self, dtype: torch.dtype, device: torch.device, cin_view: int) -> PackedConv:
         """cv1 and cv2 read the same input: their folded weights are stacked along cout so ONE launch
@@ -197,6 +213,112 @@ class C3(HipModule):
         if chain3 is not None:
             return chain3[1]
         return self.cv3.emit(plan, cat, out=out, name=name + ".cv3")
+
+
+class BottleneckCSP(HipModule):
+    """cv4(LeakyReLU(BN(cat(cv3(m(cv1(x))), cv2(x))))) (reference :119-146; the r3.1 block: Hardswish in its Conv modules, LeakyReLU(0.1) after the shared BatchNorm).
+    `cv2` and `cv3` are bare convolutions whose outputs meet in one BatchNorm over the concatenation: its first half is folded into cv3, its second into cv2, each with
+    the LeakyReLU in its epilogue, both writing straight into the concat buffer cv4 reads."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1, version="r3.1")
+        self.cv2 = nn.Conv2d(c1, c_, 1, 1, bias=False)
+        self.cv3 = nn.Conv2d(c_, c_, 1, 1, bias=False)
+        self.cv4 = Conv(2 * c_, c2, 1, 1, version="r3.1")
+        self.bn = nn.BatchNorm2d(2 * c_, eps=BN_EPS, momentum=BN_MOMENTUM)
+        self.act = nn.LeakyReLU(0.1, inplace=True)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, version="r3.1") for _ in range(n)])
+        self._half: Dict[Tuple, Tuple] = {}
+
+    @property
+    def out_channels(self) -> int:
+        return self.cv4.conv.out_channels
+
+    def packed_half(self, which: int, dtype: torch.dtype, device: torch.device, cin_view: int) -> PackedConv:
+        """cv3 (which = 0) / cv2 (which = 1) with its half of the shared BatchNorm folded in"""
+        conv = self.cv3 if which == 0 else self.cv2
+        c_ = conv.out_channels
+        sl = slice(which * c_, (which + 1) * c_)
+        bnp = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+        sig = tuple(t._version for t in (conv.weight,) + bnp) + (conv.weight.data_ptr(),)
+        key = (which, dtype, device, cin_view)
+        hit = self._half.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        pc = PackedConv(conv.weight, None, tuple(t[sl] for t in bnp) + (float(self.bn.eps),), dtype, device, cin_pad=cin_view)
+        self._half[key] = (sig, pc)
+        return pc
+
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "csp") -> View:
+        c_ = self.cv1.conv.out_channels
+        if c_ % 8:
+            raise YmiError("BottleneckCSP hidden width must be a multiple of 8")
+        cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
+        y = self.cv1.emit(plan, x, name=name + ".cv1")
+        for j, b in enumerate(self.m):
+            y = b.emit(plan, y, name=f"{name}.m.{j}")
+        act = act_code(self.act)
+        plan.conv(y, self.packed_half(0, plan.dtype, plan.device, y.c), 1, 0, act, out=cat.slice_c(0, c_), name=name + ".cv3+bn")
+        plan.conv(x, self.packed_half(1, plan.dtype, plan.device, x.c), 1, 0, act, out=cat.slice_c(c_, c_), name=name + ".cv2+bn")
+        return self.cv4.emit(plan, cat, out=out, name=name + ".cv4")
+
+
+def focus_transform(x):
+    """x(b,c,h,w) -> y(b,4c,h/2,w/2) (reference :237-240; the torch expression, for callers of the reference's helper -- the HIP path never materialises it)"""
+    return torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
+
+
+def space_to_depth(x):
+    """reference :243-249: the same rearrangement through view / permute"""
+    n, c, h, w = x.size()
+    x = x.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 5, 3, 1, 2, 4)
+    return x.reshape(n, 4 * c, h // 2, w // 2)
+
+
+class Focus(HipModule):
+    """Conv(4 c1, c2, k) over the space-to-depth rearrangement of the image (reference :210-234), the stem of the r3.1 / r4.0 models.
+    The rearrangement is never materialised: slot (dy, dx) of `focus_transform` holds pixel (2Y + dy, 2X + dx), so a k x k convolution with 'same' padding over the 12
+    half-resolution channels IS a 2k x 2k stride-2 convolution with padding k - 1 + ... over the image -- for the reference's k = 3: Conv(3, c2, 6, 2, 2) with
+    W6[o, c, 2 ky + dy, 2 kx + dx] = W3[o, 3 slot(dy, dx) + c, ky, kx], slot = (0,0) (1,0) (0,1) (1,1) -> 0 1 2 3 (ultralytics/yolov5#4825, the equivalence the r6.0 stem was
+    introduced with).  Same products, same zero padding, another summation order: the stem kernels (super-pixel form, planar-image form, fused stem + body.1) run unchanged."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True, version="r4.0"):
+        super().__init__()
+        self.conv = Conv(c1 * 4, c2, k, s, p, g, act, version=version)
+        self._packed: Dict[Tuple, Tuple] = {}
+
+    def _input_cpad(self, c: int) -> int:
+        return 4
+
+    def stem_weight(self) -> torch.Tensor:
+        w = self.conv.conv.weight   # (c2, 4 c1, 3, 3)
+        c2, c4, kh, kw = w.shape
+        c1 = c4 // 4
+        if (kh, kw) != (3, 3) or self.conv.conv.stride != (1, 1) or self.conv.conv.padding != (1, 1) or c1 != 3:
+            raise NotImplementedError("Focus is emitted for the reference's stem only: 3 image channels, k = 3, s = 1, 'same' padding")
+        w6 = w.new_zeros(c2, c1, 6, 6)
+        for slot, (dy, dx) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+            w6[:, :, dy::2, dx::2] = w[:, slot * c1:(slot + 1) * c1]
+        return w6
+
+    def packed(self, dtype: torch.dtype, device: torch.device) -> PackedConv:
+        cv = self.conv
+        sig = tuple(t._version for t in (cv.conv.weight, cv.bn.weight, cv.bn.bias, cv.bn.running_mean, cv.bn.running_var)) + (cv.conv.weight.data_ptr(),)
+        key = (dtype, device)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        bn = (cv.bn.weight, cv.bn.bias, cv.bn.running_mean, cv.bn.running_var, float(cv.bn.eps))
+        pc = PackedConv(self.stem_weight(), None, bn, dtype, device, cin_pad=None, stem_superpixel=True)
+        self._packed[key] = (sig, pc)
+        return pc
+
+    def emit(self, plan: Plan, x: View, out: Optional[View] = None, name: str = "focus") -> View:
+        if x.c != 4:
+            raise YmiError("Focus reads the NHWC4 image view (it is the network's first layer)")
+        return plan.conv(x, self.packed(plan.dtype, plan.device), (2, 2), (2, 2), act_code(self.conv.act), out=out, name=name)
 
 
 class SPP(HipModule):
