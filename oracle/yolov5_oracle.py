@@ -196,8 +196,23 @@ def _q(x: Tensor, layer: Optional[str] = None) -> Tensor:
     return y
 
 
+class _Version:
+    """Activation of the `Conv` blocks of the network being evaluated: "silu" (r4.0 / r6.0, common.py:62-63) or "hardswish" (r3.1, :64-65).  `backbone` sets it from the
+    state_dict's layout for the duration of one evaluation."""
+
+    def __init__(self) -> None:
+        self.act = "silu"
+
+
+VERSION = _Version()
+
+
+def _activation(y: Tensor) -> Tensor:
+    return F.silu(y) if VERSION.act == "silu" else F.hardswish(y)
+
+
 def conv_bn_silu(x: Tensor, sd: Dict[str, Tensor], p: str, stride: int = 1, pad: Optional[int] = None) -> Tensor:
-    """common.py:42-70 `Conv`: SiLU(BN(conv2d(x))), bias-free conv, pad=k//2 (autopad :35-39)."""
+    """common.py:42-70 `Conv`: act(BN(conv2d(x))), bias-free conv, pad=k//2 (autopad :35-39); act = SiLU, or Hardswish in an r3.1 network (VERSION)."""
     w = sd[p + ".conv.weight"]
     k = w.shape[-1]
     if TRACE.hook is not None:
@@ -206,13 +221,46 @@ def conv_bn_silu(x: Tensor, sd: Dict[str, Tensor], p: str, stride: int = 1, pad:
         scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + BN_EPS)
         bias = sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale
         y = F.conv2d(_q(x, p), _q(w * scale.view(-1, 1, 1, 1), p), bias, stride, k // 2 if pad is None else pad)
-        return F.silu(y)
+        return _activation(y)
     y = F.conv2d(x, w, None, stride, k // 2 if pad is None else pad)
     if CALIB.active:
         sd[p + ".bn.running_mean"] = y.mean(dim=(0, 2, 3))
         sd[p + ".bn.running_var"] = y.var(dim=(0, 2, 3), unbiased=False)
     y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, BN_EPS)
-    return F.silu(y)
+    return _activation(y)
+
+
+def focus(x: Tensor, sd: Dict[str, Tensor], p: str) -> Tensor:
+    """common.py:210-240 `Focus`: Conv(4 c1, c2, 3) over cat(x[::2, ::2], x[1::2, ::2], x[::2, 1::2], x[1::2, 1::2]) (rows first: `focus_transform` :237-240)"""
+    if TRACE.hook is not None:
+        TRACE.hook(p, x, 2, 2)   # the block's own input (the image): what the HIP path's stem launch reads
+    y = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
+    return conv_bn_silu(y, sd, p + ".conv")
+
+
+def bottleneck_csp(x: Tensor, sd: Dict[str, Tensor], p: str, shortcut: bool) -> Tensor:
+    """common.py:119-146 `BottleneckCSP` (r3.1): cv4(LeakyReLU_0.1(BN(cat(cv3(m(cv1 x)), cv2 x)))); cv2 / cv3 are bare 1x1 convolutions, the Bottlenecks as in `c3`."""
+    y = conv_bn_silu(x, sd, p + ".cv1")
+    for j in range(_count(sd, p + ".m")):
+        z = conv_bn_silu(conv_bn_silu(y, sd, f"{p}.m.{j}.cv1"), sd, f"{p}.m.{j}.cv2")
+        y = _q(_q(y, f"{p}.m.{j}.cv1") + z, f"{p}.m.{j}.cv2") if (shortcut and EMULATE.dtype is not None) else (y + z if shortcut else z)
+    w3, w2 = sd[p + ".cv3.weight"], sd[p + ".cv2.weight"]
+    if TRACE.hook is not None:
+        TRACE.hook(p + ".cv3", y, 1, 0)
+        TRACE.hook(p + ".cv2", x, 1, 0)
+    if EMULATE.dtype is not None:   # the shared BatchNorm folded into the two bare convolutions, half each (what the HIP path stores)
+        scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + BN_EPS)
+        bias = sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale
+        c_ = w3.shape[0]
+        t = torch.cat((F.conv2d(_q(y, p + ".cv3"), _q(w3 * scale[:c_].view(-1, 1, 1, 1), p + ".cv3"), bias[:c_]),
+                       F.conv2d(_q(x, p + ".cv2"), _q(w2 * scale[c_:].view(-1, 1, 1, 1), p + ".cv2"), bias[c_:])), dim=1)
+    else:
+        t = torch.cat((F.conv2d(y, w3), F.conv2d(x, w2)), dim=1)
+        if CALIB.active:
+            sd[p + ".bn.running_mean"] = t.mean(dim=(0, 2, 3))
+            sd[p + ".bn.running_var"] = t.var(dim=(0, 2, 3), unbiased=False)
+        t = F.batch_norm(t, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, BN_EPS)
+    return conv_bn_silu(F.leaky_relu(t, 0.1), sd, p + ".cv4")
 
 
 def _count(sd: Dict[str, Tensor], prefix: str) -> int:
@@ -243,36 +291,59 @@ def backbone(x: Tensor, sd: Dict[str, Tensor], p: str = "backbone") -> List[Tens
     (darknetv6.py:81-96, backbone_utils.py:107-110) then PathAggregationNetwork.forward
     (path_aggregation_network.py:199-239)."""
     b = p + ".body"
-    x = conv_bn_silu(x, sd, b + ".0", stride=2, pad=2)  # darknetv6.py:81 Conv(3,c,k=6,s=2,p=2)
+    legacy = f"{b}.0.conv.conv.weight" in sd          # Focus stem: darknetv4.py:86 (r3.1 / r4.0)
+    csp = f"{b}.2.cv4.conv.weight" in sd              # BottleneckCSP blocks: r3.1 (darknetv4.py:133-136, path_aggregation_network.py:242-245)
+    VERSION.act = "hardswish" if csp else "silu"
+    try:
+        return _backbone(x, sd, p, legacy, bottleneck_csp if csp else c3)
+    finally:
+        VERSION.act = "silu"
+
+
+def _backbone(x: Tensor, sd: Dict[str, Tensor], p: str, legacy: bool, block) -> List[Tensor]:
+    b = p + ".body"
     taps = []
-    for i in (1, 3, 5, 7):
-        x = conv_bn_silu(x, sd, f"{b}.{i}", stride=2)
-        x = c3(x, sd, f"{b}.{i + 1}", shortcut=True)
-        if i + 1 in (4, 6, 8):
-            taps.append(x)
+    if legacy:   # darknetv4.py:86-100: Focus, 3 x [Conv k3 s2, block], Conv k3 s2, SPP; taps after layers 4, 6, 8 (backbone_utils.py:107-110)
+        x = focus(x, sd, b + ".0")
+        for i in (1, 3, 5):
+            x = conv_bn_silu(x, sd, f"{b}.{i}", stride=2)
+            x = block(x, sd, f"{b}.{i + 1}", shortcut=True)
+            if i + 1 in (4, 6):
+                taps.append(x)
+        x = conv_bn_silu(x, sd, f"{b}.7", stride=2)
+        taps.append(spp(x, sd, f"{b}.8"))
+    else:
+        x = conv_bn_silu(x, sd, b + ".0", stride=2, pad=2)  # darknetv6.py:81 Conv(3,c,k=6,s=2,p=2)
+        for i in (1, 3, 5, 7):
+            x = conv_bn_silu(x, sd, f"{b}.{i}", stride=2)
+            x = block(x, sd, f"{b}.{i + 1}", shortcut=True)
+            if i + 1 in (4, 6, 8):
+                taps.append(x)
+    # the neck's blocks below: C3 (r4.0 / r6.0) or BottleneckCSP (r3.1)
     q = p + ".pan"
     feats = list(taps)
     if f"{q}.intermediate_blocks.p6.0.conv.weight" in sd:  # path_aggregation_network.py:10-41
         y = conv_bn_silu(feats[-1], sd, f"{q}.intermediate_blocks.p6.0", stride=2)
-        feats.append(c3(y, sd, f"{q}.intermediate_blocks.p6.1", shortcut=True))
+        feats.append(block(y, sd, f"{q}.intermediate_blocks.p6.1", shortcut=True))
     nf = len(feats)
     inners: List[Tensor] = []
     last = feats[-1]
     for idx in range(nf - 1):  # path_aggregation_network.py:215-224
         i0 = 3 * idx
-        last = spp(last, sd, f"{q}.inner_blocks.0") if idx == 0 else c3(last, sd, f"{q}.inner_blocks.{i0}", shortcut=False)
+        # path_aggregation_network.py:109-114: the r6.0 neck opens with the SPP, the r3.1 / r4.0 necks with a block (their backbones end in the SPP)
+        last = spp(last, sd, f"{q}.inner_blocks.0") if (idx == 0 and not legacy) else block(last, sd, f"{q}.inner_blocks.{i0}", shortcut=False)
         last = conv_bn_silu(last, sd, f"{q}.inner_blocks.{i0 + 1}")
         inners.insert(0, last)
         last = F.interpolate(last, scale_factor=2.0, mode="nearest")  # nn.Upsample(scale_factor=2)
         last = torch.cat([last, feats[nf - idx - 2]], dim=1)
     inners.insert(0, last)
     results = []
-    last = c3(inners[0], sd, f"{q}.layer_blocks.0", shortcut=False)  # :230-231
+    last = block(inners[0], sd, f"{q}.layer_blocks.0", shortcut=False)  # :230-231
     results.append(last)
     for idx in range(nf - 1):  # :233-237
         last = conv_bn_silu(last, sd, f"{q}.layer_blocks.{2 * idx + 1}", stride=2)
         last = torch.cat([last, inners[idx + 1]], dim=1)
-        last = c3(last, sd, f"{q}.layer_blocks.{2 * idx + 2}", shortcut=False)
+        last = block(last, sd, f"{q}.layer_blocks.{2 * idx + 2}", shortcut=False)
         results.append(last)
     return results
 

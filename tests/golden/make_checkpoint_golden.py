@@ -24,7 +24,50 @@ import torch  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 V5 = "/root/reference/yolort/v5/models"
-ARCHS = {"n": (f"{V5}/yolov5n.yaml", 11), "s": (f"{V5}/yolov5s.yaml", 12), "m": (f"{V5}/yolov5m.yaml", 13), "l": (f"{V5}/yolov5l.yaml", 14), "n6": (f"{V5}/hub/yolov5n6.yaml", 15)}
+ARCHS = {"n": (f"{V5}/yolov5n.yaml", 11), "s": (f"{V5}/yolov5s.yaml", 12), "m": (f"{V5}/yolov5m.yaml", 13), "l": (f"{V5}/yolov5l.yaml", 14), "n6": (f"{V5}/hub/yolov5n6.yaml", 15),
+         "s_r40": ("legacy:C3", 16), "s_r31": ("legacy:BottleneckCSP", 17)}   # round 5: the legacy releases (the reference vendors no yaml for them: LEGACY_YAML below)
+VERSION = {"s_r40": "r4.0", "s_r31": "r3.1"}
+
+# ultralytics/yolov5's model description of the r3.1 / r4.0 yolov5s (Focus stem, SPP inside the backbone, the neck's first block as backbone layer 9), restated in the upstream
+# yaml format; BLOCK = C3 (r4.0) or BottleneckCSP (r3.1).  The layer indices are the ones the reference's index maps assume (_checkpoint.py:53-64).
+LEGACY_YAML = """
+nc: 80
+depth_multiple: 0.33
+width_multiple: 0.50
+anchors:
+  - [10,13, 16,30, 33,23]
+  - [30,61, 62,45, 59,119]
+  - [116,90, 156,198, 373,326]
+backbone:
+  [[-1, 1, Focus, [64, 3]],
+   [-1, 1, Conv, [128, 3, 2]],
+   [-1, 3, BLOCK, [128]],
+   [-1, 1, Conv, [256, 3, 2]],
+   [-1, 9, BLOCK, [256]],
+   [-1, 1, Conv, [512, 3, 2]],
+   [-1, 9, BLOCK, [512]],
+   [-1, 1, Conv, [1024, 3, 2]],
+   [-1, 1, SPP, [1024, [5, 9, 13]]],
+   [-1, 3, BLOCK, [1024, False]],
+  ]
+head:
+  [[-1, 1, Conv, [512, 1, 1]],
+   [-1, 1, nn.Upsample, [None, 2, 'nearest']],
+   [[-1, 6], 1, Concat, [1]],
+   [-1, 3, BLOCK, [512, False]],
+   [-1, 1, Conv, [256, 1, 1]],
+   [-1, 1, nn.Upsample, [None, 2, 'nearest']],
+   [[-1, 4], 1, Concat, [1]],
+   [-1, 3, BLOCK, [256, False]],
+   [-1, 1, Conv, [256, 3, 2]],
+   [[-1, 14], 1, Concat, [1]],
+   [-1, 3, BLOCK, [512, False]],
+   [-1, 1, Conv, [512, 3, 2]],
+   [[-1, 10], 1, Concat, [1]],
+   [-1, 3, BLOCK, [1024, False]],
+   [[17, 20, 23], 1, Detect, [nc, anchors]],
+  ]
+"""
 
 
 def tensor_sha(t: torch.Tensor) -> str:
@@ -40,6 +83,12 @@ def build_upstream_checkpoint(tag: str, path: str) -> None:
     from yolort.v5.helper import add_yolov5_context
 
     cfg, seed = ARCHS[tag]
+    if cfg.startswith("legacy:"):
+        import tempfile
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False)
+        tmp.write(LEGACY_YAML.replace("BLOCK", cfg.split(":")[1]))
+        tmp.close()
+        cfg = tmp.name
     with add_yolov5_context():
         import models.yolo as upstream   # yolort/v5/models/yolo.py under its upstream name
 
@@ -57,10 +106,10 @@ def build_upstream_checkpoint(tag: str, path: str) -> None:
         torch.save(ckpt, path)
 
 
-def reference_conversion(path: str) -> dict:
+def reference_conversion(path: str, version: str = "r6.0") -> dict:
     from yolort.models._checkpoint import load_from_ultralytics
 
-    info = load_from_ultralytics(path)
+    info = load_from_ultralytics(path, version=version)
     sd = info["state_dict"]
     return {"num_classes": int(info["num_classes"]), "depth_multiple": float(info["depth_multiple"]), "width_multiple": float(info["width_multiple"]),
             "strides": [float(s) for s in torch.as_tensor(info["strides"]).tolist()], "anchor_grids": [[float(v) for v in row] for row in info["anchor_grids"]],
@@ -80,7 +129,8 @@ def main():
         for tag in ARCHS:
             path = os.path.join(GOLD, "yolov5n_upstream_format.pt") if tag == "n" else os.path.join(td, f"yolov5{tag}.pt")
             build_upstream_checkpoint(tag, path)
-            rec = reference_conversion(path)
+            rec = reference_conversion(path, VERSION.get(tag, "r6.0"))
+            rec["version"] = VERSION.get(tag, "r6.0")
             rec["checkpoint_bytes"] = os.path.getsize(path)
             out["archs"][tag] = rec
             print(tag, len(rec["keys"]), "tensors", rec["checkpoint_bytes"], "bytes", rec["size"], rec["use_p6"], rec["strides"], flush=True)

@@ -111,7 +111,8 @@ def e2e_golden(arch="yolov5_darknet_pan_n_r60", tag="n", sizes=((160, 120), (96,
 # the reference's own fp32-vs-fp64 reproducibility, and the tolerance a 16-bit evaluation can be held to, measured with jittered
 # storage emulations BEFORE it is written into a GPU test.  (2) the reference's asset photos through `predict(path)`.
 # ---------------------------------------------------------------------------------------------------------------------------
-COND_TAGS = {"yolov5_darknet_pan_n_r60": "n", "yolov5_darknet_pan_s_r60": "s", "yolov5_darknet_pan_m_r60": "m", "yolov5_darknet_pan_l6_r60": "l6"}
+COND_TAGS = {"yolov5_darknet_pan_n_r60": "n", "yolov5_darknet_pan_s_r60": "s", "yolov5_darknet_pan_m_r60": "m", "yolov5_darknet_pan_l6_r60": "l6",
+             "yolov5_darknet_pan_s_r40": "s_r40", "yolov5_darknet_pan_s_r31": "s_r31"}
 
 
 def _np_dets(dets):
@@ -330,7 +331,8 @@ def _band(ref, got, thr):
 def ref16_golden(kind, tag):
     from oracle.make_synth_bn import photo_images
     from workloads.synth import cond_images, conditioned_weights, spread_images
-    arch = {v: k for k, v in COND_TAGS.items()}[tag.split("_")[0]]   # (tag "s_s3": the extra seeds of spread_more)
+    by_tag = {v: k for k, v in COND_TAGS.items()}
+    arch = by_tag[tag] if tag in by_tag else by_tag[tag.split("_")[0]]   # (tag "s_s3": the extra seeds of spread_more; "s_r40" / "s_r31": the legacy releases)
     z = np.load(os.path.join(HERE, f"{kind}_{tag}.npz"))
     meta = json.loads(str(z["meta"]))
     S, thr, seed = meta["S"], meta["thr"], meta["seed"]
@@ -510,6 +512,7 @@ def cond_gap_golden(arch, seeds, force_last=True, variant="cond", min_dets=12):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cond-gap":   # usage: cond-gap arch seed [seed ...]
         cond_gap_golden(sys.argv[2], [int(a) for a in sys.argv[3:]])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lin-gap":   # usage: lin-gap arch seed [seed ...]   (round 5: the LINEAR-REGIME recipe, workloads/synth.py LIN_GAMMA -> tests/golden/lin_<tag>.npz + ref16_lin_<tag>.npz)
         cond_gap_golden(sys.argv[2], [int(a) for a in sys.argv[3:]], variant="lin", min_dets=16)
         sys.exit(0)

@@ -262,7 +262,7 @@ def test_converter_reproduces_the_reference_conversion_of_an_upstream_checkpoint
     assert not missing and not unexpected
 
 
-@pytest.mark.parametrize("tag", ["n", "s", "m", "l", "n6"])
+@pytest.mark.parametrize("tag", ["n", "s", "m", "l", "n6", "s_r40", "s_r31"])   # (s_r40 / s_r31, round 5: upstream-format checkpoints of the legacy releases -- Focus, SPP in the backbone, BottleneckCSP)
 def test_converter_against_the_live_reference_every_size(tag, tmp_path):
     """build container only: the checkpoint of each size is rebuilt with the reference's vendored upstream classes (same seeds as the committed record), converted by
     the UNMODIFIED reference and by this repo, and the two state_dicts are compared tensor by tensor -- and with the committed hashes (s / m / l / n6 files are 7-94 MB
@@ -281,7 +281,8 @@ def test_converter_against_the_live_reference_every_size(tag, tmp_path):
     from yolort_amd.models._checkpoint import load_from_ultralytics
     path = str(tmp_path / f"yolov5{tag}.pt")
     mk.build_upstream_checkpoint(tag, path)
-    ref, mine = ref_load(path), load_from_ultralytics(path)
+    version = mk.VERSION.get(tag, "r6.0")
+    ref, mine = ref_load(path, version=version), load_from_ultralytics(path, version=version)
     a, b = ref["state_dict"], mine["state_dict"]
     assert list(a.keys()) == list(b.keys())
     for k in a:
@@ -289,3 +290,8 @@ def test_converter_against_the_live_reference_every_size(tag, tmp_path):
     with open(os.path.join(GOLD, "ckpt_golden.json")) as f:
         rec = json.load(f)["archs"][tag]
     _assert_equals_reference_record(mine, rec)
+    if version != "r6.0":   # ... and the converted weights load into the model of that release (YOLO.load_from_yolov5, reference yolo.py:186-223)
+        from yolort_amd.models import yolo
+        model = yolo.YOLO.load_from_yolov5(path, version=version)
+        assert type(model.backbone.body["0"]).__name__ == "Focus" and len(model.state_dict()) == len(b)
+        assert all(torch.equal(model.state_dict()[k].half(), b[k]) for k in b if b[k].is_floating_point())

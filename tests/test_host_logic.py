@@ -84,6 +84,45 @@ def test_api_surface_and_kwargs():
     assert (d.score_thresh, d.nms_thresh, d.detections_per_img) == (0.005, 0.45, 300)
 
 
+@pytest.mark.parametrize("version", ["r4.0", "r3.1"])
+def test_legacy_release_models_mirror_the_reference(version):
+    """round 5: the r3.1 / r4.0 releases -- Focus stem, BottleneckCSP (r3.1) / C3 (r4.0) blocks, the neck that opens with a block.  Same state_dict keys and
+    shapes as the reference's models (live comparison when /root/reference is importable; the counts are pinned either way), the reference's activation modules, and the
+    Focus stem's 6 x 6 stride-2 form equal to Conv(12, c, 3) over `focus_transform`."""
+    import torch.nn.functional as F
+    import yolort_amd.models as M
+    from yolort_amd.models import yolo
+    from yolort_amd.v5 import Focus, focus_transform, space_to_depth
+    tag = version.replace(".", "").replace("r", "r")
+    counts = {"r4.0": {"s": 360, "m": 504, "l": 648}, "r3.1": {"s": 368, "m": 512, "l": 656}}[version]
+    for size in ("s", "m", "l"):
+        mine = yolo.__dict__[f"yolov5_darknet_pan_{size}_{tag}"]().state_dict()
+        assert len(mine) == counts[size], (size, len(mine))
+        try:
+            from oracle.reference_loader import load_reference, reference_available
+        except ImportError:
+            continue
+        if reference_available():
+            ref = load_reference().models.yolo.__dict__[f"yolov5_darknet_pan_{size}_{tag}"]().state_dict()
+            assert list(ref) == list(mine), size                                               # same keys in the same order
+            assert all(tuple(ref[k].shape) == tuple(mine[k].shape) and ref[k].dtype == mine[k].dtype for k in ref), size
+    m = M.yolov5s(upstream_version=version, score_thresh=0.3)
+    body = m.model.backbone.body
+    assert isinstance(body["0"], Focus) and type(body["2"]).__name__ == ("C3" if version == "r4.0" else "BottleneckCSP")
+    assert type(body["1"].act).__name__ == ("SiLU" if version == "r4.0" else "Hardswish")
+    assert type(m.model.backbone.pan.inner_blocks[0]).__name__ == type(body["2"]).__name__        # reference path_aggregation_network.py:111-112
+    # Focus == Conv(3, c, 6, 2, 2) with the rearranged weights (v5/models/common.py Focus.stem_weight)
+    torch.manual_seed(0)
+    f = Focus(3, 8, k=3, version=version).double()
+    x = torch.rand(2, 3, 12, 20, dtype=torch.float64)
+    assert torch.equal(focus_transform(x), space_to_depth(x))                                     # reference test/test_models_common.py:6-11
+    a = F.conv2d(focus_transform(x), f.conv.conv.weight, None, 1, 1)
+    b = F.conv2d(x, f.stem_weight(), None, 2, 2)
+    assert a.shape == b.shape and (a - b).abs().max().item() < 1e-12
+    with pytest.raises(NotImplementedError):
+        yolo.yolov5_darknet_tan_s_r40()
+
+
 def test_no_cpu_fallback_anywhere():
     from yolort_amd._lib import YmiError
     from yolort_amd.models import yolov5n

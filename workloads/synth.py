@@ -53,7 +53,7 @@ def synth_state_dict(
             v = np.zeros(shape, np.int64)
             out[key] = torch.from_numpy(v)
             continue
-        if key.endswith(".conv.weight"):
+        if key.endswith(".conv.weight") or (len(shape) == 4 and key.endswith(".weight") and ".head." not in key):   # (the second form: BottleneckCSP's bare cv2 / cv3 of the r3.1 models)
             fan_in = shape[1] * shape[2] * shape[3]
             v = _fp16_round(rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in))
         elif key.endswith(".bn.weight"):
@@ -120,7 +120,8 @@ COND_GAMMA = (0.3, 0.6)
 COND_HEAD_GAIN = 1.0
 
 
-COND_SIZE = {"yolov5_darknet_pan_n_r60": 640, "yolov5_darknet_pan_s_r60": 640, "yolov5_darknet_pan_m_r60": 1280, "yolov5_darknet_pan_l6_r60": 1280}
+COND_SIZE = {"yolov5_darknet_pan_n_r60": 640, "yolov5_darknet_pan_s_r60": 640, "yolov5_darknet_pan_m_r60": 1280, "yolov5_darknet_pan_l6_r60": 1280,
+             "yolov5_darknet_pan_s_r40": 640, "yolov5_darknet_pan_s_r31": 640}   # (round 5: the legacy releases, Focus stem; r3.1: BottleneckCSP / Hardswish / LeakyReLU)
 
 
 def cond_images(arch: str, seed: int = 0):

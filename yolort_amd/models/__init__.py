@@ -10,10 +10,12 @@ __all__ = ["YOLO", "YOLOv5", "yolov5n", "yolov5n6", "yolov5s", "yolov5s6", "yolo
 def _make(arch_r60: str, upstream_version: str, export_friendly: bool, only_r60: bool, **kwargs: Any) -> YOLOv5:
     if upstream_version == "r6.0":
         model = YOLOv5(arch=arch_r60, **kwargs)
-    elif upstream_version in ("r3.1", "r4.0") and not only_r60:
-        raise NotImplementedError(f"upstream_version {upstream_version}: legacy architectures are out of the MI355X hot-path scope (use 'r6.0')")
-    else:
+    elif upstream_version in ("r3.1", "r4.0") and not only_r60:   # reference models/__init__.py:51-54 (yolov5s / m / l)
+        model = YOLOv5(arch=arch_r60.replace("_r60", "_r31" if upstream_version == "r3.1" else "_r40"), **kwargs)
+    elif only_r60:
         raise NotImplementedError("Currently only supports r6.0 version")
+    else:
+        raise NotImplementedError("Currently doesn't support this versions.")
     if export_friendly:
         raise NotImplementedError("export_friendly targets the ONNX/TVM exporters, which this MI355X-native build drops")
     return model

@@ -1,4 +1,4 @@
-"""Ingest of ultralytics/yolov5 r6.0 checkpoints (reference yolort/models/_checkpoint.py:16-94).
+"""Ingest of ultralytics/yolov5 checkpoints (r3.1 / r4.0 / r6.0) (reference yolort/models/_checkpoint.py:16-94).
 
 An upstream ``*.pt`` is a pickle of ``{"model": <models.yolo.Model nn.Module>, ...}``.  The reference
 unpickles it with its vendored copy of the upstream classes (yolort/v5, yolort/v5/helper.py:49-82).
@@ -113,8 +113,7 @@ def _index_maps(use_p6: bool):
 def load_from_ultralytics(checkpoint_path: str, version: str = "r6.0") -> Dict[str, Any]:
     if version not in ["r3.1", "r4.0", "r6.0"]:
         raise NotImplementedError(f"Currently does not support version: {version}.")
-    if version != "r6.0":
-        raise NotImplementedError("only r6.0 checkpoints are on the MI355X hot path (legacy Focus-stem models are out of scope)")
+    # (the layer-index maps below are the same for every release: upstream's r3.1 / r4.0 / r6.0 P5 yamls all place the neck's first block at index 9 and Detect at 24)
     ckpt = torch.load(checkpoint_path, map_location="cpu", pickle_module=_StubPickle, weights_only=False)
     model = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
     if isinstance(ckpt, dict) and ckpt.get("ema") is not None and not isinstance(ckpt.get("ema"), (int, float)):

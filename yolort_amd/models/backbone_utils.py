@@ -10,7 +10,7 @@ from torch import nn
 
 from ..engine import Plan, View
 from ..hipmodule import HipModule
-from . import darknetv6 as darknet
+from . import darknetv4, darknetv6
 from .path_aggregation_network import PathAggregationNetwork
 
 
@@ -55,7 +55,7 @@ class BackboneWithPAN(HipModule):
             step = nf - 2 - int(ti)  # top-down step that concatenates this tap (reference pan :224)
             if step >= 0:
                 c_up = self.pan.td_slot_channels(step)
-                c_tap = layer.cv3.conv.out_channels
+                c_tap = layer.out_channels
                 cat = plan.alloc(x.n, x.h, x.w, c_up + c_tap)
                 td_cat[step] = cat
                 x = layer.emit(plan, x, out=cat.slice_c(c_up, c_tap), name=f"{name}.body.{lname}")
@@ -69,10 +69,9 @@ def darknet_pan_backbone(backbone_name: str, depth_multiple: float, width_multip
                          returned_layers: Optional[List[int]] = None, version: str = "r6.0", use_p6: bool = False):
     """Same signature as the reference (:60-122)."""
     assert version in ["r3.1", "r4.0", "r6.0"], "Currently only supports version 'r3.1', 'r4.0' and 'r6.0'."
-    if version != "r6.0":
-        raise NotImplementedError("only the r6.0 architectures are on the MI355X hot path (legacy r3.1/r4.0 Focus-stem models are out of scope)")
     last_channel = 768 if use_p6 else 1024
-    backbone = darknet.__dict__[backbone_name](pretrained=pretrained, last_channel=last_channel).features
+    factories = {**darknetv4.__dict__, **darknetv6.__dict__}   # the reference's `darknet` namespace (darknet.py re-exports both)
+    backbone = factories[backbone_name](pretrained=pretrained, last_channel=last_channel).features
     if returned_layers is None:
         returned_layers = [4, 6, 8]
     return_layers = {str(k): str(i) for i, k in enumerate(returned_layers)}

@@ -1,6 +1,7 @@
-"""PAN neck (reference yolort/models/path_aggregation_network.py:10-245), r6.0 form.
+"""PAN neck (reference yolort/models/path_aggregation_network.py:10-245): r6.0 (SPP first, C3 blocks), r4.0 (C3 first, C3 blocks) and r3.1 (BottleneckCSP throughout,
+Hardswish convolutions).
 
-Top-down: SPP / C3 -> 1x1 Conv -> nearest x2 upsample -> concat with the backbone tap -> C3;
+Top-down: SPP / block -> 1x1 Conv -> nearest x2 upsample -> concat with the backbone tap -> C3;
 bottom-up: 3x3 s2 Conv -> concat with the matching top-down tensor -> C3; optional P6 level.
 Every concat of the reference (:224, :235) is a pre-allocated buffer whose halves are written in
 place by their producers (1x1 conv epilogue, upsample kernel, backbone tap, 3x3 s2 conv).
@@ -13,7 +14,9 @@ from torch import nn
 
 from ..engine import Plan, View
 from ..hipmodule import HipModule
-from ..v5 import C3, SPP, Conv
+from ..v5 import C3, SPP, BottleneckCSP, Conv
+
+_block = {"r3.1": BottleneckCSP, "r4.0": C3}   # reference :242-245
 
 
 class IntermediateLevelP6(HipModule):
@@ -22,7 +25,7 @@ class IntermediateLevelP6(HipModule):
     def __init__(self, depth_multiple: float, in_channel: int, out_channel: int, version: str = "r4.0"):
         super().__init__()
         n = max(round(3 * depth_multiple), 1)
-        self.p6 = nn.Sequential(Conv(in_channel, out_channel, k=3, s=2, version=version), C3(out_channel, out_channel, n=n))
+        self.p6 = nn.Sequential(Conv(in_channel, out_channel, k=3, s=2, version=version), _block[version](out_channel, out_channel, n=n))
 
     def emit(self, plan: Plan, x, out=None, name: str = "p6"):
         feats = list(x) if isinstance(x, (list, tuple)) else [x]
@@ -35,19 +38,20 @@ class PathAggregationNetwork(HipModule):
     def __init__(self, in_channels: List[int], depth_multiple: float, version: str = "r4.0",
                  block: Optional[Callable[..., nn.Module]] = None, use_p6: bool = False):
         super().__init__()
-        if version != "r6.0":
-            raise NotImplementedError(f"Version {version} is not implemented yet (only the r6.0 neck is on the hot path).")
-        mv = "r4.0"  # module_version of the reference (:87)
+        if version not in ("r3.1", "r4.0", "r6.0"):
+            raise NotImplementedError(f"Version {version} is not implemented yet.")
+        mv = "r4.0" if version == "r6.0" else version  # module_version of the reference (:87)
         if use_p6:
             assert len(in_channels) == 4, "Length of in channels should be 4."
             self.intermediate_blocks = IntermediateLevelP6(depth_multiple, in_channels[2], in_channels[3], version=mv)
         else:
             assert len(in_channels) == 3, "Length of in channels should be 3."
             self.intermediate_blocks = None
-        block = block or C3
+        block = block or _block[mv]
         n = max(round(3 * depth_multiple), 1)
         c = in_channels
-        inner: List[nn.Module] = [SPP(c[-1], c[-1], k=(5, 9, 13))]
+        # reference :109-114: the r6.0 neck opens with the SPP (its backbone ends in a C3), the older ones with a block (their backbones end in the SPP)
+        inner: List[nn.Module] = [SPP(c[-1], c[-1], k=(5, 9, 13))] if version == "r6.0" else [block(c[-1], c[-1], n=n, shortcut=False)]
         if use_p6:
             inner += [Conv(c[-1], c[2], 1, 1, version=mv), nn.Upsample(scale_factor=2), block(c[1] + c[-1], c[2], n=n, shortcut=False)]
         inner += [Conv(c[2], c[1], 1, 1, version=mv), nn.Upsample(scale_factor=2), block(c[-1], c[1], n=n, shortcut=False),

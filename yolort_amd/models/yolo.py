@@ -541,17 +541,24 @@ yolov5_darknet_pan_l6_r60 = _r60("l", 1.0, 1.0, True)
 yolov5_darknet_pan_x6_r60 = _r60("x", 1.33, 1.25, True)
 
 
-def _legacy(name: str):
-    def factory(*args: Any, **kwargs: Any):
-        raise NotImplementedError(f"{name}: legacy r3.1/r4.0 (Focus stem / BottleneckCSP / TAN) architectures are out of the MI355X hot-path scope")
+def _legacy(size: str, depth: float, width: float, version: str):
+    tag = version.replace(".", "").replace("r", "r")   # "r31" / "r40"
 
+    def factory(pretrained: bool = False, progress: bool = True, num_classes: int = 80, **kwargs: Any) -> YOLO:
+        return build_model(f"darknet_{size}_{version.replace('.', '_')}", depth, width, version, f"yolov5_darknet_pan_{size}_{tag}_coco", pretrained=pretrained,
+                           progress=progress, num_classes=num_classes, **kwargs)
+
+    factory.__doc__ = f"yolov5{size} release {version[1:]} (Focus stem, {'BottleneckCSP / Hardswish' if version == 'r3.1' else 'C3 / SiLU'}; depth {depth}, width {width}); reference yolo.py:292-469"
     return factory
 
 
-yolov5_darknet_pan_s_r31 = _legacy("yolov5_darknet_pan_s_r31")
-yolov5_darknet_pan_m_r31 = _legacy("yolov5_darknet_pan_m_r31")
-yolov5_darknet_pan_l_r31 = _legacy("yolov5_darknet_pan_l_r31")
-yolov5_darknet_pan_s_r40 = _legacy("yolov5_darknet_pan_s_r40")
-yolov5_darknet_pan_m_r40 = _legacy("yolov5_darknet_pan_m_r40")
-yolov5_darknet_pan_l_r40 = _legacy("yolov5_darknet_pan_l_r40")
-yolov5_darknet_tan_s_r40 = _legacy("yolov5_darknet_tan_s_r40")
+yolov5_darknet_pan_s_r31 = _legacy("s", 0.33, 0.5, "r3.1")
+yolov5_darknet_pan_m_r31 = _legacy("m", 0.67, 0.75, "r3.1")
+yolov5_darknet_pan_l_r31 = _legacy("l", 1.0, 1.0, "r3.1")
+yolov5_darknet_pan_s_r40 = _legacy("s", 0.33, 0.5, "r4.0")
+yolov5_darknet_pan_m_r40 = _legacy("m", 0.67, 0.75, "r4.0")
+yolov5_darknet_pan_l_r40 = _legacy("l", 1.0, 1.0, "r4.0")
+
+
+def yolov5_darknet_tan_s_r40(*args: Any, **kwargs: Any):
+    raise NotImplementedError("yolov5_darknet_tan_s_r40: the transformer neck (C3TR, reference yolo.py:837-867) is out of the MI355X hot-path scope")

@@ -280,7 +280,7 @@ def space_to_depth(x):
 class Focus(HipModule):
     """Conv(4 c1, c2, k) over the space-to-depth rearrangement of the image (reference :210-234), the stem of the r3.1 / r4.0 models.
     The rearrangement is never materialised: slot (dy, dx) of `focus_transform` holds pixel (2Y + dy, 2X + dx), so a k x k convolution with 'same' padding over the 12
-    half-resolution channels IS a 2k x 2k stride-2 convolution with padding k - 1 + ... over the image -- for the reference's k = 3: Conv(3, c2, 6, 2, 2) with
+    half-resolution channels IS a 2k x 2k stride-2 convolution over the image -- for the reference's k = 3: Conv(3, c2, 6, 2, 2) with
     W6[o, c, 2 ky + dy, 2 kx + dx] = W3[o, 3 slot(dy, dx) + c, ky, kx], slot = (0,0) (1,0) (0,1) (1,1) -> 0 1 2 3 (ultralytics/yolov5#4825, the equivalence the r6.0 stem was
     introduced with).  Same products, same zero padding, another summation order: the stem kernels (super-pixel form, planar-image form, fused stem + body.1) run unchanged."""
 
