@@ -43,9 +43,8 @@ extern "C" {
 /* activation after conv */
 #define YMI_ACT_NONE 0
 #define YMI_ACT_SILU 1
-/* the activations of the legacy r3.1 blocks (common.py:64-65 `Conv(version="r3.1")`: Hardswish; common.py:140 `BottleneckCSP.act`: LeakyReLU(0.1)): carried by the general
- * epilogues of the implicit-GEMM / LDS-halo families and by the fp32 mode; the kernels with a SiLU-only epilogue (streaming 1x1, resident-weights 3x3, fused C3 / stem,
- * chained convs) refuse them */
+/* the activations of the legacy r3.1 blocks (common.py:64-65 `Conv(version="r3.1")`: Hardswish; common.py:140 `BottleneckCSP.act`: LeakyReLU(0.1)): NOT carried by the
+ * convolution epilogues (ymi_conv2d refuses them) -- such a convolution runs with YMI_ACT_NONE and ymi_act rewrites its output in place */
 #define YMI_ACT_HARDSWISH 2
 #define YMI_ACT_LEAKY 3
 
@@ -191,6 +190,10 @@ int ymi_spp_pool(void* buf, int n, int h, int w, int c, int cstride, int dtype, 
  * yolort/models/path_aggregation_network.py:123,131,134 -- written straight into its concat slot. */
 int ymi_upsample2x(const void* x, int x_cstride, int n, int h, int w, int c, void* y, int y_cstride,
                    int dtype, void* stream);
+/* y <- act(y) (+ res) in place over the view (npix, c): the legacy r3.1 activations YMI_ACT_HARDSWISH (common.py:64-65) / YMI_ACT_LEAKY (LeakyReLU(0.1), common.py:140)
+ * after a convolution run with YMI_ACT_NONE; `res`: the Bottleneck shortcut, added after the activation (common.py:115-116).  c and the strides in multiples of one
+ * 16-byte packet (8 halves / 4 floats). */
+int ymi_act(void* y, int y_cstride, int npix, int c, int dtype, int act, const void* res, int res_cstride, void* stream);
 /* strided channel-slice copy (only used where a producer cannot write into its concat slot) */
 int ymi_copy_view(const void* x, int x_cstride, int npix, int c, void* y, int y_cstride, int dtype,
                   void* stream);
@@ -325,6 +328,7 @@ int ymi_plan_add_upsample2x(ymi_plan* p, const void* x, int x_cstride, int n, in
                             int y_cstride, int dtype);
 int ymi_plan_add_copy_view(ymi_plan* p, const void* x, int x_cstride, int npix, int c, void* y,
                            int y_cstride, int dtype);
+int ymi_plan_add_act(ymi_plan* p, void* y, int y_cstride, int npix, int c, int dtype, int act, const void* res, int res_cstride);
 int ymi_plan_add_postprocess(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_add_post_begin(ymi_plan* p, const ymi_post_desc* d);
 int ymi_plan_add_head_decode(ymi_plan* p, const ymi_conv_desc* conv, const ymi_post_desc* d, int level);

@@ -75,6 +75,7 @@ def sim():
     lib.sim_conv_head_decode_group.argtypes, lib.sim_conv_head_decode_group.restype = [C.POINTER(ConvDesc), C.c_int, C.POINTER(PostDesc)], C.c_int
     lib.ymi_batched_nms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ymi_copy_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ymi_act.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ymi_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.ymi_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ymi_spp_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -1297,84 +1298,31 @@ def test_fp32_pipelined_kernel_split_shortcut_upsample(sim, tile):
 
 
 @pytest.mark.parametrize("act_name", ["hardswish", "leaky"])
-@pytest.mark.parametrize("tile,k,s_,cin,cout,residual", [(21, 1, 1, 64, 128, False), (12, 3, 1, 32, 64, True), (61, 3, 2, 64, 128, False), (111, 1, 1, 128, 128, False), (93, 3, 1, 64, 64, True),
-                                                         (142, 1, 1, 64, 128, False)])
-def test_legacy_activations_in_the_general_epilogues(sim, act_name, tile, k, s_, cin, cout, residual):
-    """Hardswish (reference common.py:64-65, `Conv(version="r3.1")`) and LeakyReLU(0.1) (common.py:140, `BottleneckCSP.act`) ride in the GENERAL epilogue of every 16-bit
-    kernel family (4- / 8-wave implicit GEMM, LDS halo, row-transposed stores, the register-staged kernel): against torch on the same rounded operands"""
-    from yolort_amd import engine
-    from yolort_amd._lib import ACT_HARDSWISH, ACT_LEAKY
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("residual", [False, True])
+def test_legacy_activation_kernel(sim, act_name, dtype, residual):
+    """csrc/preproc_pool.hip act_kernel / ymi_act: Hardswish (reference common.py:64-65, `Conv(version="r3.1")`) and LeakyReLU(0.1) (common.py:140, `BottleneckCSP.act`) as
+    the launch that follows an r3.1 convolution run with YMI_ACT_NONE -- in place, over a channel-slice view, the Bottleneck shortcut added AFTER the activation
+    (common.py:115-116).  fp32: bit for bit torch's own functions (same order of operations); 16-bit: torch's result on the same stored values, rounded once."""
+    from yolort_amd._lib import ACT_HARDSWISH, ACT_LEAKY, dtype_code
     act, fn = (ACT_HARDSWISH, F.hardswish) if act_name == "hardswish" else (ACT_LEAKY, lambda t: F.leaky_relu(t, 0.1))
-    dtype = torch.float16
-    g = torch.Generator().manual_seed(tile * 7 + k)
-    n, h, w, p = 2, 14, 20, k // 2
-    x = (torch.randn(n, cin, h, w, generator=g) * 2.0).to(dtype).float()   # (x 2: both clamps of the Hardswish are exercised)
-    wt = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).to(dtype).float()
-    bias = torch.randn(cout, generator=g) * 0.5
-    ref = fn(F.conv2d(x, wt, bias, s_, p))
-    ho, wo = ref.shape[2], ref.shape[3]
-    pc = engine.PackedConv(wt, bias, None, dtype, torch.device("cpu"), cin_pad=(cin + 7) // 8 * 8)
-    xb = Buf(n, h, w, pc.cin, dtype)
-    xb.view()[..., :cin] = x.permute(0, 2, 3, 1).to(dtype)
-    yb = Buf(n, ho, wo, cout, dtype)
-    rb = None
+    g = torch.Generator().manual_seed(3)
+    n, h, w, c, cs, off = 2, 7, 9, 24, 48, 16          # a 24-channel slice at offset 16 of a 48-channel buffer
+    buf = (torch.randn(n, h, w, cs, generator=g) * 3.0).to(dtype)
+    before = buf.clone()
+    res = (torch.randn(n, h, w, 32, generator=g)).to(dtype) if residual else None
+    es = buf.element_size()
+    _check(sim, sim.ymi_act(buf.data_ptr() + off * es, cs, n * h * w, c, dtype_code(dtype), act, None if res is None else res.data_ptr() + 8 * es, 32, None))
+    want = fn(before[..., off:off + c].float())
     if residual:
-        r = torch.randn(n, cout, ho, wo, generator=g).to(dtype).float()
-        ref = ref + r
-        rb = Buf(n, ho, wo, cout, dtype, fill=r.permute(0, 2, 3, 1))
-    d = _conv_desc(xb, pc, yb, tile, k=k, pad=p, res=rb, stride=s_)
-    d.act = act
-    if tile < 0:
-        d.zeros = None
-    if k > 1:
-        kt = pc.ktab(w, xb.cs)
-        d.ktab = kt.data_ptr()
-    _check(sim, sim.sim_conv2d(C.byref(d)))
-    got = yb.view().float().permute(0, 3, 1, 2)
-    assert (got - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
-    assert float((ref < 0).float().mean()) > 0.05   # the negative branch is populated
-
-
-@pytest.mark.parametrize("act_name", ["hardswish", "leaky"])
-@pytest.mark.parametrize("tile", [202, 206, -100])
-def test_legacy_activations_fp32_mode_are_exact(sim, act_name, tile):
-    """fp32 mode: torch's own order of operations ((x * clamp(x + 3, 0, 6)) / 6 with a true division; x > 0 ? x : 0.1 x) -- to rounding-order accuracy of the convolution itself"""
-    from yolort_amd import engine
-    from yolort_amd._lib import ACT_HARDSWISH, ACT_LEAKY
-    act, fn = (ACT_HARDSWISH, F.hardswish) if act_name == "hardswish" else (ACT_LEAKY, lambda t: F.leaky_relu(t, 0.1))
-    g = torch.Generator().manual_seed(5)
-    n, h, w, cin, cout = 2, 9, 12, 32, 48
-    x = torch.randn(n, cin, h, w, generator=g) * 2.0
-    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
-    bias = torch.randn(cout, generator=g) * 0.5
-    z = F.conv2d(x, wt, bias, 1, 1)
-    ref = fn(z)
-    pc = engine.PackedConv(wt, bias, None, torch.float32, torch.device("cpu"), cin_pad=cin)
-    numel = n * h * w * cin
-    xt = torch.zeros(numel + 64)
-    xt[:numel].view(n, h, w, cin)[...] = x.permute(0, 2, 3, 1)
-    yb = torch.zeros(n, h, w, cout)
-    d = _f32_desc((xt, n, h, w, cin, numel), pc, yb, tile, 3, 1, 1, act=act)
-    _check(sim, sim.sim_conv2d(C.byref(d)))
-    got = yb.permute(0, 3, 1, 2)
-    assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
-    # ... and the activation itself bit for bit: applied in torch to THIS kernel's pre-activation it reproduces the kernel's output wherever the inverse is unambiguous
-    yb0 = torch.zeros(n, h, w, cout)
-    from yolort_amd._lib import ACT_NONE
-    d0 = _f32_desc((xt, n, h, w, cin, numel), pc, yb0, tile, 3, 1, 1, act=ACT_NONE)
-    _check(sim, sim.sim_conv2d(C.byref(d0)))
-    assert torch.equal(fn(yb0), yb)
-
-
-def test_the_streaming_1x1_kernel_refuses_the_legacy_activations(sim):
-    from yolort_amd import engine
-    from yolort_amd._lib import ACT_HARDSWISH
-    dtype = torch.float16
-    pc = engine.PackedConv(torch.randn(64, 64, 1, 1) / 8, torch.zeros(64), None, dtype, torch.device("cpu"))
-    xb, yb = Buf(1, 8, 8, 64, dtype), Buf(1, 8, 8, 64, dtype)
-    d = _conv_desc(xb, pc, yb, 121)
-    d.act = ACT_HARDSWISH
-    assert sim.sim_conv2d(C.byref(d)) != 0 and b"SiLU / identity only" in sim.sim_last_error()
+        want = want + res[..., 8:8 + c].float()
+    got = buf[..., off:off + c]
+    if dtype == torch.float32:
+        assert torch.equal(got, want)
+    else:
+        assert torch.equal(got, want.to(dtype))
+    assert torch.equal(buf[..., :off], before[..., :off]) and torch.equal(buf[..., off + c:], before[..., off + c:])   # nothing outside the slice is touched
+    assert float((before[..., off:off + c].float() < -3).float().mean()) > 0.05 and float((before[..., off:off + c].float() > 3).float().mean()) > 0.05   # both clamps of the Hardswish are exercised
 
 
 def test_layout_edges_and_view_copy(sim):

@@ -92,6 +92,9 @@ class _SimLib:
     def ymi_postprocess_ws_bytes(self, *a):
         return self.sim.ymi_postprocess_ws_bytes(*a)
 
+    def ymi_plan_add_act(self, h, y, ycs, npix, c, dt, act, res, rcs):
+        return self._done(self.sim.ymi_act(y, ycs, npix, c, dt, act, res, rcs, None), "ymi_act")
+
     def ymi_plan_add_copy_view(self, h, x, xcs, npix, c, y, ycs, dt):
         return self._done(self.sim.ymi_copy_view(x, xcs, npix, c, y, ycs, dt, None), "ymi_copy_view")
 

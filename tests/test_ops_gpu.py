@@ -234,6 +234,52 @@ def test_conv_views_and_residual(dev):
     _run_conv(dev, torch.float16, n=2, cin=64, cout=32, h=20, w=20, k=1, s=1, p=0, x_cs_extra=32, y_cs_extra=32)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("act_name,residual", [("hardswish", False), ("hardswish", True), ("leaky", False)])
+def test_legacy_activation_layer(dev, dtype, act_name, residual):
+    """an r3.1 layer = convolution with YMI_ACT_NONE + the activation launch (ymi_act; csrc/preproc_pool.hip): Plan.conv(act=ACT_HARDSWISH / ACT_LEAKY) records both.
+    Against torch on the same rounded operands: Hardswish (reference common.py:64-65), LeakyReLU(0.1) (:140), the Bottleneck shortcut added after the activation (:115-116).
+    A conv descriptor that names such an activation is refused with a message that points at ymi_act (never a silently linear layer)."""
+    import ctypes as C
+
+    from yolort_amd import _lib, engine
+    from yolort_amd._lib import ACT_HARDSWISH, ACT_LEAKY
+    act, fn = (ACT_HARDSWISH, F.hardswish) if act_name == "hardswish" else (ACT_LEAKY, lambda t: F.leaky_relu(t, 0.1))
+    g = torch.Generator().manual_seed(9)
+    n, cin, cout, h, w = 2, 64, 96, 20, 24
+    x = (torch.randn(n, cin, h, w, generator=g) * 2.0).to(dtype).float()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)).to(dtype).float()
+    bias = torch.randn(cout, generator=g) * 0.5
+    pre = F.conv2d(x, wt, bias, 1, 1)
+    ref = fn(pre.to(dtype).float())          # the pre-activation is stored in the compute dtype between the two launches
+    plan = engine.Plan(dev, dtype) if dtype != torch.float32 else engine.Plan(dev, torch.float32)
+    xv = plan.alloc(n, h, w, cin, zero=True)
+    xv.as_tensor().copy_(_nhwc(x).to(dev, dtype))
+    pc = engine.PackedConv(wt, bias, None, dtype, dev)
+    cat = plan.alloc(n, h, w, cout + 32, zero=True)
+    yv = cat.slice_c(16, cout)               # a channel slice: the neighbours must stay untouched
+    rv = None
+    if residual:
+        r = torch.randn(n, cout, h, w, generator=g).to(dtype).float()
+        ref = ref + r
+        rv = plan.alloc(n, h, w, cout)
+        rv.as_tensor().copy_(_nhwc(r).to(dev, dtype))
+    n0 = plan.num_ops
+    plan.conv(xv, pc, 1, 1, act=act, out=yv, res=rv)
+    assert plan.num_ops == n0 + 2 and plan.meta[-1]["kind"] == "act" and plan.io[n0]["post_act"]["act"] == act
+    plan.run()
+    torch.cuda.synchronize()
+    got = yv.as_tensor().float().cpu().permute(0, 3, 1, 2)
+    tol = 2e-3 if dtype == torch.float16 else (1.6e-2 if dtype == torch.bfloat16 else 4e-6)
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    full = cat.as_tensor().float().cpu()
+    assert full[..., :16].abs().max().item() == 0 and full[..., 16 + cout:].abs().max().item() == 0
+    d = plan.conv_descs[n0]
+    d.act = act
+    lib = _lib.load(require_gpu=True)
+    assert lib.ymi_conv2d(C.byref(d), _lib.stream_ptr()) != 0 and b"ymi_act" in lib.ymi_last_error()
+
+
 def test_conv_second_output(dev):
     """one launch, two destinations: couts [0,32) -> y, [32,64) -> channel slice of another buffer (C3 cv1+cv2)"""
     from yolort_amd import engine

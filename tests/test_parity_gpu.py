@@ -149,7 +149,8 @@ def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size
         with torch.no_grad():
             batch, _ = O.letterbox(imgs_cpu, size, size, kw.get("size_divisible", 32))
             assert tuple(batch.shape[-2:]) == (e.x.h, e.x.w)
-            O.yolo_forward(batch[:n_oracle], sdf, 0.25, p="model.")
+            feats = O.backbone(batch[:n_oracle].to(torch.float32), sdf, "model.backbone")   # the conv stack and the head only (the layer inputs are what is needed):
+            O.head(feats, sdf, "model.head")                                                  # the CPU post-process of a hot synthetic network takes minutes (O(n^2) NMS)
     finally:
         O.TRACE.hook = None
     known = set(inputs)
@@ -183,10 +184,12 @@ def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size
         xq = inputs[p0].float()
         _fill_rep(io["x"], xq, dtype)
         res_q = None
-        if io["res"] is not None:         # Bottleneck shortcut: the block's input = input of its cv1
+        post_act = io.get("post_act")     # r3.1 layers: the convolution with YMI_ACT_NONE + the activation launch (ymi_act, shortcut included) are ONE reference layer
+        res_view = io["res"] if post_act is None else post_act["res"]
+        if res_view is not None:          # Bottleneck shortcut: the block's input = input of its cv1
             res_q = inputs[p0.rsplit(".", 1)[0] + ".cv1"].float()
-            _fill_rep(io["res"], res_q, dtype)
-        plan.run(idx, idx + 1)
+            _fill_rep(res_view, res_q, dtype)
+        plan.run(idx, idx + (1 if post_act is None else 2))
         torch.cuda.synchronize()
         stride, pad = io["stride"][0], io["pad"][0]
         if parts[0].endswith("body.0"):   # stem: the plan runs its super-pixel form (6x3 s(2,1)); the layer is Conv(3,c,6,2,2)
@@ -224,6 +227,8 @@ def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size
     # the first layers as the benchmark runs them equal ops 0 (and 1) on the letterboxed batch bit for bit:
     #   fixed-size streams   straight from the planar images, the stem alone (ymi_conv_stem_planar) or stem + body.1 as one launch (ymi_stem_body1_planar)
     #   dynamic-shape ones   stem + body.1 as one launch from the canvas (ymi_plan_set_fuse_stem), when the plan offers it
+    if 1 not in plan.io or plan.io[0].get("post_act") is not None:   # r3.1: op 1 is the stem's Hardswish launch -- there is no fused stem + body.1 form to compare
+        return
     canvas_fused = plan.fuse_stem
     plan.set_fuse_stem(False)
     batch_q, _ = O.letterbox(imgs_cpu, size, size, kw.get("size_divisible", 32))

@@ -94,6 +94,8 @@ _SIGS = {
     "ymi_spp_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ymi_upsample2x": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ymi_copy_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ymi_act": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "ymi_plan_add_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "ymi_postprocess_ws_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "ymi_postprocess": (C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
     "ymi_post_begin": (C.c_int, [C.POINTER(PostDesc), C.c_void_p]),

@@ -60,7 +60,7 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s);
 int conv_head_decode_launch(const ymi_conv_desc* d, const ymi_post_desc* post, int level, hipStream_t s);
 int conv_head_decode_group_launch(const ymi_conv_desc* descs, int n_levels, const ymi_post_desc* post, hipStream_t s);
 
-enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_HEAD_GROUP, OP_POST_FINISH, OP_C3_FUSED };
+enum OpKind { OP_CONV, OP_SPP, OP_UP, OP_COPY, OP_POST, OP_POST_BEGIN, OP_HEAD_DECODE, OP_HEAD_GROUP, OP_POST_FINISH, OP_C3_FUSED, OP_ACT };
 
 struct Op {
     OpKind kind;
@@ -86,6 +86,7 @@ static int run_op(const Op& op, hipStream_t s) {
         case OP_HEAD_GROUP: return conv_head_decode_group_launch(op.convs, op.i[0], &op.post, s);
         case OP_POST_FINISH: return post_finish_launch(&op.post, s);
         case OP_C3_FUSED: return c3_fused_launch(&op.c3, s);
+        case OP_ACT: return ymi_act(op.y, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.x, op.i[5], s);
     }
     set_error("unknown op kind");
     return YMI_EINVAL;
@@ -215,6 +216,18 @@ extern "C" int ymi_plan_add_copy_view(ymi_plan* p, const void* x, int x_cstride,
     op.kind = OP_COPY;
     op.x = x; op.y = y;
     op.i[0] = x_cstride; op.i[1] = npix; op.i[2] = c; op.i[3] = y_cstride; op.i[4] = dtype;
+    p->ops.push_back(op);
+    drop_graph(p);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int ymi_plan_add_act(ymi_plan* p, void* y, int y_cstride, int npix, int c, int dtype, int act, const void* res, int res_cstride) {
+    YMI_REQUIRE(p && y, "ymi_plan_add_act: null argument");
+    Op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = OP_ACT;
+    op.x = res; op.y = y;
+    op.i[0] = y_cstride; op.i[1] = npix; op.i[2] = c; op.i[3] = dtype; op.i[4] = act; op.i[5] = res_cstride;
     p->ops.push_back(op);
     drop_graph(p);
     return (int)p->ops.size() - 1;

@@ -271,7 +271,6 @@ int conv1x1_stream_launch(const ConvArgs& a, int dtype, int out_dtype, int varia
     YMI_REQUIRE(a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.ph == 0 && a.pw == 0 && a.cin % 32 == 0 && a.cin <= 128 && a.k_pad == a.cin,
                 "ymi_conv2d: the streaming kernel handles 1x1 stride-1 convolutions with cin in {32, 64, 96, 128}");
     YMI_REQUIRE(out_dtype == dtype, "ymi_conv2d: the streaming 1x1 kernel stores the compute dtype");
-    YMI_REQUIRE(a.act == YMI_ACT_NONE || a.act == YMI_ACT_SILU, "ymi_conv2d: the streaming 1x1 kernel carries SiLU / identity only (activation %d: use a general tile)", a.act);
     YMI_REQUIRE(a.x_cs % 8 == 0 && a.up2 == 0, "ymi_conv2d: the streaming 1x1 kernel needs x_cstride %% 8 == 0 and has no upsampled second output");
     YMI_REQUIRE(variant >= 1 && variant <= 4, "ymi_conv2d: streaming 1x1 variant (cout tiles per wave) must be 1..4");
     const int bw = 32 * variant;

@@ -65,17 +65,6 @@ __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) {
 }
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
-// legacy r3.1 activations (general epilogues only): Hardswish x * relu6(x + 3) / 6, LeakyReLU(0.1).  `EXACT`: the fp32 mode's form -- torch's own order of operations
-// (x * min(max(x + 3, 0), 6)) / 6 with a true division; the 16-bit paths multiply by 1/6 (the result is rounded to 11 / 8 bits anyway)
-template <bool EXACT = false>
-__device__ __forceinline__ float act_legacy(float v, int act) {
-    if (act == YMI_ACT_HARDSWISH) {
-        const float c = fminf(fmaxf(v + 3.0f, 0.0f), 6.0f);
-        return EXACT ? (v * c) / 6.0f : v * c * 0.16666666666666666f;
-    }
-    if (act == YMI_ACT_LEAKY) return v > 0.0f ? v : v * 0.1f;
-    return v;
-}
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N-1
 template <int I, int N, class F>
@@ -163,7 +152,6 @@ __device__ __forceinline__ void finish_subtile(const ConvArgs& a, const f32x16& 
         for (int e = 0; e < 4; ++e) {
             float t = acc[g * 4 + e];
             if (a.act == YMI_ACT_SILU) t = silu(t);
-            else if (a.act > YMI_ACT_SILU) t = act_legacy(t, a.act);
             v[g][e] = t;
         }
         if constexpr (RES) {

@@ -134,7 +134,6 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float t = acc[j][g * 4 + e] + (co + e < a.cout_pad ? a.bias[co + e] : 0.f);
                 if (a.act == YMI_ACT_SILU) t = silu_exact(t);
-                else if (a.act > YMI_ACT_SILU) t = act_legacy<true>(t, a.act);
                 if (R != nullptr && co + e < a.cout) t += R[mo * a.res_cs + co + e];
                 v[e] = t;
             }

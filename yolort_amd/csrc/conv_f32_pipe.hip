@@ -299,7 +299,6 @@ __global__ __launch_bounds__(256, 2) void conv_f32_pipe_kernel(const ConvArgs a)
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][g * 4 + e] + bias_regs[i][g][e];
                     if (a.act == YMI_ACT_SILU) t = silu_exact_f32(t);
-                    else if (a.act > YMI_ACT_SILU) t = act_legacy<true>(t, a.act);
                     if (R != nullptr) t += rr[e];
                     v[e] = t;
                 }

@@ -147,7 +147,7 @@ int conv2d_launch(const ymi_conv_desc* d, hipStream_t s) {
     YMI_REQUIRE(d->k_pad >= d->kh * d->kw * d->cin, "ymi_conv2d: k_pad %d < K %d", d->k_pad, d->kh * d->kw * d->cin);
     YMI_REQUIRE(d->y_cstride % 4 == 0 && (d->res == nullptr || d->res_cstride % 4 == 0), "ymi_conv2d: y/res cstride must be multiples of 4");
     YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16 || d->dtype == YMI_F32, "ymi_conv2d: dtype must be F16, BF16 or F32 (parity mode)");
-    YMI_REQUIRE(d->act >= YMI_ACT_NONE && d->act <= YMI_ACT_LEAKY, "ymi_conv2d: unknown activation %d", d->act);
+    YMI_REQUIRE(d->act == YMI_ACT_NONE || d->act == YMI_ACT_SILU, "ymi_conv2d: the convolution epilogues carry SiLU / identity only (activation %d: run the convolution with YMI_ACT_NONE and ymi_act over its output)", d->act);
     YMI_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == YMI_F32, "ymi_conv2d: out_dtype must equal dtype or be F32");
     YMI_REQUIRE(d->ho == (d->h + 2 * d->ph - d->kh) / d->sh + 1 && d->wo == (d->w_in + 2 * d->pw - d->kw) / d->sw + 1,
                 "ymi_conv2d: output size %dx%d inconsistent with input %dx%d k%dx%d s%dx%d p%dx%d", d->ho, d->wo, d->h, d->w_in, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw);

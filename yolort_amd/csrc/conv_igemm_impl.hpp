@@ -163,7 +163,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][g * 4 + e] + b[e];
                     if (a.act == YMI_ACT_SILU) t = silu(t);
-                    else if (a.act > YMI_ACT_SILU) t = act_legacy(t, a.act);
                     v[e] = t;
                 }
                 if (a.res != nullptr) {

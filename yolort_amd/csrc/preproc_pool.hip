@@ -699,6 +699,58 @@ __global__ __launch_bounds__(256) void copy_view_kernel(const uint16_t* x, int x
     *reinterpret_cast<u32x4*>(y + pix * y_cs + cc) = *reinterpret_cast<const u32x4*>(x + pix * x_cs + cc);
 }
 
+// ---- activations of the legacy r3.1 blocks as a launch of their own (round 5) ------------------------------------------------------------------------------------
+// Hardswish (common.py:64-65, `Conv(version="r3.1")`) and LeakyReLU(0.1) (common.py:140, `BottleneckCSP.act`), with the Bottleneck's shortcut (common.py:115-116) added
+// AFTER the activation like the reference does.  The convolution epilogues carry SiLU / identity only: folding these two into the general epilogue of every conv kernel
+// moved the register allocation of kernels that sat at their limit (the 256-wide 8-wave implicit GEMM: 2-3 x slower on the r6.0 plans, profiles/r05k_*), so an r3.1
+// convolution runs with YMI_ACT_NONE and this kernel rewrites its output in place: one 16-byte packet (8 halves / 4 floats) per thread, HBM-bound.
+// fp32 mode: torch's own order of operations -- (x * min(max(x + 3, 0), 6)) / 6 with a true division; x > 0 ? x : 0.1 x -- on the exactly stored fp32 pre-activation.
+__device__ __forceinline__ float act_legacy_f32(float v, int act) {
+    if (act == YMI_ACT_HARDSWISH) return (v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f)) / 6.0f;
+    return v > 0.0f ? v : v * 0.1f;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void act_kernel(uint16_t* y, int y_cs, int64_t npix, int c, int act, const uint16_t* res, int res_cs) {
+    const int c8 = c / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix * c8) return;
+    const int cc = (int)(gid % c8) * 8;
+    const int64_t pix = gid / c8;
+    u32x4 v = *reinterpret_cast<const u32x4*>(y + pix * y_cs + cc);
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (res != nullptr) r = *reinterpret_cast<const u32x4*>(res + pix * res_cs + cc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float lo = from16<DT>((uint16_t)(v[q] & 0xffff)), hi = from16<DT>((uint16_t)(v[q] >> 16));
+        lo = act_legacy_f32(lo, act);
+        hi = act_legacy_f32(hi, act);
+        if (res != nullptr) {
+            lo += from16<DT>((uint16_t)(r[q] & 0xffff));
+            hi += from16<DT>((uint16_t)(r[q] >> 16));
+        }
+        v[q] = (uint32_t)to16<DT>(lo) | ((uint32_t)to16<DT>(hi) << 16);
+    }
+    *reinterpret_cast<u32x4*>(y + pix * y_cs + cc) = v;
+}
+
+__global__ __launch_bounds__(256) void act_f32_kernel(float* y, int y_cs, int64_t npix, int c, int act, const float* res, int res_cs) {
+    const int c4 = c / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix * c4) return;
+    const int cc = (int)(gid % c4) * 4;
+    const int64_t pix = gid / c4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * y_cs + cc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = act_legacy_f32(v[q], act);
+    if (res != nullptr) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(res + pix * res_cs + cc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += r[q];
+    }
+    *reinterpret_cast<f32x4*>(y + pix * y_cs + cc) = v;
+}
+
 // fp32 mode: the SPPF cascade in LDS (round 5; the direct 169-tap kernel above took 155 us on the yolov5s bs-32 plan against 17 us for the 16-bit LDS kernel).
 // A block owns the whole h x w plane of ONE image and FOUR channels (16 bytes per pixel): plane -> LDS, then three times {5-wide row maximum into the scratch plane,
 // 5-tall column maximum back into the plane, store as the next concat slot}.  max is exact and mp5(mp5(x)) = mp9(x), mp5(mp9(x)) = mp13(x) (common.py:196), so the three
@@ -875,6 +927,22 @@ extern "C" int ymi_upsample2x(const void* x, int x_cstride, int n, int h, int w,
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipLaunchKernelGGL(upsample2x_kernel, grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, x_cstride, n, h, w, c, (uint16_t*)y, y_cstride);
     return check_launch("upsample2x_kernel");
+}
+
+extern "C" int ymi_act(void* y, int y_cstride, int npix, int c, int dtype, int act, const void* res, int res_cstride, void* stream) {
+    YMI_REQUIRE(y != nullptr && npix >= 0 && c > 0, "ymi_act: null buffer / bad extent");
+    YMI_REQUIRE(act == YMI_ACT_HARDSWISH || act == YMI_ACT_LEAKY, "ymi_act: activation must be YMI_ACT_HARDSWISH or YMI_ACT_LEAKY (SiLU rides in the convolution's epilogue)");
+    YMI_REQUIRE(dtype == YMI_F16 || dtype == YMI_BF16 || dtype == YMI_F32, "ymi_act: dtype must be F16/BF16/F32");
+    const int lanes = dtype == YMI_F32 ? 4 : 8;   // elements per 16-byte packet
+    YMI_REQUIRE(c % lanes == 0 && y_cstride % lanes == 0 && (res == nullptr || res_cstride % lanes == 0), "ymi_act: channels / strides must be multiples of %d", lanes);
+    const int64_t total = (int64_t)npix * (c / lanes);
+    if (total == 0) return YMI_OK;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == YMI_F32) hipLaunchKernelGGL(act_f32_kernel, grid, block, 0, s, (float*)y, y_cstride, (int64_t)npix, c, act, (const float*)res, res_cstride);
+    else if (dtype == YMI_F16) hipLaunchKernelGGL((act_kernel<YMI_F16>), grid, block, 0, s, (uint16_t*)y, y_cstride, (int64_t)npix, c, act, (const uint16_t*)res, res_cstride);
+    else hipLaunchKernelGGL((act_kernel<YMI_BF16>), grid, block, 0, s, (uint16_t*)y, y_cstride, (int64_t)npix, c, act, (const uint16_t*)res, res_cstride);
+    return check_launch("act_kernel");
 }
 
 extern "C" int ymi_copy_view(const void* x, int x_cstride, int npix, int c, void* y, int y_cstride, int dtype, void* stream) {

@@ -278,6 +278,14 @@ class Plan:
         `chain` = (packed 1x1 conv, output view): a second conv on the first `split` (or all) output channels, evaluated in
         this launch's epilogue from registers (Bottleneck.cv1 chained to C3.cv1; K in {32, 64}).  A third element
         `x2` (view) makes it a conv over the concat [fresh outputs | x2] (C3.cv3 chained to the last Bottleneck.cv2)."""
+        if act not in (ACT_NONE, ACT_SILU):
+            # the legacy r3.1 activations (Hardswish / LeakyReLU(0.1)) are a launch of their own: the convolution runs with YMI_ACT_NONE, ymi_act rewrites its output in
+            # place and adds the shortcut AFTER the activation like the reference (common.py:115-116) -- see csrc/preproc_pool.hip act_kernel for why they are not fused
+            if out2 is not None or chain is not None or up2_out is not None:
+                raise YmiError(f"{name}: second outputs / chained convolutions / the folded upsample carry SiLU or identity only")
+            y = self.conv(x, pc, stride, pad, ACT_NONE, out=out, res=None, out_dtype=out_dtype, name=name, tile=tile)
+            self.io[self.num_ops - 1]["post_act"] = {"act": act, "res": res}   # (per-launch parity tests run this op and the next as ONE layer)
+            return self.act(y, act, res, name=name + ".act")
         s = (stride, stride) if isinstance(stride, int) else tuple(stride)
         p = (pad, pad) if isinstance(pad, int) else tuple(pad)
         x_arg = x
@@ -328,8 +336,6 @@ class Plan:
                     # candidate tiles differ per kind, so a table entry must not be applied across kinds
                     0 if chain is None else (1 if len(chain) < 3 or chain[2] is None else 2 + chain[2].c))
             pinned = tile_table().get(tile_key_str(tkey, self.dtype), 0) if self.use_tile_table else 0
-            if act not in (ACT_NONE, ACT_SILU) and 121 <= pinned <= 124:
-                pinned = 0   # the table key does not carry the activation: the streaming 1x1 kernel has a SiLU / identity epilogue only (legacy r3.1 blocks take the general tiles)
             if self.autotune:
                 d.tile = self._autotune_tile(d, tkey, chain)
             elif pinned >= 132 and os.environ.get("YOLORT_AMD_RULES_FIRST", "0") != "1" and self._pinned_ok(d, pinned):
@@ -546,6 +552,15 @@ class Plan:
         self._record(self.lib.ymi_plan_add_upsample2x(self.handle, x.ptr, x.cs, x.n, x.h, x.w, x.c, out.ptr, out.cs, dtype_code(x.dtype)), name,
                      kind="upsample", flops=0.0, bytes=float(x.n * x.h * x.w * x.c * x.base.element_size() * 5), shape=f"c{x.c} {x.h}x{x.w}")
         return out
+
+    def act(self, y: View, act: int, res: Optional[View] = None, name: str = "act") -> View:
+        """y <- act(y) (+ res) in place (ymi_act: the legacy r3.1 activations after a convolution run with YMI_ACT_NONE)"""
+        if res is not None and (res.n, res.h, res.w, res.c) != (y.n, y.h, y.w, y.c):
+            raise YmiError(f"{name}: shortcut view does not match the output")
+        esz = y.base.element_size()
+        self._record(self.lib.ymi_plan_add_act(self.handle, y.ptr, y.cs, y.n * y.h * y.w, y.c, dtype_code(y.dtype), act, None if res is None else res.ptr, 0 if res is None else res.cs),
+                     name, kind="act", flops=0.0, bytes=float(y.n * y.h * y.w * y.c * esz * (3 if res is not None else 2)), shape=f"c{y.c} {y.h}x{y.w}")
+        return y
 
     def copy(self, x: View, out: View, name: str = "copy") -> View:
         assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, x.c)

@@ -94,7 +94,8 @@ class PathAggregationNetwork(HipModule):
                 plan.copy(tap, cat.slice_c(c_t, tap.c), name=f"{name}.cat_tap.{t}")
             # nn.Upsample(scale_factor=2) (reference :221-223): folded into the 1x1 conv's epilogue when its channel count
             # allows (the conv writes its output AND the four upsampled copies), else a separate kernel
-            fold = c_t % 32 == 0 and not plan.use_v1 and (cat.h, cat.w) == (2 * feats[level].h, 2 * feats[level].w)
+            fold = (c_t % 32 == 0 and not plan.use_v1 and (cat.h, cat.w) == (2 * feats[level].h, 2 * feats[level].w)
+                    and isinstance(conv.act, (nn.SiLU, nn.Identity)))   # (an r3.1 Hardswish layer is two launches -- conv + ymi_act: its upsample stays a launch of its own)
             top = conv.emit(plan, last, out=bu_cat[idx].slice_c(c_down, c_t), name=f"{name}.inner_blocks.{3 * t + 1}",
                             up2_out=cat.slice_c(0, c_t) if fold else None)
             if not fold:

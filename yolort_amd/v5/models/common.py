@@ -217,8 +217,8 @@ class C3(HipModule):
 
 class BottleneckCSP(HipModule):
     """cv4(LeakyReLU(BN(cat(cv3(m(cv1(x))), cv2(x))))) (reference :119-146; the r3.1 block: Hardswish in its Conv modules, LeakyReLU(0.1) after the shared BatchNorm).
-    `cv2` and `cv3` are bare convolutions whose outputs meet in one BatchNorm over the concatenation: its first half is folded into cv3, its second into cv2, each with
-    the LeakyReLU in its epilogue, both writing straight into the concat buffer cv4 reads."""
+    `cv2` and `cv3` are bare convolutions whose outputs meet in one BatchNorm over the concatenation: its first half is folded into cv3, its second into cv2, each
+    followed by the LeakyReLU launch (Plan.conv with a legacy activation = convolution + ymi_act), both writing straight into the concat buffer cv4 reads."""
 
     def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
         super().__init__()
