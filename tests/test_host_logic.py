@@ -123,6 +123,46 @@ def test_legacy_release_models_mirror_the_reference(version):
         yolo.yolov5_darknet_tan_s_r40()
 
 
+def test_c_pass_over_the_image_list_agrees_with_the_per_image_reads():
+    """torch_ext/sig_ext.cpp `images()`: the checks YOLOv5.forward_async / Plan.stem_planar_ok / Plan.stem_from_planar make per image (3-d, device, dtype, shape,
+    contiguity, 16-byte alignment, data_ptr), in one pass -- against the same facts read through the tensors' Python attributes (CPU tensors here: device index -1)"""
+    import struct
+
+    from yolort_amd import hipmodule
+    ext = hipmodule._SIG_EXT
+    if ext is None:
+        pytest.skip("yolort_amd/lib/_ymi_sig.so is not built (python -m yolort_amd.torch_ext)")
+    wide = torch.rand(3, 16, 32)
+    cases = {
+        "uniform": [torch.rand(3, 16, 24) for _ in range(5)],
+        "mixed shapes": [torch.rand(3, 16, 24), torch.rand(3, 8, 24), torch.rand(3, 16, 24)],
+        "mixed dtypes": [torch.rand(3, 8, 8), torch.rand(3, 8, 8).half()],
+        "strided view": [wide[:, :, ::2], wide[:, :, 1::2]],
+        "interleaved uint8": [torch.zeros(16, 24, 3, dtype=torch.uint8)] * 2,
+        "a 2-d tensor": [torch.rand(3, 8, 8), torch.rand(8, 8)],
+        "misaligned": [torch.rand(3 * 8 * 8 + 1)[1:].view(3, 8, 8)],
+    }
+    for name, ims in cases.items():
+        all3, dev, same, uniform, shapes, contig, aligned, ptrs = ext.images(ims)
+        assert all3 == all(t.dim() == 3 for t in ims), name
+        assert dev == -1, name                                                        # nothing here lives on a GPU
+        assert struct.unpack(f"{len(ims)}Q", ptrs) == tuple(t.data_ptr() for t in ims), name
+        if all3:
+            assert same == (len({t.dtype for t in ims}) == 1), name
+            assert contig == all(t.is_contiguous() for t in ims), name
+            assert aligned == all(t.data_ptr() % 16 == 0 for t in ims), name
+            if len({tuple(t.shape) for t in ims}) == 1:
+                assert uniform == tuple(ims[0].shape) and shapes is None, name
+            else:
+                assert uniform is None and shapes == tuple(tuple(t.shape) for t in ims), name
+    assert not cases["misaligned"][0].data_ptr() % 16 == 0 and cases["strided view"][0].is_contiguous() is False
+    with pytest.raises(TypeError):
+        ext.images([torch.rand(3, 4, 4), "not a tensor"])
+    with pytest.raises(TypeError):
+        ext.images((torch.rand(3, 4, 4),))   # a list is required (forward_async builds one)
+    assert ext.images([])[3] is None
+
+
 def test_no_cpu_fallback_anywhere():
     from yolort_amd._lib import YmiError
     from yolort_amd.models import yolov5n
