@@ -37,6 +37,23 @@ def test_abi_version_and_error_channel(lib):
     t = (C.c_int32 * 8)()
     rc = lib.ymi_conv_build_ktab(7, 3, 3, 10, 8, 32, t)   # cin not a multiple of 8
     assert rc == -1 and b"ktab" in lib.ymi_last_error()
+    # round 5 entry points: argument validation happens before anything touches the device
+    assert lib.ymi_plan_begin(None, None, None) == -1 and b"ymi_plan_begin" in lib.ymi_last_error()
+    assert lib.ymi_plan_submit(None, 0, 0, 0, None, None, None, None, 0, 0) == -1 and b"ymi_plan_submit" in lib.ymi_last_error()
+    assert lib.ymi_plan_done_query(None) == -1 and lib.ymi_plan_done_sync(None) == -1
+    p = lib.ymi_plan_create()
+    try:
+        assert lib.ymi_plan_done_query(p) == 1                                  # nothing submitted yet: "done"
+        assert lib.ymi_plan_submit(p, 1, 0, 0, None, None, None, None, 0, 0) == -1 and b"first <= n_conv" in lib.ymi_last_error()
+        buf = (C.c_uint16 * 64)()
+        assert lib.ymi_plan_add_act(p, buf, 8, 4, 8, 0, 1, None, 0) == 0         # (recorded; the activation code is validated at launch)
+        assert lib.ymi_plan_num_ops(p) == 1
+    finally:
+        lib.ymi_plan_destroy(p)
+    assert lib.ymi_act(None, 8, 4, 8, 0, 2, None, 0, None) == -1 and b"ymi_act" in lib.ymi_last_error()
+    buf = (C.c_uint16 * 64)()
+    assert lib.ymi_act(buf, 8, 4, 8, 0, 1, None, 0, None) == -1 and b"HARDSWISH" in lib.ymi_last_error()     # SiLU belongs to the convolution's epilogue
+    assert lib.ymi_act(buf, 8, 4, 12, 0, 2, None, 0, None) == -1 and b"multiples" in lib.ymi_last_error()    # channels in whole 16-byte packets
 
 
 def test_ktab_known_answers(lib):
