@@ -303,3 +303,24 @@ def test_fp32_parity_mode_on_the_simulator_meets_the_north_star_tolerance(sim, f
         total += len(rs)
     print(f"fp32 parity mode on the simulator: {paired} of {total} reference detections paired (same label, |dscore| <= 1e-4, IoU >= 1 - 1e-3)")
     assert total > 50 and paired == total
+
+
+@pytest.mark.parametrize("name", ["Conv.output_shape", "Conv.stride_2", "Conv.version_r31", "Conv.no_activation", "Bottleneck.with_shortcut", "Bottleneck.without_shortcut",
+                                  "C3.output_shape", "C3.different_channels", "SPP.output_shape", "SPPF.output_shape", "Focus.output_shape", "Focus.r31", "BottleneckCSP.r31"])
+def test_reference_block_cases_on_the_simulator(sim, name):
+    """the block-level cases of the reference's test/test_v5_common.py (tests/_blocks.py: same constructor calls, same input shapes) through the product's emitters on the
+    simulator: the shape the reference asserts, and the oracle's fp32 value of the same module"""
+    import _blocks
+    dtype = torch.float16
+    m, x, out_shape = _blocks.build(name)
+    want = _blocks.expected(name, m, x)
+    m = m.to(dtype)
+    plan = _sim_plan(sim, dtype, fuse_c3=False, small_tiles=True)
+    n, c, h, w = x.shape
+    xv = plan.alloc(n, h, w, m._input_cpad(c), zero=True)
+    xv.as_tensor()[..., :c] = x.permute(0, 2, 3, 1).to(dtype)
+    y = m.emit(plan, xv)
+    plan.handle = None
+    got = y.as_tensor()[..., :y.c].float().permute(0, 3, 1, 2)
+    assert tuple(got.shape) == out_shape == tuple(want.shape)
+    assert (got - want).abs().max().item() <= 1e-2 * max(1.0, want.abs().max().item()), name
