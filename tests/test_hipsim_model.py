@@ -179,7 +179,8 @@ def test_yolov5s_conv_stack_on_the_simulator_and_fused_c3_inside_it(sim):
 @pytest.mark.parametrize("arch,S,div,gain,dtype,fused_head", [("yolov5_darknet_pan_n_r60", 96, 32, 0.5, torch.float16, False), ("yolov5_darknet_pan_n_r60", 96, 32, 0.5, torch.float16, True),
                                                             ("yolov5_darknet_pan_l6_r60", 128, 64, 4.0, torch.float16, True), ("yolov5_darknet_pan_m_r60", 64, 32, 2.0, torch.bfloat16, False),
                                                             # the legacy releases (round 5): Focus stem as the 6 x 6 stride-2 convolution it equals; r3.1: BottleneckCSP, Hardswish / LeakyReLU(0.1) epilogues
-                                                            ("yolov5_darknet_pan_s_r40", 64, 32, 0.25, torch.float16, True), ("yolov5_darknet_pan_s_r31", 64, 32, 0.25, torch.float16, True)])
+                                                            ("yolov5_darknet_pan_s_r40", 64, 32, 0.25, torch.float16, True), ("yolov5_darknet_pan_s_r31", 64, 32, 0.25, torch.float16, True),
+                                                            ("yolov5_darknet_pan_m_r31", 64, 32, 0.25, torch.float16, False), ("yolov5_darknet_pan_m_r40", 64, 32, 0.25, torch.bfloat16, False)])   # widths 48 / 96 / 192: padded hidden buffers under the activation launch
 def test_yolov5n_detections_on_the_simulator_vs_oracle(sim, arch, S, div, gain, dtype, fused_head):
     """letterbox -> backbone + PAN -> head -> decode / sort / NMS / top-k, every kernel on the simulator, driven by the product's
     emitters and its host recipe; against the oracle's fp32 forward with the matching criterion of __graft_entry__.smoke().
