@@ -123,6 +123,16 @@ def test_legacy_release_models_mirror_the_reference(version):
         yolo.yolov5_darknet_tan_s_r40()
 
 
+@pytest.mark.parametrize("n, b, h, w", [(1, 3, 480, 640), (4, 3, 416, 320), (4, 3, 320, 416)])
+def test_space_to_depth(n, b, h, w):
+    """reference test/test_models_common.py:6-11, unchanged but for the import"""
+    from yolort_amd.v5 import focus_transform, space_to_depth
+    tensor_input = torch.rand((n, b, h, w))
+    out1 = focus_transform(tensor_input)
+    out2 = space_to_depth(tensor_input)
+    torch.testing.assert_close(out2, out1)
+
+
 def test_c_pass_over_the_image_list_agrees_with_the_per_image_reads():
     """torch_ext/sig_ext.cpp `images()`: the checks YOLOv5.forward_async / Plan.stem_planar_ok / Plan.stem_from_planar make per image (3-d, device, dtype, shape,
     contiguity, 16-byte alignment, data_ptr), in one pass -- against the same facts read through the tensors' Python attributes (CPU tensors here: device index -1)"""
