@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 5
+#define YMI_ABI_VERSION 6
 
 /* error codes */
 #define YMI_OK 0
@@ -147,18 +147,29 @@ int ymi_conv_build_ktab(int cin, int kh, int kw, int w_in, int x_cstride, int k_
 int ymi_conv_f32_pick_tile(int m_pixels, int cout_pad);
 
 /* ------------------------------------------------------------------------------------------
- * A whole C3 block in one launch: y = cv3(cat(m(cv1(x)), cv2(x))), m = ONE Bottleneck
+ * A whole C3 block in one launch: y = cv3(cat(m(cv1(x)), cv2(x))), m = Bottleneck(s)
  * x1 + cv2(cv1(x1)) -- yolort/v5/models/common.py:172-173 (C3.forward) with :115-116
  * (Bottleneck.forward) inlined, every Conv being :69-70 with BatchNorm folded into W/bias.
  * Intermediates never reach memory; results are bit-identical to the separate ymi_conv2d launches.
- * This build holds ONE instance: c_in = 64, c_hidden = 32, c_out = 64, one shortcut Bottleneck
- * (yolov5s backbone.body.2); anything else returns YMI_EINVAL.  The Python side emits it by default since
- * round 3 (YOLORT_AMD_FUSE_C3=0 restores the separate launches).
+ * Two instances:
+ *   (1) c_in = 64, c_hidden = 32, c_out = 64, one shortcut Bottleneck (yolov5s backbone.body.2): resident weights,
+ *       csrc/c3_fused32.hip; wblob = NULL, mode = 0.
+ *   (2) ABI 6 -- c_hidden = 64 or 128, c_out = 2 * c_hidden, c_in % 32 == 0, feature maps whose halo strip of whole rows
+ *       fits the LDS patch (80 x 80 / 40 x 40 of yolov5s; ymi_c3_tile_supported says): the strip kernel of csrc/c3_tile.hip,
+ *       weights streamed in MFMA fragment order from `wblob` (ymi_c3_blob_bytes / ymi_c3_pack build it from w12 .. b3).
+ *       A C3 with n > 1 Bottlenecks is a chain of launches over the same descriptor fields (`mode`):
+ *         0  whole block, one Bottleneck:   x -> y
+ *         1  HEAD  cv1 | cv2 + Bottleneck 0:   x -> y1_out (the Bottleneck's output), y2 (cv2(x))
+ *         2  MID   one Bottleneck:             y1_in -> y1_out     (wm1 / wm2 = THAT Bottleneck's weights; never in place)
+ *         3  TAIL  last Bottleneck + cv3:      y1_in, y2 -> y
+ * Anything else returns YMI_EINVAL.  The Python side emits (1) since round 3 and (2) since round 6
+ * (YOLORT_AMD_FUSE_C3=0 / YOLORT_AMD_C3_TILE=0 restore the separate launches).
  *   x / y       NHWC views (n,h,w,c_in) / (n,h,w,c_out), 16-bit, pixel strides x_cstride / y_cstride
  *   w12, b12    cv1 and cv2 stacked along cout: packed [>= 2*c_hidden][k12_pad] like ymi_conv_desc.w
  *               (rows 0..c_hidden-1 = cv1), fp32 bias [2*c_hidden]
  *   wm1, bm1    Bottleneck.cv1 (1x1, c_hidden -> c_hidden);  wm2, bm2  Bottleneck.cv2 (3x3 pad 1,
  *               k = (ky*3 + kx)*c_hidden + c);  w3, b3  cv3 (1x1, 2*c_hidden -> c_out)
+ *   shortcut    1: the Bottleneck adds its input (common.py:116 `self.add`)
  * ---------------------------------------------------------------------------------------- */
 typedef struct ymi_c3_desc {
     const void* x;
@@ -174,10 +185,22 @@ typedef struct ymi_c3_desc {
     int32_t n, h, w, x_cstride, y_cstride, dtype;
     int32_t c_in, c_hidden, c_out, n_bottlenecks, shortcut;
     int32_t k12_pad, km1_pad, km2_pad, k3_pad;
-    int32_t reserved0;
+    int32_t mode;            /* ABI 6 (was reserved0): 0 whole block, 1 HEAD, 2 MID, 3 TAIL */
+    /* ABI 6 */
+    const void* wblob;       /* instance (2): ymi_c3_pack's weight stream for THIS mode (device memory, 16-byte aligned); NULL for instance (1) */
+    const void* y1_in;       /* modes 2, 3: (n,h,w,c_hidden) view, the Bottleneck's input */
+    void* y1_out;            /* modes 1, 2: (n,h,w,c_hidden) view, the Bottleneck's output */
+    void* y2;                /* mode 1: cv2(x) is written here; mode 3: read from here; (n,h,w,c_hidden) view */
+    int32_t y1_in_cstride, y1_out_cstride, y2_cstride, reserved1;
 } ymi_c3_desc;
 
 int ymi_c3_fused(const ymi_c3_desc* d, void* stream);
+/* instance (2): size of / builder for the fragment-ordered weight stream of descriptor d's (c_in, c_hidden, mode); reads w12 .. b3 (device
+ * pointers, the ymi_conv_desc.w layout) and writes `blob` on `stream`.  Weights that a mode does not use (w12 in modes 2 / 3, w3 in 1 / 2) may be NULL. */
+int64_t ymi_c3_blob_bytes(const ymi_c3_desc* d);
+int ymi_c3_pack(const ymi_c3_desc* d, void* blob, void* stream);
+/* 1 when a strip geometry exists for (n, h, w, c_hidden) of d, i.e. ymi_c3_fused would take instance (2) for it */
+int ymi_c3_tile_supported(const ymi_c3_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * SPP max-pool pyramid: given x = channels [0,c) of a (n,h,w,4c) concat buffer, writes

@@ -39,7 +39,7 @@ def sim():
     out_dir = os.path.join(SIM_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhipsim_kernels.so")
-    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem", "sim_kernels_f32", "sim_kernels_f32p"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
+    units = ["sim_kernels", "sim_kernels_gemm", "sim_kernels_v2", "sim_kernels_pre", "sim_kernels_post", "sim_kernels_stem", "sim_kernels_f32", "sim_kernels_f32p", "sim_kernels_c3t"]   # translation units, compiled in parallel (-O0: ~10 s; the optimiser would take two minutes and save one)
     csrc = os.path.join(ROOT, "yolort_amd", "csrc")
     srcs = [os.path.join(SIM_DIR, f) for f in ("hipsim.h", "hipsim.cpp", "sim_fill.h")] + [os.path.join(SIM_DIR, u + ".cpp") for u in units] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")) and not f.startswith(("conv_inst", "head_inst"))] + \
@@ -60,6 +60,10 @@ def sim():
     from yolort_amd._lib import C3Desc, ConvDesc
     lib.sim_c3_fused.argtypes, lib.sim_c3_fused.restype = [C.POINTER(C3Desc)], C.c_int
     lib.sim_conv2d.argtypes, lib.sim_conv2d.restype = [C.POINTER(ConvDesc)], C.c_int
+    lib.sim_c3_tile.argtypes, lib.sim_c3_tile.restype = [C.POINTER(C3Desc)], C.c_int
+    lib.ymi_c3_blob_bytes.argtypes, lib.ymi_c3_blob_bytes.restype = [C.POINTER(C3Desc)], C.c_int64
+    lib.ymi_c3_pack.argtypes, lib.ymi_c3_pack.restype = [C.POINTER(C3Desc), C.c_void_p, C.c_void_p], C.c_int
+    lib.ymi_c3_tile_supported.argtypes, lib.ymi_c3_tile_supported.restype = [C.POINTER(C3Desc)], C.c_int
     lib.sim_conv_f32_pick_tile.argtypes, lib.sim_conv_f32_pick_tile.restype = [C.c_int, C.c_int], C.c_int
     lib.sim_last_error.restype = C.c_char_p
     lib.sim_max_lds.restype = C.c_int
@@ -1340,3 +1344,132 @@ def test_layout_edges_and_view_copy(sim):
     _check(sim, sim.ymi_copy_view(nhwc.slice_c(8, 16).ptr, 24, 2 * 7 * 9, 16, dst.slice_c(16, 16).ptr, 40, YMI_F16, None))
     d = dst.view().float()
     assert torch.equal(d[..., 16:32], v[..., 8:24]) and d[..., :16].abs().max().item() == 0 and d[..., 32:].abs().max().item() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The strip kernel of a whole C3 / its Bottlenecks (csrc/c3_tile.hip, round 6): hidden widths 64 / 128, weights streamed
+# through one LDS ring in MFMA fragment order (ymi_c3_pack).  BIT-IDENTICAL to the separate launches of the tiles the pinned
+# plan records for these layers (1x1: any implicit-GEMM tile; 3x3: the 8-wave LDS-halo kernel), and close to torch fp32.
+# ---------------------------------------------------------------------------------------------------------------------
+def _make_c3_wide(c1, c2, n, shortcut, seed):
+    from yolort_amd.v5.models.common import C3
+    torch.manual_seed(seed)
+    m = C3(c1, c2, n=n, shortcut=shortcut).eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.6, 1.4)
+                mod.bias.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m
+
+
+def _c3_tile_desc(dtype, n, h, w, c_in, c_, shortcut, mode, pc12, pcm1, pcm2, pc3):
+    from yolort_amd._lib import C3Desc, dtype_code
+    d = C3Desc()
+    d.n, d.h, d.w, d.dtype = n, h, w, dtype_code(dtype)
+    d.c_in, d.c_hidden, d.c_out, d.n_bottlenecks, d.shortcut, d.mode = c_in, c_, 2 * c_, 1, 1 if shortcut else 0, mode
+    if pc12 is not None:
+        d.w12, d.b12, d.k12_pad = pc12.w.data_ptr(), pc12.bias.data_ptr(), pc12.k_pad
+    d.wm1, d.bm1, d.km1_pad = pcm1.w.data_ptr(), pcm1.bias.data_ptr(), pcm1.k_pad
+    d.wm2, d.bm2, d.km2_pad = pcm2.w.data_ptr(), pcm2.bias.data_ptr(), pcm2.k_pad
+    if pc3 is not None:
+        d.w3, d.b3, d.k3_pad = pc3.w.data_ptr(), pc3.bias.data_ptr(), pc3.k_pad
+    return d
+
+
+def _c3_pack(sim, d):
+    nb = sim.ymi_c3_blob_bytes(C.byref(d))
+    assert nb > 0
+    blob = torch.zeros(nb + 16, dtype=torch.uint8)
+    _check(sim, sim.ymi_c3_pack(C.byref(d), blob.data_ptr(), None))
+    d.wblob = blob.data_ptr()
+    return blob
+
+
+def _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t1x1=21, t3x3=91, blocks=None):
+    cpu = torch.device("cpu")
+    m = _make_c3_wide(c_in, 2 * c_, nb, shortcut, seed=h * 7 + w + nb)
+    x = torch.randn(n, c_in, h, w, generator=torch.Generator().manual_seed(n + h + c_)).to(dtype).float()
+    xb = Buf(n, h, w, c_in, dtype, fill=x.permute(0, 2, 3, 1))
+    pc12 = m.packed_pair(dtype, cpu, c_in)
+    pc3 = m.cv3.packed(dtype, cpu, 2 * c_)
+    pcs = [(b.cv1.packed(dtype, cpu, c_), b.cv2.packed(dtype, cpu, c_)) for b in m.m]
+
+    # ---- the separate launches (what C3.emit records without the strip kernel) ----
+    cat, out_sep = Buf(n, h, w, 2 * c_, dtype), Buf(n, h, w, 2 * c_, dtype)
+    y = Buf(n, h, w, c_, dtype)
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(xb, pc12, y, t1x1, y2=cat.slice_c(c_, c_), split=c_))))
+    for j, (pcm1, pcm2) in enumerate(pcs):
+        t = Buf(n, h, w, c_, dtype)
+        _check(sim, sim.sim_conv2d(C.byref(_conv_desc(y, pcm1, t, t1x1))))
+        yo = cat.slice_c(0, c_) if j == nb - 1 else Buf(n, h, w, c_, dtype)
+        _check(sim, sim.sim_conv2d(C.byref(_conv_desc(t, pcm2, yo, t3x3, k=3, pad=1, res=y if shortcut else None))))
+        y = yo
+    _check(sim, sim.sim_conv2d(C.byref(_conv_desc(cat, pc3, out_sep, t1x1))))
+
+    # ---- the strip kernel: one launch (nb == 1) or HEAD, MID ..., TAIL ----
+    if blocks is not None:
+        os.environ["YOLORT_AMD_C3T_BLOCKS"] = str(blocks)
+    try:
+        wide = Buf(n, h, w, 2 * c_ + 32, dtype)   # the output is a channel slice of a wider buffer
+        out_f = wide.slice_c(16, 2 * c_)
+        keep = []
+        if nb == 1:
+            d = _c3_tile_desc(dtype, n, h, w, c_in, c_, shortcut, 0, pc12, pcs[0][0], pcs[0][1], pc3)
+            d.x, d.x_cstride, d.y, d.y_cstride = xb.ptr, xb.cs, out_f.ptr, out_f.cs
+            assert sim.ymi_c3_tile_supported(C.byref(d)) == 1
+            keep.append(_c3_pack(sim, d))
+            _check(sim, sim.sim_c3_tile(C.byref(d)))
+        else:
+            cat_f = Buf(n, h, w, 2 * c_, dtype)
+            y2v = cat_f.slice_c(c_, c_)
+            ya, yb_ = Buf(n, h, w, c_, dtype), Buf(n, h, w, c_, dtype)
+            d = _c3_tile_desc(dtype, n, h, w, c_in, c_, shortcut, 1, pc12, pcs[0][0], pcs[0][1], None)
+            d.x, d.x_cstride = xb.ptr, xb.cs
+            d.y1_out, d.y1_out_cstride, d.y2, d.y2_cstride = ya.ptr, ya.cs, y2v.ptr, y2v.cs
+            keep.append(_c3_pack(sim, d))
+            _check(sim, sim.sim_c3_tile(C.byref(d)))
+            cur, nxt = ya, yb_
+            for j in range(1, nb - 1):
+                d = _c3_tile_desc(dtype, n, h, w, c_in, c_, shortcut, 2, None, pcs[j][0], pcs[j][1], None)
+                d.y1_in, d.y1_in_cstride, d.y1_out, d.y1_out_cstride = cur.ptr, cur.cs, nxt.ptr, nxt.cs
+                keep.append(_c3_pack(sim, d))
+                _check(sim, sim.sim_c3_tile(C.byref(d)))
+                cur, nxt = nxt, cur
+            d = _c3_tile_desc(dtype, n, h, w, c_in, c_, shortcut, 3, None, pcs[nb - 1][0], pcs[nb - 1][1], pc3)
+            d.y1_in, d.y1_in_cstride, d.y2, d.y2_cstride = cur.ptr, cur.cs, y2v.ptr, y2v.cs
+            d.y, d.y_cstride = out_f.ptr, out_f.cs
+            keep.append(_c3_pack(sim, d))
+            _check(sim, sim.sim_c3_tile(C.byref(d)))
+    finally:
+        os.environ.pop("YOLORT_AMD_C3T_BLOCKS", None)
+
+    a, b = out_sep.view(), out_f.view()
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"strip kernel vs separate launches: max difference {(a.float() - b.float()).abs().max().item()}"
+    w_all = wide.view().float()
+    assert w_all[..., :16].abs().max().item() == 0 and w_all[..., 16 + 2 * c_:].abs().max().item() == 0   # nothing outside the slice
+    with torch.no_grad():
+        x1, x2 = _torch_conv(m.cv1, x, dtype), _torch_conv(m.cv2, x, dtype)
+        for bt in m.m:
+            x1 = _torch_conv(bt.cv2, _torch_conv(bt.cv1, x1, dtype), dtype, res=x1 if shortcut else None)
+        ref = _torch_conv(m.cv3, torch.cat([x1, x2], 1), dtype).permute(0, 2, 3, 1)
+    tol = 4e-3 if dtype == torch.float16 else 3.2e-2
+    err = (b.float() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("case", [
+    # (dtype, n, h, w, c_in, hidden, bottlenecks, shortcut, blocks)
+    (torch.float16, 1, 40, 40, 256, 128, 1, False, None),    # yolov5s pan.layer_blocks.2: R = 5, eight strips, one centre group per wave
+    (torch.float16, 2, 13, 40, 64, 128, 1, True, 3),         # a ragged last strip, the shortcut, three blocks walking six strips
+    (torch.bfloat16, 1, 10, 40, 96, 128, 3, True, 1),        # HEAD, MID, TAIL (backbone.body.6's chain), ONE block: the ring runs across strips
+    (torch.float16, 1, 12, 80, 128, 64, 1, False, None),     # 80 x 80 level: two centre groups per wave
+    (torch.float16, 1, 9, 80, 64, 64, 2, True, 1),           # HEAD + TAIL (backbone.body.4's chain)
+    (torch.bfloat16, 1, 7, 24, 64, 64, 1, True, None),       # a narrow map: many rows per strip
+    (torch.float16, 1, 20, 20, 96, 128, 1, False, None),
+])
+def test_c3_strip_kernel_equals_the_separate_launches_and_torch(sim, case):
+    dtype, n, h, w, c_in, c_, nb, shortcut, blocks = case
+    _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t3x3=91 if c_ == 128 else 92, blocks=blocks)

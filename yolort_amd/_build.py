@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.environ.get("YOLORT_AMD_BUILD_OUT") or os.path.join(LIBDIR, "libyolort_amd.so")   # override: tuning builds only
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_halo8.hip", "conv_igemm8.hip", "conv1x1_stream.hip", "conv3x3_c32.hip", "conv3x3_res.hip", "conv3x3_rw.hip", "conv3x3_rw2.hip", "conv3x3_rs.hip", "c3_fused32.hip", "stem_body1_fused.hip", "conv_stem.hip", "conv_f32.hip", "conv_f32_pipe.hip", "preproc_pool.hip", "postprocess.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv3x3_halo.hip", "conv_halo8.hip", "conv_igemm8.hip", "conv1x1_stream.hip", "conv3x3_c32.hip", "conv3x3_res.hip", "conv3x3_rw.hip", "conv3x3_rw2.hip", "conv3x3_rs.hip", "c3_fused32.hip", "c3_tile.hip", "stem_body1_fused.hip", "conv_stem.hip", "conv_f32.hip", "conv_f32_pipe.hip", "preproc_pool.hip", "postprocess.hip"]
 # the conv tile x dtype space and the fused heads are instantiated in their own translation units (parallel build)
 INST_SOURCES = sorted(f for f in os.listdir(CSRC) if (f.startswith("conv_inst_") or f.startswith("head_inst_")) and f.endswith(".hip"))
 MONOLITHIC = "-DYMI_STAMPS" in os.environ.get("YOLORT_AMD_BUILD_FLAGS", "")   # the timeline instrumentation keeps one device symbol: single TU

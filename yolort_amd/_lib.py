@@ -48,11 +48,14 @@ class C3Desc(C.Structure):
         ("wm2", C.c_void_p), ("bm2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
         ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("x_cstride", C.c_int32), ("y_cstride", C.c_int32), ("dtype", C.c_int32),
         ("c_in", C.c_int32), ("c_hidden", C.c_int32), ("c_out", C.c_int32), ("n_bottlenecks", C.c_int32), ("shortcut", C.c_int32),
-        ("k12_pad", C.c_int32), ("km1_pad", C.c_int32), ("km2_pad", C.c_int32), ("k3_pad", C.c_int32), ("reserved0", C.c_int32),
+        ("k12_pad", C.c_int32), ("km1_pad", C.c_int32), ("km2_pad", C.c_int32), ("k3_pad", C.c_int32), ("mode", C.c_int32),
+        # ABI 6: the strip kernel (csrc/c3_tile.hip)
+        ("wblob", C.c_void_p), ("y1_in", C.c_void_p), ("y1_out", C.c_void_p), ("y2", C.c_void_p),
+        ("y1_in_cstride", C.c_int32), ("y1_out_cstride", C.c_int32), ("y2_cstride", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
-ABI_VERSION = 5   # include/yolort_amd.h YMI_ABI_VERSION
+ABI_VERSION = 6   # include/yolort_amd.h YMI_ABI_VERSION
 POST_EXACT_FULL = 1
 
 
@@ -85,6 +88,9 @@ _SIGS = {
     "ymi_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ymi_c3_fused": (C.c_int, [C.POINTER(C3Desc), C.c_void_p]),
     "ymi_plan_add_c3_fused": (C.c_int, [C.c_void_p, C.POINTER(C3Desc)]),
+    "ymi_c3_blob_bytes": (C.c_int64, [C.POINTER(C3Desc)]),
+    "ymi_c3_pack": (C.c_int, [C.POINTER(C3Desc), C.c_void_p, C.c_void_p]),
+    "ymi_c3_tile_supported": (C.c_int, [C.POINTER(C3Desc)]),
     "ymi_conv_stem_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "ymi_stem_body1_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "ymi_stem_body1": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),

@@ -266,8 +266,12 @@ static int launch_c3_fused32(const C3Args& a, hipStream_t s) {
     return check_launch("c3_fused32_kernel");
 }
 
+int c3_tile_launch(const ymi_c3_desc* d, hipStream_t s);   // c3_tile.hip: hidden widths 64 / 128, streamed weights
+
 int c3_fused_launch(const ymi_c3_desc* d, hipStream_t s) {
     YMI_REQUIRE(d != nullptr, "ymi_c3_fused: null descriptor");
+    if (d->c_hidden == 64 || d->c_hidden == 128) return c3_tile_launch(d, s);
+    YMI_REQUIRE(d->mode == 0 && d->wblob == nullptr, "ymi_c3_fused: the resident-weights instance takes mode 0 without a weight stream");
     YMI_REQUIRE(d->x && d->y && d->w12 && d->b12 && d->wm1 && d->bm1 && d->wm2 && d->bm2 && d->w3 && d->b3, "ymi_c3_fused: null buffer");
     YMI_REQUIRE(d->dtype == YMI_F16 || d->dtype == YMI_BF16, "ymi_c3_fused: 16-bit storage only");
     YMI_REQUIRE(d->c_in == 64 && d->c_hidden == 32 && d->c_out == 64 && d->n_bottlenecks == 1 && d->shortcut == 1,
