@@ -179,3 +179,92 @@ def test_fused_stem_body1_leaves_yolov5s_detections_unchanged(dev, monkeypatch):
         for a, b in zip(*res):
             for k in ("scores", "labels", "boxes"):
                 assert torch.equal(a[k], b[k]), (shape, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the strip kernel (csrc/c3_tile.hip) -- C3 blocks of 64 / 128 hidden channels, one launch per block or per Bottleneck
+# ---------------------------------------------------------------------------------------------------------------------
+def _make_c3_wide(c1, c2, n, shortcut, seed):
+    from yolort_amd.v5.models.common import C3
+    torch.manual_seed(seed)
+    m = C3(c1, c2, n=n, shortcut=shortcut).eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.6, 1.4)
+                mod.bias.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m
+
+
+def _torch_c3_wide(m, x, dtype, shortcut):
+    def conv(c, t, res=None):
+        bn = c.bn
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = (c.conv.weight * scale.view(-1, 1, 1, 1)).to(dtype).float()
+        y = F.silu(F.conv2d(t, w, bn.bias - bn.running_mean * scale, c.conv.stride, c.conv.padding))
+        if res is not None:
+            y = y + res
+        return y.to(dtype).float()
+    with torch.no_grad():
+        x1, x2 = conv(m.cv1, x), conv(m.cv2, x)
+        for b in m.m:
+            x1 = conv(b.cv2, conv(b.cv1, x1), res=x1 if shortcut else None)
+        return conv(m.cv3, torch.cat([x1, x2], 1))
+
+
+def _run_strip(dev, m, x, dtype, strip, t3x3):
+    """strip = True: C3.emit with the strip kernel; False: the separate launches recorded by hand on tiles whose k order the strip kernel shares (1x1: tile 21; 3x3: the
+    8-wave LDS-halo kernel) -- what the comparison is bit for bit against"""
+    from yolort_amd import engine
+    plan = engine.Plan(dev, dtype)
+    n, c1, h, w = x.shape
+    c_ = m.cv1.conv.out_channels
+    nb = len(m.m)
+    xv = plan.alloc(n, h, w, c1)
+    xv.as_tensor().copy_(x.permute(0, 2, 3, 1).to(dev, dtype))
+    wide = plan.alloc(n, h, w, 2 * c_ + 64, zero=True)
+    out = wide.slice_c(32, 2 * c_)
+    if strip:
+        plan.c3_tile_on = True
+        m.emit(plan, xv, out=out, name="c3")
+        assert plan.num_ops == max(1, nb), plan.names
+    else:
+        pk = lambda cv, cin: cv.packed(dtype, dev, cin)  # noqa: E731
+        cat = plan.alloc(n, h, w, 2 * c_)
+        y = plan.alloc(n, h, w, c_)
+        plan.conv(xv, m.packed_pair(dtype, dev, c1), out=y, out2=cat.slice_c(c_, c_), split=c_, tile=21)
+        for j, b in enumerate(m.m):
+            t = plan.conv(y, pk(b.cv1, c_), tile=21)
+            y = plan.conv(t, pk(b.cv2, c_), 1, 1, out=cat.slice_c(0, c_) if j == nb - 1 else None, res=y if b.add else None, tile=t3x3)
+        plan.conv(cat, pk(m.cv3, 2 * c_), out=out, tile=21)
+    plan.run()
+    torch.cuda.synchronize()
+    return out.as_tensor().cpu(), wide.as_tensor().cpu()
+
+
+@pytest.mark.parametrize("case", [
+    # (dtype, n, h, w, c_in, hidden, bottlenecks, shortcut)
+    (torch.float16, 32, 40, 40, 256, 128, 1, False),   # yolov5s pan.layer_blocks.2 at the benchmark's batch
+    (torch.float16, 32, 40, 40, 512, 128, 1, False),   # pan.inner_blocks.3
+    (torch.float16, 32, 40, 40, 256, 128, 3, True),    # backbone.body.6: HEAD, MID, TAIL
+    (torch.float16, 32, 80, 80, 128, 64, 2, True),     # backbone.body.4: HEAD, TAIL
+    (torch.float16, 32, 80, 80, 256, 64, 1, False),    # pan.layer_blocks.0
+    (torch.bfloat16, 3, 37, 40, 96, 128, 2, True),     # ragged last strip
+    (torch.bfloat16, 2, 50, 76, 64, 64, 1, True),
+    (torch.float16, 5, 20, 20, 128, 128, 1, False),
+    (torch.float16, 300, 13, 24, 64, 64, 1, False),    # more strips than blocks: the ring runs across strips
+])
+def test_c3_strip_kernel_equals_the_separate_launches(dev, case):
+    dtype, n, h, w, c1, c_, nb, shortcut = case
+    m = _make_c3_wide(c1, 2 * c_, nb, shortcut, seed=h * 7 + w + nb)
+    x = torch.randn(n, c1, h, w, generator=torch.Generator().manual_seed(n + h)).to(dtype).float()
+    sep, _ = _run_strip(dev, m, x, dtype, False, 91 if c_ == 128 else 92)
+    got, whole = _run_strip(dev, m, x, dtype, True, 0)
+    assert torch.equal(sep.view(torch.int16), got.view(torch.int16)), f"max difference {(sep.float() - got.float()).abs().max().item()}"
+    assert whole[..., :32].abs().max().item() == 0 and whole[..., 32 + 2 * c_:].abs().max().item() == 0
+    ref = _torch_c3_wide(m, x[: min(n, 4)], dtype, shortcut).permute(0, 2, 3, 1)
+    tol = (4e-3 if dtype == torch.float16 else 3.2e-2) * (1 + nb) / 2
+    err = (got[: min(n, 4)].float() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err

@@ -162,6 +162,48 @@ def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size
 
     for idx in sorted(plan.io):
         io = plan.io[idx]
+        if io.get("c3_mode") is not None:   # round 6, the strip kernel (csrc/c3_tile.hip): a whole C3 / its head / one Bottleneck / its tail per launch -- the oracle's
+            # layers chained, each output rounded to the storage type like the separate launches round it (common.py:172-173, :115-116)
+            mode = io["c3_mode"]
+            b = "model." + io["name"].split(".tile")[0]
+            tail = io["name"].split(".tile")[1]
+            j = 0 if mode in (0, 1) else int(tail.split(".m.")[1].split("+")[0])
+            mj = f"{b}.m.{j}"
+
+            def bottleneck(x1):
+                v = _ref_conv(sdf, mj + ".cv2", q(_ref_conv(sdf, mj + ".cv1", x1, 1, 0)), 1, 1)
+                return v + x1 if io["shortcut"] else v
+
+            outs = []
+            with torch.no_grad():
+                if mode in (0, 1):
+                    xq = inputs[b + ".cv1"].float()
+                    _fill_rep(io["x"], xq, dtype)
+                    x1, x2 = q(_ref_conv(sdf, b + ".cv1", xq, 1, 0)), _ref_conv(sdf, b + ".cv2", xq, 1, 0)
+                    v = bottleneck(x1)
+                    if mode == 0:
+                        outs.append((_ref_conv(sdf, b + ".cv3", torch.cat([q(v), q(x2)], 1), 1, 0), io["y"], 5))
+                    else:
+                        outs += [(v, io["y1_out"], 3), (x2, io["y2"], 1)]
+                else:
+                    x1 = inputs[mj + ".cv1"].float()
+                    _fill_rep(io["y1_in"], x1, dtype)
+                    v = bottleneck(x1)
+                    if mode == 2:
+                        outs.append((v, io["y1_out"], 2))
+                    else:
+                        c_ = x1.shape[1]
+                        x2 = inputs[b + ".cv3"].float()[:, c_:]
+                        _fill_rep(io["y2"], x2, dtype)
+                        outs.append((_ref_conv(sdf, b + ".cv3", torch.cat([q(v), x2], 1), 1, 0), io["y"], 3))
+            plan.run(idx, idx + 1)
+            torch.cuda.synchronize()
+            for ref, view, depth in outs:
+                scale, err = float(ref.abs().max()), _err_vs(view, ref)
+                worst.append((err / scale, f"{io['name']} (strip kernel, mode {mode})", -3, plan.meta[idx].get("shape")))
+                assert err <= (2 if depth > 1 else 1) * tol * scale + 1e-6, f"op {idx} {io['name']}: |hip-ref| {err:.5f} > {tol} x {scale:.3f}"   # chained roundings: twice the bound
+            checked += {0: 5, 1: 4, 2: 2, 3: 3}[mode]
+            continue
         if io.get("fused_c3"):   # the whole one-Bottleneck C3 in one launch (csrc/c3_fused32.hip): the oracle's five layers chained, each output
             # rounded to the storage type like the separate launches round it (common.py:172-173, :115-116)
             b = "model." + io["name"].rsplit(".", 1)[0]

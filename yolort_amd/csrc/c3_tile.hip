@@ -64,10 +64,12 @@ template <int CH> struct C3TCfg;
 template <> struct C3TCfg<128> {   // 40 x 40: a wave owns ONE centre group, or two halo-only groups
     static constexpr int NP = 4, NHJ = 2, GC = 1;
     static constexpr bool maybe_w1(int hj) { return true; }
+    static constexpr int geom_of(int hj) { return hj; }           // (half-job 1 is either a second halo-only group or cv2's half of job 0's group: its own geometry)
 };
 template <> struct C3TCfg<64> {    // 80 x 80: a wave owns up to TWO centre groups and one halo-only group
     static constexpr int NP = 2, NHJ = 5, GC = 2;
     static constexpr bool maybe_w1(int hj) { return (hj & 1) == 0; }
+    static constexpr int geom_of(int hj) { return hj & ~1; }      // cv2's half shares the geometry of its group's cv1 half
 };
 
 template <int DT>
@@ -118,32 +120,19 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
 
     for (int i = tid; i < BIAS_BYTES / 16; i += 512) bl[i] = *reinterpret_cast<const f32x4*>(a.blob + a.bias_off + i * 16);
 
-    // ---- this wave's half-jobs and the per-lane patch geometry of their slots q = group * 32 + frow = delta + r * pw + c ----
-    int jg[NHJ], jh[NHJ], jr[NHJ], jc[NHJ];
+    // ---- this wave's half-jobs and the per-lane patch geometry of their slots q = group * 32 + frow = delta + r * pw + c (packed: (r + 8) << 16 | c) ----
+    int jg[NHJ], jh[NHJ], jrc[NHJ];
 #pragma unroll
     for (int k = 0; k < NHJ; ++k) {
         jg[k] = g.grp[wave][k];
         jh[k] = g.half[wave][k];
+        jrc[k] = 0;
+        if (Cfg::geom_of(k) != k) continue;
         const int q = (jg[k] >= 0 ? jg[k] : 0) * 32 + frow;
         const int qq = q - g.delta;
         const int qp = qq >= 0 ? qq : 0;
         const int r = fast_div(qp, g.pw, g.magic_pw);
-        jr[k] = qq >= 0 ? r : -4;                              // slots before the first row: never inside
-        jc[k] = qp - r * g.pw;                                 // c == w: the pad slot between two rows
-    }
-    // centre jobs: LDS byte offsets of the nine taps' fragments (k16 half 0; half 1 = ^ 32) inside a plane.  Slot q' = q + (dy - 1) pw + (dx - 1) holds its four
-    // 16-byte channel octets at q' * 64 + ((octet ^ ((q' >> 2) & 3)) * 16): 32 CONSECUTIVE slots under any constant shift cover every 16-byte bank slot once per
-    // ds_read_b128 lane group (MI355X_MICROARCH.md, LDS).  Lanes whose slot is no output pixel read a safe slot (results never stored).
-    int ea[GC][9];
-#pragma unroll
-    for (int c = 0; c < GC; ++c) {
-        const bool out_px = jg[2 * c] >= 0 && jr[2 * c] >= 1 && jr[2 * c] <= g.R && jc[2 * c] < a.w;
-        const int q = out_px ? jg[2 * c] * 32 + frow : g.delta + g.pw;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int qs = q + (t / 3 - 1) * g.pw + (t % 3 - 1);
-            ea[c][t] = qs * 64 + ((hi ^ ((qs >> 2) & 3)) * 16);
-        }
+        jrc[k] = (((qq >= 0 ? r : -4) + 8) << 16) | (qp - r * g.pw);   // r = -4: the slots before the first row (never inside); c == w: the pad slot between two rows
     }
     const u32x2 none[4] = {};
 
@@ -213,18 +202,20 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
         cur = cur == 2 ? 0 : cur + 1;
     };
 
-    // per-tile pixel geometry of the half-jobs: pm = pixel index (clamped into the image), fl bit 0 = inside the image (else: zero padding), bit 1 = an output pixel of this tile
-    int pm[NHJ], fl[NHJ];
-    auto tile_geom = [&](int t, int (&pm_)[NHJ], int (&fl_)[NHJ]) {
+    // per-tile pixel geometry of the half-jobs, packed: pixel index (clamped into the image) * 4 + bit 0 (inside the image; else: zero padding) + bit 1 (an output pixel of this tile)
+    int pmf[NHJ];
+    auto tile_geom = [&](int t, int (&pmf_)[NHJ]) {
         const int img = t / g.tiles_per_img, ty = t - img * g.tiles_per_img;
 #pragma unroll
         for (int k = 0; k < NHJ; ++k) {
-            const int iy = ty * g.R + jr[k] - 1;
-            const bool slot_ok = jg[k] >= 0 && jr[k] >= 0 && jr[k] <= g.R + 1 && jc[k] < a.w;
+            pmf_[k] = 0;
+            if (Cfg::geom_of(k) != k) continue;
+            const int r = (jrc[k] >> 16) - 8, c = jrc[k] & 0xffff;
+            const int iy = ty * g.R + r - 1;
+            const bool slot_ok = jg[k] >= 0 && r >= 0 && r <= g.R + 1 && c < a.w;
             const bool inside = slot_ok && iy >= 0 && iy < a.h;
-            const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = jc[k] < a.w ? jc[k] : a.w - 1;
-            pm_[k] = (img * a.h + cy) * a.w + cx;
-            fl_[k] = (inside ? 1 : 0) | ((inside && jr[k] >= 1 && jr[k] <= g.R) ? 2 : 0);
+            const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = c < a.w ? c : a.w - 1;
+            pmf_[k] = (((img * a.h + cy) * a.w + cx) << 2) | (inside ? 1 : 0) | ((inside && r >= 1 && r <= g.R) ? 2 : 0);
         }
     };
     // phase A's activation fragments of one k32 stage: lane (pixel, hi) reads channels 32 j + 16 s + 8 hi .. + 7 of its pixel (the cv1-half job of a group loads, its cv2 half shares)
@@ -233,12 +224,12 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
     for (int k = 0; k < NHJ; ++k)
 #pragma unroll
         for (int s = 0; s < 2; ++s) xn[k][s] = frag{};
-    auto load_x = [&](int j, const int (&pm_)[NHJ]) {
+    auto load_x = [&](int j, const int (&pmf_)[NHJ]) {
 #pragma unroll
         for (int k = 0; k < NHJ; ++k) {
             if (!Cfg::maybe_w1(k)) continue;
             if (jg[k] >= 0 && jh[k] == 0) {   // wave-uniform
-                const uint16_t* px = a.x + (int64_t)pm_[k] * a.x_cs + 32 * j + 8 * hi;
+                const uint16_t* px = a.x + (int64_t)(pmf_[Cfg::geom_of(k)] >> 2) * a.x_cs + 32 * j + 8 * hi;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) xn[k][s] = *reinterpret_cast<const frag*>(px + 16 * s);
             }
@@ -252,14 +243,14 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
     // prologue: stages 0 and 1 (and the first tile's first activation fragments between them: the order every later step keeps)
     pend = issue_stage(0, 0);
     if (has_a) {
-        tile_geom(xcd_remap(idx, ntiles), pm, fl);
-        load_x(0, pm);
+        tile_geom(xcd_remap(idx, ntiles), pmf);
+        load_x(0, pmf);
     }
     pend = issue_stage(1, 1);
 
     for (; idx < ntiles; idx += gridDim.x) {
         const bool more = idx + (int)gridDim.x < ntiles;
-        tile_geom(xcd_remap(idx, ntiles), pm, fl);
+        tile_geom(xcd_remap(idx, ntiles), pmf);
         ts = 0;
 
         // packets: pk[k] = the rounded outputs of half-job k -- cv1's (k even, or a halo-only job) or cv2's (jh[k] == 1) -- as 16-byte channel octets
@@ -284,7 +275,7 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
                 for (int k = 0; k < NHJ; ++k)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) xc[k][s] = xn[k][s];
-                if (j + 1 < a.nst_a) load_x(j + 1, pm);
+                if (j + 1 < a.nst_a) load_x(j + 1, pmf);
                 step_issue(more);
                 const unsigned char* const ws = ring + cur * SLOT + lane * 16;
 #pragma unroll
@@ -310,8 +301,8 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
 #pragma unroll
                 for (int k = 1; k < NHJ; k += 2) {
                     if (jg[k] < 0 || jh[k] != 1) continue;
-                    if (fl[k] & 2) {
-                        uint16_t* yp = a.y2_out + (int64_t)pm[k] * a.y2_cs + 8 * hi;
+                    if (pmf[Cfg::geom_of(k)] & 2) {
+                        uint16_t* yp = a.y2_out + (int64_t)(pmf[Cfg::geom_of(k)] >> 2) * a.y2_cs + 8 * hi;
 #pragma unroll
                         for (int i = 0; i < NP; ++i)
 #pragma unroll
@@ -326,7 +317,8 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
             for (int k = 0; k < NHJ; ++k) {
                 if (jg[k] < 0) continue;
                 if (jh[k] == 1 && !has_d) continue;
-                const uint16_t* src = jh[k] == 1 ? a.y2_in + (int64_t)pm[k] * a.y2_cs : a.y1_in + (int64_t)pm[k] * a.y1i_cs;
+                const int64_t m = pmf[Cfg::geom_of(k)] >> 2;
+                const uint16_t* src = jh[k] == 1 ? a.y2_in + m * a.y2_cs : a.y1_in + m * a.y1i_cs;
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
@@ -369,7 +361,7 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
                 for (int i = 0; i < NP; ++i) {
                     u32x4 o[2];
                     silu_pack_subtile<DT, false, true>(accb[k][i], none, o);
-                    if (!(fl[k] & 1)) o[0] = o[1] = u32x4{0u, 0u, 0u, 0u};
+                    if (!(pmf[k] & 1)) o[0] = o[1] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(tq + i * plane_b + (((2 * p + hi) ^ swz) * 16)) = o[p];
                 }
@@ -381,6 +373,24 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
 #pragma unroll
         for (int c = 0; c < GC; ++c) cj[c] = jg[2 * c + 1] >= 0 && jh[2 * c + 1] == 1;   // wave-uniform
         {
+            // LDS byte offsets of the nine taps' fragments (k16 half 0; half 1 = ^ 32) inside a plane.  Slot q' = q + (dy - 1) pw + (dx - 1) holds its four 16-byte channel
+            // octets at q' * 64 + ((octet ^ ((q' >> 2) & 3)) * 16): 32 CONSECUTIVE slots under any constant shift cover every 16-byte bank slot once per ds_read_b128 lane
+            // group (MI355X_MICROARCH.md, LDS).  Lanes whose slot is no output pixel read a safe slot (results never stored).  Recomputed per tile on purpose (the
+            // opaque `fr`): kept across the other phases the 9 GC offsets cost registers the 1x1 phases do not have.
+            int fr = frow;
+            asm volatile("" : "+v"(fr));
+            int ea[GC][9];
+#pragma unroll
+            for (int c = 0; c < GC; ++c) {
+                const int r = (jrc[2 * c] >> 16) - 8, cc = jrc[2 * c] & 0xffff;
+                const bool out_px = jg[2 * c] >= 0 && r >= 1 && r <= g.R && cc < a.w;
+                const int q = out_px ? jg[2 * c] * 32 + fr : g.delta + g.pw;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int qs = q + (t / 3 - 1) * g.pw + (t % 3 - 1);
+                    ea[c][t] = qs * 64 + ((hi ^ ((qs >> 2) & 3)) * 16);
+                }
+            }
             f32x16 acc[GC][NP];
 #pragma unroll
             for (int c = 0; c < GC; ++c)
@@ -429,8 +439,8 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
                     pk[2 * c][i][1] = o[1];
                 }
                 if (!has_d) {   // HEAD / MID: the Bottleneck's output goes to memory
-                    if (fl[2 * c] & 2) {
-                        uint16_t* yp = a.y1_out + (int64_t)pm[2 * c] * a.y1o_cs + 8 * hi;
+                    if (pmf[2 * c] & 2) {
+                        uint16_t* yp = a.y1_out + (int64_t)(pmf[2 * c] >> 2) * a.y1o_cs + 8 * hi;
 #pragma unroll
                         for (int i = 0; i < NP; ++i)
 #pragma unroll
@@ -453,8 +463,8 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
                 step_wait();
                 if constexpr (j == 2 * NP - 1) {   // the tile's last step: the next tile's first activation fragments go ahead of its stage 1
                     if (more && has_a) {
-                        int pmn[NHJ], fln[NHJ];
-                        tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn, fln);
+                        int pmn[NHJ];
+                        tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
                         load_x(0, pmn);
                     }
                 }
@@ -474,12 +484,12 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
 #pragma unroll
             for (int c = 0; c < GC; ++c) {
                 if (!cj[c]) continue;
-                uint16_t* yp = a.y + (int64_t)pm[2 * c] * a.y_cs + 8 * hi;
+                uint16_t* yp = a.y + (int64_t)(pmf[2 * c] >> 2) * a.y_cs + 8 * hi;
 #pragma unroll
                 for (int i = 0; i < 2 * NP; ++i) {
                     u32x4 o[2];
                     silu_pack_subtile<DT, false, true>(acc[c][i], none, o);
-                    if (fl[2 * c] & 2) {
+                    if (pmf[2 * c] & 2) {
 #pragma unroll
                         for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = o[p];
                     }
@@ -488,8 +498,8 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
             }
         } else if (more && has_a) {
             // HEAD: the next tile's first activation fragments (issued after this tile's stores: the next wait is vmcnt(0) anyway)
-            int pmn[NHJ], fln[NHJ];
-            tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn, fln);
+            int pmn[NHJ];
+            tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
             load_x(0, pmn);
         }
     }

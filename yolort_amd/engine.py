@@ -180,6 +180,9 @@ class Plan:
         # round 3: bit-identical to the three launches it replaces (tests/test_c3_fused_gpu.py) and 91 vs 196 us on the 160x160 level of
         # the bs-32 yolov5s plan (profiles/r03a_c3fused_ab.txt); YOLORT_AMD_FUSE_C3=0 restores the separate launches
         self.fuse_c3 = os.environ.get("YOLORT_AMD_FUSE_C3", "1") != "0"
+        # round 6: C3 blocks of 64 / 128 hidden channels (yolov5s' 80 x 80 and 40 x 40 levels) through the strip kernel (csrc/c3_tile.hip): one launch per block
+        # (one Bottleneck) or per Bottleneck (HEAD / MID / TAIL); bit-identical to the separate launches; YOLORT_AMD_C3_TILE=0 restores those
+        self.c3_tile_on = os.environ.get("YOLORT_AMD_C3_TILE", "1") != "0"
         # Tile selection is DETERMINISTIC: a pinned per-(shape, dtype) table for gfx950 committed in-tree
         # (yolort_amd/data/tiles_gfx950.json, produced by tools/tune_tiles.py on an MI355X) and, for shapes it does not hold,
         # the library's shape heuristic (tile 0).  Different tiles accumulate K in different orders, so a timing-based choice
@@ -207,6 +210,7 @@ class Plan:
             self.use_v1 = os.environ.get("YOLORT_AMD_F32_V1", "0") == "1"
             self.chain_1x1, self.chain_cv3 = False, False
             self.fuse_c3 = False
+            self.c3_tile_on = False
             self.chain_next = False
 
     def __del__(self):
@@ -541,6 +545,69 @@ class Plan:
         self._record(self.lib.ymi_plan_add_c3_fused(self.handle, C.byref(d)), name, kind="conv", flops=flops, bytes=nbytes, ref_convs=5, tile=-1,
                      shape=f"C3 {x.c}->{pc3.cout} hidden {c_} n1 {x.h}x{x.w}")
         return out
+
+    def c3_tile_ok(self, x: View, c_: int) -> bool:
+        """does the strip kernel (csrc/c3_tile.hip) hold a geometry for a C3 of hidden width c_ over x?"""
+        if self.fp32 or self.use_v1 or not self.c3_tile_on or c_ not in (64, 128) or x.c % 32 or x.cs % 8 or x.dtype != self.dtype:
+            return False
+        d = C3Desc()
+        d.n, d.h, d.w, d.c_hidden, d.c_out = x.n, x.h, x.w, c_, 2 * c_
+        return bool(self.lib.ymi_c3_tile_supported(C.byref(d)))
+
+    def c3_tile(self, mode: int, pcm1: PackedConv, pcm2: PackedConv, shortcut: bool, x: Optional[View] = None, pc12: Optional[PackedConv] = None,
+                pc3: Optional[PackedConv] = None, out: Optional[View] = None, y1_in: Optional[View] = None, y1_out: Optional[View] = None,
+                y2: Optional[View] = None, name: str = "c3.tile") -> Optional[View]:
+        """One launch of the strip kernel (ymi_c3_fused, instance (2) of include/yolort_amd.h; reference common.py:172-173 with :115-116 inlined):
+        mode 0 the whole one-Bottleneck block x -> out; 1 HEAD x -> y1_out, y2; 2 MID y1_in -> y1_out; 3 TAIL y1_in, y2 -> out.
+        Bit-identical to the separate launches (1x1: k ascending; 3x3: the LDS-halo kernels' order)."""
+        c_ = pcm1.cout
+        has_a, has_d = mode in (0, 1), mode in (0, 3)
+        src = x if has_a else y1_in
+        if src is None or (has_a and pc12 is None) or (has_d and pc3 is None):
+            raise YmiError(f"{name}: mode {mode} is missing an operand")
+        if has_d and out is None:
+            out = self.alloc(src.n, src.h, src.w, pc3.cout)
+        if ((pcm1.kh, pcm1.kw, pcm2.kh, pcm2.kw) != (1, 1, 3, 3) or pcm1.cin != c_ or pcm2.cin != c_ or pcm2.cout != c_
+                or (has_a and ((pc12.kh, pc12.kw) != (1, 1) or pc12.cin != x.c or pc12.cout != 2 * c_))
+                or (has_d and ((pc3.kh, pc3.kw) != (1, 1) or pc3.cin != 2 * c_ or pc3.cout != 2 * c_ or (out.n, out.h, out.w, out.c) != (src.n, src.h, src.w, 2 * c_)))
+                or (not has_a and y1_in.c != c_) or (not has_d and (y1_out is None or (y1_out.n, y1_out.h, y1_out.w, y1_out.c) != (src.n, src.h, src.w, c_)))
+                or (mode in (1, 3) and (y2 is None or (y2.n, y2.h, y2.w, y2.c) != (src.n, src.h, src.w, c_)))):
+            raise YmiError(f"{name}: the packed convolutions / views do not form mode {mode} of a C3 with {c_} hidden channels")
+        d = C3Desc()
+        d.n, d.h, d.w, d.dtype = src.n, src.h, src.w, dtype_code(self.dtype)
+        d.c_in, d.c_hidden, d.c_out, d.n_bottlenecks, d.shortcut, d.mode = (x.c if has_a else c_), c_, 2 * c_, 1, 1 if shortcut else 0, mode
+        if has_a:
+            d.x, d.x_cstride = x.ptr, x.cs
+            d.w12, d.b12, d.k12_pad = pc12.w.data_ptr(), pc12.bias.data_ptr(), pc12.k_pad
+        else:
+            d.y1_in, d.y1_in_cstride = y1_in.ptr, y1_in.cs
+        d.wm1, d.bm1, d.km1_pad = pcm1.w.data_ptr(), pcm1.bias.data_ptr(), pcm1.k_pad
+        d.wm2, d.bm2, d.km2_pad = pcm2.w.data_ptr(), pcm2.bias.data_ptr(), pcm2.k_pad
+        if has_d:
+            d.y, d.y_cstride = out.ptr, out.cs
+            d.w3, d.b3, d.k3_pad = pc3.w.data_ptr(), pc3.bias.data_ptr(), pc3.k_pad
+        else:
+            d.y1_out, d.y1_out_cstride = y1_out.ptr, y1_out.cs
+        if mode in (1, 3):
+            d.y2, d.y2_cstride = y2.ptr, y2.cs
+        nb = int(self.lib.ymi_c3_blob_bytes(C.byref(d)))
+        if nb <= 0:
+            raise YmiError(f"{name}: no weight stream layout for this descriptor")
+        blob = torch.empty(nb, device=self.device, dtype=torch.uint8)
+        check(self.lib.ymi_c3_pack(C.byref(d), blob.data_ptr(), _lib.stream_ptr() if self.device.type == "cuda" else None), "ymi_c3_pack")
+        d.wblob = blob.data_ptr()
+        self.keep.extend([pc12, pcm1, pcm2, pc3, blob, d])
+        npix, esz = src.n * src.h * src.w, 2
+        # the reference convolutions this launch stands for: (cin, cout, taps); every one reads its input once and writes its output once (SURVEY.md 8d)
+        convs = ([(x.c, c_, 1), (x.c, c_, 1)] if has_a else []) + [(c_, c_, 1), (c_, c_, 9)] + ([(2 * c_, 2 * c_, 1)] if has_d else [])
+        flops = sum(2.0 * npix * ci * co * k for ci, co, k in convs)
+        nbytes = float(sum(npix * esz * (ci + co) + esz * ci * co * k for ci, co, k in convs))
+        self.io[self.num_ops] = {"name": name, "x": x, "y": out, "y2": y2, "split": 0, "up2": None, "res": None, "chain_y": None, "chain_x2": None,
+                                 "stride": (1, 1), "pad": (0, 0), "fused_c3": True, "c3_mode": mode, "y1_in": y1_in, "y1_out": y1_out, "shortcut": bool(shortcut)}
+        what = {0: "C3", 1: "C3 head", 2: "Bottleneck", 3: "C3 tail"}[mode]
+        self._record(self.lib.ymi_plan_add_c3_fused(self.handle, C.byref(d)), name, kind="conv", flops=flops, bytes=nbytes, ref_convs=len(convs), tile=-3,
+                     shape=f"{what} {(x.c if has_a else c_)}->{2 * c_ if has_d else c_} hidden {c_} {src.h}x{src.w}")
+        return out if has_d else y1_out
 
     def spp_pool(self, buf: View, c: int, name: str = "spp_pool") -> None:
         assert buf.c == 4 * c

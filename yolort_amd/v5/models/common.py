@@ -162,6 +162,24 @@ class C3(HipModule):
             b0 = self.m[0]
             return plan.c3_fused(x, self.packed_pair(plan.dtype, plan.device, x.c), b0.cv1.packed(plan.dtype, plan.device, c_),
                                  b0.cv2.packed(plan.dtype, plan.device, c_), self.cv3.packed(plan.dtype, plan.device, 2 * c_), out=out, name=name + ".fused")
+        # round 6 (csrc/c3_tile.hip): hidden widths 64 / 128 on maps whose halo strip of whole rows fits the LDS patch -- the whole block in one launch, or
+        # one launch per Bottleneck (HEAD, MID ..., TAIL); intermediates of a launch never reach memory, weights stream in fragment order
+        if (nb >= 1 and self.cv3.conv.out_channels == 2 * c_ and getattr(plan, "c3_tile_on", False) and plan.c3_tile_ok(x, c_)
+                and all(isinstance(b, Bottleneck) and b.cv1.conv.kernel_size == (1, 1) and b.cv2.conv.kernel_size == (3, 3) and b.cv2.conv.stride == (1, 1)
+                        and b.cv2.conv.groups == 1 and b.cv1.conv.out_channels == c_ and b.cv2.conv.out_channels == c_ and b.add == self.m[0].add
+                        and isinstance(b.cv1.act, nn.SiLU) and isinstance(b.cv2.act, nn.SiLU) for b in self.m)
+                and all(isinstance(c.act, nn.SiLU) for c in (self.cv1, self.cv2, self.cv3)) and (out is None or out.cs % 8 == 0)):
+            pk = lambda cv, cin: cv.packed(plan.dtype, plan.device, cin)  # noqa: E731
+            pc12, pc3 = self.packed_pair(plan.dtype, plan.device, x.c), pk(self.cv3, 2 * c_)
+            add = bool(self.m[0].add)
+            if nb == 1:
+                return plan.c3_tile(0, pk(self.m[0].cv1, c_), pk(self.m[0].cv2, c_), add, x=x, pc12=pc12, pc3=pc3, out=out, name=name + ".tile")
+            y2 = plan.alloc(x.n, x.h, x.w, c_)
+            ping = [plan.alloc(x.n, x.h, x.w, c_), plan.alloc(x.n, x.h, x.w, c_) if nb > 2 else None]
+            cur = plan.c3_tile(1, pk(self.m[0].cv1, c_), pk(self.m[0].cv2, c_), add, x=x, pc12=pc12, y1_out=ping[0], y2=y2, name=name + ".tile.cv1+cv2+m.0")
+            for j in range(1, nb - 1):
+                cur = plan.c3_tile(2, pk(self.m[j].cv1, c_), pk(self.m[j].cv2, c_), add, y1_in=cur, y1_out=ping[j % 2], name=f"{name}.tile.m.{j}")
+            return plan.c3_tile(3, pk(self.m[nb - 1].cv1, c_), pk(self.m[nb - 1].cv2, c_), add, y1_in=cur, y2=y2, pc3=pc3, out=out, name=f"{name}.tile.m.{nb - 1}+cv3")
         cat = plan.alloc(x.n, x.h, x.w, 2 * c_)
         fuse = (not plan.use_v1) and c_ % 8 == 0 and nb >= 1 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
         t0 = None
