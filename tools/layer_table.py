@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
-CONV_LIKE = ("ymi::conv", "spp_pool", "ymi::c3_fused", "ymi::stem_body1")     # kernels that correspond 1:1 to plan ops of kind conv / pool (incl. the fused head)
+CONV_LIKE = ("ymi::conv", "spp_pool", "ymi::c3_fused", "ymi::c3_tile", "ymi::stem_body1")     # kernels that correspond 1:1 to plan ops of kind conv / pool (incl. the fused head)
 STEM = ("conv_stem", "letterbox")     # first kernel of a step
 
 

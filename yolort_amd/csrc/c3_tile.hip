@@ -35,7 +35,23 @@
 
 namespace ymi {
 
-constexpr int C3T_MAXHJ = 6;
+
+// tuning aid (never in the shipped build): -DC3T_DBG=n removes one ingredient to time the rest (results are garbage): 1 MFMAs, 2 DMA sends, 3 SiLU arithmetic, 4 barriers, 5 fragment reads
+#ifndef C3T_DBG
+#define C3T_DBG 0
+#endif
+#ifdef YMI_STAMPS   // tuning aid (never in the shipped build): s_memtime timeline of every wave of the first 256 blocks (tools/stamp_c3t.py); record = id << 56 | cycle
+constexpr int C3T_NSTAMP = 256;
+__device__ unsigned long long ymi_stamps_c3t[256 * 8 * C3T_NSTAMP];
+#define C3T_STAMP(id)                                                                                                                                     \
+    do {                                                                                                                                                  \
+        if (lane == 0 && blockIdx.x < 256 && st_n < C3T_NSTAMP)                                                                                           \
+            ymi_stamps_c3t[(blockIdx.x * 8 + wave) * C3T_NSTAMP + st_n] = ((unsigned long long)(id) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull); \
+        ++st_n;                                                                                                                                           \
+    } while (0)
+#else
+#define C3T_STAMP(id) ((void)0)
+#endif
 
 struct C3TArgs {
     const uint16_t* x;        // modes 0, 1: the block's input (n, h, w, cin)
@@ -48,29 +64,35 @@ struct C3TArgs {
     int n, h, w, cin;
     int x_cs, y_cs, y1i_cs, y1o_cs, y2_cs;
     int mode, shortcut;
-    int nst_a, nst_d;         // stages of phases A / D in this mode (0 when the phase is not part of it)
+    int nst_a, nst_d;         // k32 chunks of phases A (= cin / 32) / D in this mode (0 when the phase is not part of it)
+    int nst_ap;               // ... of phase A in the stream: padded with zero chunks to a multiple of 4 (whole stages, no tail logic in the kernel)
     int bias_off;             // byte offset of the bias section in the blob
 };
 
 struct C3TGeom {
     int R, pw, delta, nslot, tiles_per_img, ntiles;
     unsigned magic_pw;
-    signed char grp[8][C3T_MAXHJ];    // per wave: the patch-slot group of each half-job (-1: none)
-    signed char half[8][C3T_MAXHJ];   // 0: cv1's half of phase A (+ phase B); 1: cv2's half (its group is a centre group: phases C, D)
+    signed char role[8];      // per wave: which static job list it runs (C3TRole)
+    signed char grp[8][3];    // per wave: the patch-slot groups of its jobs (-1: none -- the job runs on clamped addresses and writes nothing)
 };
 
-// CH = hidden width.  NHJ half-jobs per wave: (group, cv1 half) or (group, cv2 half) of phase A; centre job c is the pair (2c, 2c + 1).
-template <int CH> struct C3TCfg;
-template <> struct C3TCfg<128> {   // 40 x 40: a wave owns ONE centre group, or two halo-only groups
-    static constexpr int NP = 4, NHJ = 2, GC = 1;
-    static constexpr bool maybe_w1(int hj) { return true; }
-    static constexpr int geom_of(int hj) { return hj; }           // (half-job 1 is either a second halo-only group or cv2's half of job 0's group: its own geometry)
-};
-template <> struct C3TCfg<64> {    // 80 x 80: a wave owns up to TWO centre groups and one halo-only group
-    static constexpr int NP = 2, NHJ = 5, GC = 2;
-    static constexpr bool maybe_w1(int hj) { return (hj & 1) == 0; }
-    static constexpr int geom_of(int hj) { return hj & ~1; }      // cv2's half shares the geometry of its group's cv1 half
-};
+// CH = hidden width.  A wave's jobs are 32-slot groups: NC CENTRE groups first (they hold output pixels: cv1 | cv2, m.cv1, the 3x3, cv3), then halo-only groups
+// (cv1 and m.cv1 only: the 3x3's input rows above / below the strip).  The job list is STATIC per role so that the MFMA loops are straight-line code.
+template <int CH, int ROLE> struct C3TRole;
+template <> struct C3TRole<128, 0> { static constexpr int NG = 1, NC = 1; };   // 40 x 40: one centre group ...
+template <> struct C3TRole<128, 1> { static constexpr int NG = 2, NC = 0; };   // ... or two halo-only groups
+template <> struct C3TRole<64, 0> { static constexpr int NG = 3, NC = 2; };    // 80 x 80: two centre groups and one halo-only group
+
+#if C3T_DBG == 1
+#define C3T_MMA(w, x, acc) (acc)
+#else
+#define C3T_MMA(w, x, acc) Mfma<DT>::run(w, x, acc)
+#endif
+#if C3T_DBG == 3
+#define C3T_SILU false
+#else
+#define C3T_SILU true
+#endif
 
 template <int DT>
 __device__ __forceinline__ typename Mfma<DT>::frag c3t_frag(const u32x4& p) {
@@ -90,44 +112,136 @@ __device__ __forceinline__ f32x16 c3t_bias_acc(const f32x4* bl, int group, int h
     return acc;
 }
 
-template <int DT, int CH>
-__global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3TGeom g) {
-    typedef C3TCfg<CH> Cfg;
-    constexpr int NP = Cfg::NP, NHJ = Cfg::NHJ, GC = Cfg::GC;
-    constexpr int SLOT = 6 * NP * 1024;                       // ring slot = the largest stage (one kernel row of one 32-channel chunk of the 3x3)
-    constexpr int NPC_A = 4 * NP, NPC_B = 2 * NP, NPC_C = 6 * NP;   // 1 KiB pieces per stage (phase D = A's size)
-    constexpr int PW_A = (NPC_A + 7) / 8, PW_B = (NPC_B + 7) / 8, PW_C = (NPC_C + 7) / 8;   // ... issued per wave (surplus slots re-send the last piece)
+// Explicitly scheduled fragment reads.  hipcc sinks a plain LDS load to just in front of its first use and waits for it with lgkmcnt(0): every MFMA group then
+// starts with an exposed LDS round trip (measured on this kernel: SQ_WAIT_ANY 48 % of the wave cycles at 21 % LDS utilisation, profiles/r06e_pmc_c3t.txt).  Here
+// the reads are inline assembly (hipcc neither moves nor counts them), issued one whole sub-step ahead into a three-deep register ring, and the wait that releases
+// a sub-step's fragments is a counted lgkmcnt that names them as operands (so the MFMAs that use them cannot be scheduled above it).  An outstanding scalar load of
+// the compiler's can only make the count stricter.  On the CPU simulator (YMI_HIPSIM) the reads are plain loads and the waits nothing.
+__device__ __forceinline__ unsigned c3t_lds_addr(const unsigned char* p) {
+#ifdef YMI_HIPSIM
+    (void)p;
+    return 0u;
+#else
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+#endif
+}
+template <int OFF, class F>
+__device__ __forceinline__ void c3t_lds_read(F& dst, const unsigned char* p, unsigned lds_addr) {
+#ifdef YMI_HIPSIM
+    (void)lds_addr;
+    dst = *reinterpret_cast<const F*>(p + OFF);
+#else
+    (void)p;
+#if C3T_DBG == 5
+    asm volatile("" : "=v"(dst) : "v"(lds_addr));
+#else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+#endif
+#endif
+}
+template <int N, class F>
+__device__ __forceinline__ void c3t_lds_wait(F& first) {   // at most N LDS reads of this wave still in flight; `first` (and, through c3t_lds_dep, the others) become available here
+#ifdef YMI_HIPSIM
+    (void)first;
+#else
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(N));
+#endif
+}
+template <class F>
+__device__ __forceinline__ void c3t_lds_dep(F& f) {
+#ifndef YMI_HIPSIM
+    asm volatile("" : "+v"(f));
+#else
+    (void)f;
+#endif
+}
+
+// Phase A's activation fragments come through vector memory one or two k32 chunks ahead.  As plain loads hipcc waits for them with vmcnt(0) at every control-flow
+// merge (the unit guards, the sender's branches): the whole prefetch ring drains at each chunk.  As inline assembly it neither moves nor counts them; the consumer
+// waits with a COUNTED vmcnt computed from this wave's own issue sequence numbers (loads retire in order).
+template <class F>
+__device__ __forceinline__ void c3t_gload(F& dst, const char* base_uniform, unsigned voff) {
+#ifdef YMI_HIPSIM
+    dst = *reinterpret_cast<const F*>(base_uniform + voff);
+#else
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base_uniform));
+#endif
+}
+
+__device__ __forceinline__ void c3t_wait_vmcnt(int n) {   // at most n vector-memory operations of this wave still in flight (a smaller count is always safe)
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        case 17: wait_vmcnt<17>(); break;
+        default: wait_vmcnt<18>(); break;
+    }
+}
+
+// byte offset of weight fragment (sub-step, cout group i) inside one k32 chunk of [cv1 | cv2] / cv3 rows, and inside one k64 group of m.cv1 rows (see ymi_c3_pack)
+template <int NP> struct C3TOffAD { static constexpr int at(int sub, int i) { return (((sub & 1) * NP + i) * 2 + (sub >> 1)) * 1024; } };   // phases A (centre roles) / D: sub = (k16 half s, lower / upper CH rows)
+template <int NP> struct C3TOffAH { static constexpr int at(int sub, int i) { return (i * 2 + sub) * 1024; } };                              // phase A, halo-only role: cv1's rows only, sub = s
+template <int NP> struct C3TOffB { static constexpr int at(int sub, int i) { return (i * 4 + sub) * 1024; } };                               // phase B: sub = k16 step of the k64 group
+
+template <int DT, int CH, int ROLE>
+__device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsigned char* const c3t_sm, const int wave, const int lane) {
+    typedef C3TRole<CH, ROLE> Role;
+    constexpr int NP = CH / 32, NG = Role::NG, NC = Role::NC, NCA = NC > 0 ? NC : 1;
+    // The weight ring: TWO slots of 36 KiB.  A stage is as many whole units of its phase as fit a slot -- few, long steps: every step costs a barrier, a planning
+    // pass and an exposed first LDS round trip whatever its length (measured: 34 of 56 us remained with the MFMAs removed at 30 steps per strip, profiles/r06g_dbg.txt)
+    //   A / D   unit = one k32 chunk of the 2 CH stacked rows (4 NP KiB);   B   the whole of m.cv1 (2 NP^2 KiB);   C   unit = one tap of one k32 chunk (2 NP KiB)
+    constexpr int SLOT = 36 * 1024;
+    constexpr int CB = 4 * NP * 1024;                         // bytes of an A / D chunk (= of a k64 group of phase B)
+    constexpr int KC = SLOT / CB;                             // chunks per A / D stage: 2 (CH 128) / 4 (CH 64)
+    constexpr int NGB = NP / 2;                               // k64 groups of phase B (one stage)
+    constexpr int TAPB = 2 * NP * 1024;                       // bytes of a tap
+    constexpr int TPS = SLOT / TAPB;                          // taps per C stage: 4 (CH 128) / 9 (CH 64)
+    constexpr int NTAP = 9 * NP;                              // taps of the 3x3 in sending order (chunk, dy, dx)
+    constexpr int NSTC = NTAP / TPS, NSTD = 2 * NP / KC;      // stages of phases C / D
+    static_assert(NTAP % TPS == 0 && (2 * NP) % KC == 0 && NGB * CB <= SLOT, "whole stages");
+    constexpr int SZ_A = KC * CB, SZ_B = NGB * CB, SZ_C = TPS * TAPB;
+    constexpr int PWMAX = (SLOT / 1024 + 7) / 8;              // pieces a wave sends per stage, at most
     constexpr int BIAS_BYTES = 6 * NP * 32 * 4;               // b12 (2 CH) | bm1 | bm2 | b3 (2 CH)
     constexpr int BG_M1 = 2 * NP, BG_M2 = 3 * NP, BG_3 = 4 * NP;   // 32-cout group index of each bias section (b12 starts at 0)
     typedef typename Mfma<DT>::frag frag;
-    static_assert(PW_A <= 3 && PW_B <= 3 && PW_C <= 3, "the counted waits below know 0 .. 3 pieces");
-    static_assert(2 * GC + (NHJ & 1) == NHJ, "centre job c = half-jobs (2c, 2c + 1)");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char c3t_sm[];
-    f32x4* const bl = reinterpret_cast<f32x4*>(c3t_sm);
+    const f32x4* const bl = reinterpret_cast<const f32x4*>(c3t_sm);
     unsigned char* const T = c3t_sm + BIAS_BYTES;
     const int plane_b = g.nslot * 64;                         // one 32-channel plane of the patch
     unsigned char* const ring = T + NP * plane_b;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, frow = lane & 31;
+    const unsigned l16 = (unsigned)lane * 16u;
+#ifdef YMI_STAMPS
+    int st_n = 1;
+#endif
 
-    const bool has_a = a.nst_a > 0, has_d = a.nst_d > 0;     // block-uniform
-    const int S = a.nst_a + 4 * NP + a.nst_d;                 // stages per tile
-    const int off_b = a.nst_a * NPC_A * 1024, off_c = off_b + NP * NPC_B * 1024, off_d = off_c + 3 * NP * NPC_C * 1024;
+    const bool has_a = a.nst_a > 0, has_d = a.nst_d > 0;     // block-uniform (nst_a = k32 chunks of phase A)
+    const int off_b = a.nst_ap * CB, off_c = off_b + SZ_B, off_d = off_c + NTAP * TAPB;
+    const int stream_end = off_d + (has_d ? 2 * NP * CB : 0);
 
-    for (int i = tid; i < BIAS_BYTES / 16; i += 512) bl[i] = *reinterpret_cast<const f32x4*>(a.blob + a.bias_off + i * 16);
+    const int ntiles = g.ntiles;
+    int idx = blockIdx.x;
+    const int my_tiles = (ntiles - idx + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles this block walks
 
-    // ---- this wave's half-jobs and the per-lane patch geometry of their slots q = group * 32 + frow = delta + r * pw + c (packed: (r + 8) << 16 | c) ----
-    int jg[NHJ], jh[NHJ], jrc[NHJ];
+    // ---- this wave's groups and the per-lane patch geometry of their slots q = group * 32 + frow = delta + r * pw + c (packed: (r + 8) << 16 | c) ----
+    int jg[NG], jrc[NG];
 #pragma unroll
-    for (int k = 0; k < NHJ; ++k) {
+    for (int k = 0; k < NG; ++k) {
         jg[k] = g.grp[wave][k];
-        jh[k] = g.half[wave][k];
-        jrc[k] = 0;
-        if (Cfg::geom_of(k) != k) continue;
         const int q = (jg[k] >= 0 ? jg[k] : 0) * 32 + frow;
         const int qq = q - g.delta;
         const int qp = qq >= 0 ? qq : 0;
@@ -136,80 +250,108 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
     }
     const u32x2 none[4] = {};
 
-    // ---- the weight ring: flat stage sequence of a tile = [A: nst_a][B: NP][C: 3 NP][D: nst_d]; stage ts of the NEXT tile follows the last one ----
-    int ts = 0;                 // tile-local index of the stage being consumed
-    int cur = 0;                // its ring slot
-    int pend = 0;               // pieces this wave issued for the latest stage (0: nothing was issued)
+    // ---- the sender: the stream is contiguous in sending order, so it is a byte cursor that advances by the size of the stage it has just sent (a function of the
+    //      section it is in) and wraps to the next tile's first stage; a step sends the stage the NEXT step consumes into the slot the previous step has released ----
+    int cur = 0;                // ring slot of the stage being consumed
+    int vseq = 0;               // sequence number of the last vector-memory LOAD this wave has issued (pieces, activation fragments, packets); they retire in order
+    int pseq = 0;               // ... of the last piece it has sent
     bool st_pending = false;    // global stores were issued since the last wait: loads and stores retire out of order with each other -> the next wait is vmcnt(0)
-    auto issue_stage = [&](int s_idx, int slot) -> int {   // returns the number of pieces this wave issued
-        unsigned char* const dst = ring + slot * SLOT;
-        const unsigned char* src;
-        auto send = [&](int npieces, auto pwt) {
-            constexpr int pw_n = decltype(pwt)::value;
+    int cursor = 0;             // byte offset of the next stage to send
+    int sent_slot = 0;          // ring slot it goes to
+    constexpr int PW = PWMAX;   // pieces EVERY wave sends per stage (CH 128: every stage is 32 pieces = 4 per wave; CH 64: 8 .. 36 pieces, surplus slots re-send the last piece:
+                                // identical bytes) -- no branch: hipcc counts the vector-memory operations in flight only along straight-line code
+    auto send_stage = [&]() {
+        const int sz = cursor < off_b ? SZ_A : (cursor < off_c ? SZ_B : (cursor < off_d ? SZ_C : SZ_A));
+        const unsigned char* const src = a.blob + cursor;
+        unsigned char* const dst = ring + sent_slot * SLOT;
+        const int np = sz >> 10;
+        cursor += sz;
+        cursor = cursor >= stream_end ? 0 : cursor;   // (behind the last tile the first stages are sent once more, into slots nobody reads: the kernel drains them before it ends)
+        sent_slot ^= 1;
 #pragma unroll
-            for (int j = 0; j < pw_n; ++j) {
-                int p = wave + 8 * j;
-                p = p < npieces ? p : npieces - 1;
-                glds16(reinterpret_cast<const uint16_t*>(src + p * 1024 + lane * 16), reinterpret_cast<uint16_t*>(dst + p * 1024));
-            }
-        };
-        if (s_idx < a.nst_a) {
-            src = a.blob + s_idx * (NPC_A * 1024);
-            send(NPC_A, std::integral_constant<int, PW_A>{});
-            return PW_A;
+        for (int j = 0; j < PW; ++j) {
+            int p = wave + 8 * j;
+            p = p < np ? p : np - 1;
+            unsigned lo = l16;
+            asm volatile("" : "+v"(lo));   // (opaque: a per-piece lane address hoisted out of the loops costs two registers for the whole kernel -- or a scratch reload in front of the DMA)
+#if C3T_DBG != 2
+            glds16(reinterpret_cast<const uint16_t*>(src + p * 1024 + lo), reinterpret_cast<uint16_t*>(dst + p * 1024));
+#endif
         }
-        s_idx -= a.nst_a;
-        if (s_idx < NP) {
-            src = a.blob + off_b + s_idx * (NPC_B * 1024);
-            send(NPC_B, std::integral_constant<int, PW_B>{});
-            return PW_B;
-        }
-        s_idx -= NP;
-        if (s_idx < 3 * NP) {
-            src = a.blob + off_c + s_idx * (NPC_C * 1024);
-            send(NPC_C, std::integral_constant<int, PW_C>{});
-            return PW_C;
-        }
-        s_idx -= 3 * NP;
-        src = a.blob + off_d + s_idx * (NPC_A * 1024);
-        send(NPC_A, std::integral_constant<int, PW_A>{});
-        return PW_A;
-    };
-    // top of a step: this wave's pieces of the current stage have landed (everything it issued before the latest stage's pieces), then every wave's
-    auto step_wait = [&]() {
-        if (st_pending || pend == 0) wait_vmcnt<0>();
-        else if (pend == 1) wait_vmcnt<1>();
-        else if (pend == 2) wait_vmcnt<2>();
-        else wait_vmcnt<3>();
-        st_pending = false;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the previous stage / writes of the patch are done
-        __builtin_amdgcn_s_barrier();
+        vseq += PW;
+        pseq = vseq;
+        asm volatile("" ::: "memory");             // the loads a step issues afterwards stay behind its pieces (the count below relies on the order)
         __builtin_amdgcn_sched_barrier(0);
     };
-    // the stage two ahead goes into the slot the previous step has just released (every wave is past this step's barrier) -- the LAST vector-memory operation of a step
-    auto step_issue = [&](bool more_tiles) {
-        int nts = ts + 2;
-        bool ok = true;
-        if (nts >= S) {
-            nts -= S;
-            ok = more_tiles;
-        }
-        const int slot = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
-        pend = ok ? issue_stage(nts, slot) : 0;
+    // Top of a step.  Vector-memory loads retire in order and the pieces of the stage consumed now were sent during the previous step: they have landed when at most as
+    // many loads are in flight as this wave has issued since that send.  Then every wave's (barrier).  The next stage is sent behind the step's first MFMA group: a
+    // burst at the head delays the first fragment reads by the pieces' issue time, and where those MFMAs consume operands that came through vector memory (phase A's
+    // activation fragments, the packets MID / TAIL read) hipcc waits for them with vmcnt(0) whenever pieces whose number depends on control flow are younger.
+    auto step_sync = [&]() {
+        C3T_STAMP(1);
+        c3t_wait_vmcnt(st_pending ? 0 : vseq - pseq);   // at most the loads issued behind the pieces are still in flight
+        st_pending = false;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the previous stage / writes of the patch are done
+        C3T_STAMP(2);
+#if C3T_DBG != 4
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        C3T_STAMP(3);
     };
-    auto step_done = [&]() {
-        ++ts;
-        cur = cur == 2 ? 0 : cur + 1;
+    auto step_end = [&]() {
+        C3T_STAMP(4);
+        cur ^= 1;
+    };
+    // One stage of a 1x1 GEMM phase: `nch` units (k32 chunks / k64 groups, CB bytes each) of NSUB sub-steps of NP weight fragments (Off::at(sub, i) = byte offset
+    // inside the unit), read through a two-deep register ring one sub-step ahead across the units (c3t_lds_read: a buffer is refilled right behind the MFMAs that read
+    // it -- its new contents arrive a full LDS round trip, >= 64 cycles, after the refill issues; the MFMAs, issued before it in order, have read their operands by
+    // then).  mma(kc, sub, w) issues a sub-step's MFMAs.  The reads run one sub-step past the stage's end (bytes of the slot nobody uses: no branch in the loop).
+    const unsigned ring_lds = c3t_lds_addr(ring);
+    auto w_stage = [&](auto nsubt, auto off, auto&& mma) {
+        constexpr int NSUB = decltype(nsubt)::value;
+        static_assert(NSUB == 2 || NSUB == 4, "even: the buffer of a sub-step does not depend on the unit");
+        typedef decltype(off) Off;
+        const unsigned char* const ws0 = ring + cur * SLOT + l16;
+        const unsigned ws0_lds = ring_lds + (unsigned)(cur * SLOT) + l16;
+        const unsigned char *ws = ws0, *wn = ws0;   // this unit's / the next unit's fragments (behind the last unit: the stage's first again -- read, never used)
+        unsigned ws_lds = ws0_lds, wn_lds = ws0_lds;
+        frag w[2][NP];
+        auto rd = [&](auto subt) {   // sub >= NSUB: the next unit's
+            constexpr int sub = decltype(subt)::value;
+            static_for<0, NP>([&](auto it) {
+                constexpr int i = decltype(it)::value;
+                if constexpr (sub < NSUB) c3t_lds_read<Off::at(sub, i)>(w[sub % 2][i], ws, ws_lds);
+                else c3t_lds_read<Off::at(sub - NSUB, i)>(w[sub % 2][i], wn, wn_lds);
+            });
+        };
+        rd(std::integral_constant<int, 0>{});
+        rd(std::integral_constant<int, 1>{});
+        static_for<0, KC>([&](auto kct) {   // (units are compile-time: phase A's activation ring is indexed by them)
+            constexpr int kc = decltype(kct)::value;
+            wn = kc + 1 < KC ? ws + CB : ws0;
+            wn_lds = kc + 1 < KC ? ws_lds + CB : ws0_lds;
+            static_for<0, NSUB>([&](auto subt) {
+                constexpr int sub = decltype(subt)::value;
+                c3t_lds_wait<NP>(w[sub % 2][0]);
+#pragma unroll
+                for (int i = 1; i < NP; ++i) c3t_lds_dep(w[sub % 2][i]);
+                mma(kct, subt, w[sub % 2]);
+                rd(std::integral_constant<int, sub + 2>{});
+                if constexpr (sub == 0 && kc == 0) send_stage();   // ONE burst behind the first MFMA group (see step_sync)
+                __builtin_amdgcn_sched_barrier(0);                 // (the next sub-step's wait names other registers: without the fence hipcc sinks this group's MFMAs below it)
+            });
+            ws = wn;
+            ws_lds = wn_lds;
+        });
     };
 
-    // per-tile pixel geometry of the half-jobs, packed: pixel index (clamped into the image) * 4 + bit 0 (inside the image; else: zero padding) + bit 1 (an output pixel of this tile)
-    int pmf[NHJ];
-    auto tile_geom = [&](int t, int (&pmf_)[NHJ]) {
+    // per-tile pixel geometry of the groups, packed: pixel index (clamped into the image) * 4 + bit 0 (inside the image; else: zero padding) + bit 1 (an output pixel of this tile)
+    int pmf[NG];
+    auto tile_geom = [&](int t, int (&pmf_)[NG]) {
         const int img = t / g.tiles_per_img, ty = t - img * g.tiles_per_img;
 #pragma unroll
-        for (int k = 0; k < NHJ; ++k) {
-            pmf_[k] = 0;
-            if (Cfg::geom_of(k) != k) continue;
+        for (int k = 0; k < NG; ++k) {
             const int r = (jrc[k] >> 16) - 8, c = jrc[k] & 0xffff;
             const int iy = ty * g.R + r - 1;
             const bool slot_ok = jg[k] >= 0 && r >= 0 && r <= g.R + 1 && c < a.w;
@@ -218,95 +360,121 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
             pmf_[k] = (((img * a.h + cy) * a.w + cx) << 2) | (inside ? 1 : 0) | ((inside && r >= 1 && r <= g.R) ? 2 : 0);
         }
     };
-    // phase A's activation fragments of one k32 stage: lane (pixel, hi) reads channels 32 j + 16 s + 8 hi .. + 7 of its pixel (the cv1-half job of a group loads, its cv2 half shares)
-    frag xn[NHJ][2];
+    // phase A's activation fragments: lane (pixel, hi) reads channels 16 t + 8 hi .. + 7 of its pixel for k16 step t.  They come straight from memory (HBM / the
+    // infinity cache: ~1.4 us per round trip under load, measured as the cost of one more k32 chunk with a one-chunk lookahead) against 0.5-0.6 us of MFMAs per
+    // chunk: a register ring of XF k16 steps per group keeps XF - 1 of them in flight -- slot t % XF is reloaded with step t + XF right after its last use.
+    // Addresses = block-uniform base (x + 32 t bytes) + a 32-bit per-lane byte offset per group (the launcher checks the tensor stays below 2 GiB).
+    constexpr int XF = 2;   // (deeper rings were measured slower: with 256 registers the extra slots spill, and every scratch reload is a vmcnt(0) that drains the ring -- profiles/r06i_*)
+    constexpr int XU = (XF / 2 + KC - 1) / KC;   // stages per trip round the ring (the stage loop is unrolled by it: ring slots are compile-time)
+    static_assert((XU * KC * 2) % XF == 0 && 4 % (XU * KC) == 0, "a stage starts at a fixed ring slot; the stream pads phase A to multiples of 4 chunks");
+    frag xf[NG][XF];
 #pragma unroll
-    for (int k = 0; k < NHJ; ++k)
+    for (int k = 0; k < NG; ++k)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) xn[k][s] = frag{};
-    auto load_x = [&](int j, const int (&pmf_)[NHJ]) {
+        for (int t = 0; t < XF; ++t) xf[k][t] = frag{};
+    unsigned xo[NG];
+    auto x_offsets = [&](const int (&pmf_)[NG]) {
 #pragma unroll
-        for (int k = 0; k < NHJ; ++k) {
-            if (!Cfg::maybe_w1(k)) continue;
-            if (jg[k] >= 0 && jh[k] == 0) {   // wave-uniform
-                const uint16_t* px = a.x + (int64_t)(pmf_[Cfg::geom_of(k)] >> 2) * a.x_cs + 32 * j + 8 * hi;
+        for (int k = 0; k < NG; ++k) xo[k] = ((unsigned)(pmf_[k] >> 2) * (unsigned)a.x_cs + 8u * (unsigned)hi) * 2u;
+    };
+    const int nk16 = 2 * a.nst_a;
+    auto load_x = [&](int t, auto slott) {   // k16 step t (clamped to the last real one: a surplus reload fetches bytes nobody uses, no branch) into ring slot `slot`
+        constexpr int slot = decltype(slott)::value;
+        const int tc = t < nk16 ? t : nk16 - 1;
+        const char* const xb = reinterpret_cast<const char*>(a.x) + (size_t)tc * 32;   // block-uniform
 #pragma unroll
-                for (int s = 0; s < 2; ++s) xn[k][s] = *reinterpret_cast<const frag*>(px + 16 * s);
-            }
-        }
+        for (int k = 0; k < NG; ++k) xf[k][slot] = *reinterpret_cast<const frag*>(xb + xo[k]);
+        vseq += NG;
+    };
+    auto load_x_head = [&]() {   // the first XF steps of a tile
+        static_for<0, XF>([&](auto tt) { load_x(decltype(tt)::value, tt); });
     };
 
-    const int ntiles = g.ntiles;
-    int idx = blockIdx.x;
-    if (idx >= ntiles) return;
-    __syncthreads();   // the biases are in LDS
-    // prologue: stages 0 and 1 (and the first tile's first activation fragments between them: the order every later step keeps)
-    pend = issue_stage(0, 0);
+    // prologue: the first stage, then the first tile's first activation fragments
+    send_stage();
     if (has_a) {
         tile_geom(xcd_remap(idx, ntiles), pmf);
-        load_x(0, pmf);
+        x_offsets(pmf);
+        load_x_head();
     }
-    pend = issue_stage(1, 1);
 
     for (; idx < ntiles; idx += gridDim.x) {
         const bool more = idx + (int)gridDim.x < ntiles;
         tile_geom(xcd_remap(idx, ntiles), pmf);
-        ts = 0;
+        if (has_a) x_offsets(pmf);
+        C3T_STAMP(8);
 
-        // packets: pk[k] = the rounded outputs of half-job k -- cv1's (k even, or a halo-only job) or cv2's (jh[k] == 1) -- as 16-byte channel octets
-        // (cout group i, packet p: octets 2p + hi of the group): exactly the activation fragments of the next 1x1
-        u32x4 pk[NHJ][NP][2];
-#pragma unroll
-        for (int k = 0; k < NHJ; ++k)
-#pragma unroll
-            for (int i = 0; i < NP; ++i) pk[k][i][0] = pk[k][i][1] = u32x4{0u, 0u, 0u, 0u};
+        // packets: the rounded outputs of a 1x1 as 16-byte channel octets (cout group i, packet p: octets 2p + hi of the group) -- exactly the activation fragments
+        // of the next 1x1.  pk1 = cv1's / the Bottleneck's input, later the Bottleneck's output; pk2 = cv2's (centre groups)
+        u32x4 pk1[NG][NP][2], pk2[NCA][NP][2];
+        // the next tile's first activation fragments: issued behind the last MFMA of this tile (ahead of its epilogue)
+        auto prefetch_next_x = [&]() {
+            if (more && has_a) {
+                int pmn[NG];
+                tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
+                x_offsets(pmn);
+                load_x_head();
+            }
+        };
 
         if (has_a) {
-            // ---------------- phase A: cv1 | cv2 over this wave's groups, K = cin ----------------
-            f32x16 acc[NHJ][NP];
+            // ---------------- phase A: cv1 | cv2 over this wave's groups, K = cin; sub-step = (k16 half s, cv1 / cv2 rows): NP weight fragments ----------------
+            f32x16 acc1[NG][NP], acc2[NCA][NP];
 #pragma unroll
-            for (int k = 0; k < NHJ; ++k)
+            for (int i = 0; i < NP; ++i) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) acc[k][i] = c3t_bias_acc(bl, (jh[k] == 1 ? NP : 0) + i, hi);
-            for (int j = 0; j < a.nst_a; ++j) {
-                step_wait();
-                frag xc[NHJ][2];
+                for (int k = 0; k < NG; ++k) acc1[k][i] = c3t_bias_acc(bl, i, hi);
 #pragma unroll
-                for (int k = 0; k < NHJ; ++k)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) xc[k][s] = xn[k][s];
-                if (j + 1 < a.nst_a) load_x(j + 1, pmf);
-                step_issue(more);
-                const unsigned char* const ws = ring + cur * SLOT + lane * 16;
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int k = 0; k < NHJ; ++k) {
-                        if (jg[k] < 0) continue;   // wave-uniform
-                        frag xb = xc[k][s];
-                        if (k > 0 && jh[k] == 1) xb = xc[k > 0 ? k - 1 : 0][s];   // cv2's half of the same group
-                        const unsigned char* const wk = ws + (jh[k] == 1 ? NP * 2048 : 0);
-#pragma unroll
-                        for (int i = 0; i < NP; ++i) acc[k][i] = Mfma<DT>::run(*reinterpret_cast<const frag*>(wk + (i * 2 + s) * 1024), xb, acc[k][i]);
-                    }
-                step_done();
+                for (int k = 0; k < NCA; ++k) acc2[k][i] = c3t_bias_acc(bl, NP + i, hi);
             }
+            for (int j0 = 0; j0 < a.nst_ap; j0 += XU * KC) {   // (the stream pads phase A with zero chunks to whole stages; their activation loads are clamped to the last real k16 step)
+                static_for<0, XU>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value;
+                    const int jb = j0 + u * KC;   // first chunk of this stage
+                    step_sync();
+                    auto mma = [&](auto kct, auto subt, frag (&w)[NP]) {
+                        constexpr int kc = decltype(kct)::value, sub = decltype(subt)::value;
+                        constexpr int s = NC > 0 ? sub >> 1 : sub, half = NC > 0 ? sub & 1 : 0;
+                        constexpr int slot = (2 * (u * KC + kc) + s) % XF;   // ring slot of k16 step 2 (jb + kc) + s
+                        if constexpr (half == 0) {
 #pragma unroll
-            for (int k = 0; k < NHJ; ++k) {
-                if (jg[k] < 0) continue;
+                            for (int k = 0; k < NG; ++k)
 #pragma unroll
-                for (int i = 0; i < NP; ++i) silu_pack_subtile<DT, false, true>(acc[k][i], none, pk[k][i]);
+                                for (int i = 0; i < NP; ++i) acc1[k][i] = C3T_MMA(w[i], xf[k][slot], acc1[k][i]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NC; ++k)
+#pragma unroll
+                                for (int i = 0; i < NP; ++i) acc2[k][i] = C3T_MMA(w[i], xf[k][slot], acc2[k][i]);
+                        }
+                        if constexpr (half == 1 || NC == 0) load_x(2 * (jb + kc) + s + XF, std::integral_constant<int, slot>{});   // the last use of this slot: XF steps ahead
+                    };
+                    if constexpr (NC > 0) w_stage(std::integral_constant<int, 4>{}, C3TOffAD<NP>{}, mma);
+                    else w_stage(std::integral_constant<int, 2>{}, C3TOffAH<NP>{}, mma);
+                    step_end();
+                });
+            }
+            pseq = vseq;   // (the surplus reloads behind the last chunk are dead and may not have been issued at all: do not count on them -- the next wait is vmcnt(0))
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+#pragma unroll
+                for (int t = 0; t < XF; ++t) xf[k][t] = frag{};   // (the ring is dead until the next tile's head loads: say so, or its registers stay reserved through phases B - D)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+#pragma unroll
+                for (int k = 0; k < NG; ++k) silu_pack_subtile<DT, false, C3T_SILU>(acc1[k][i], none, pk1[k][i]);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) silu_pack_subtile<DT, false, C3T_SILU>(acc2[k][i], none, pk2[k][i]);
             }
             if (a.mode == 1) {   // HEAD: cv2(x) goes to memory for the TAIL launch
 #pragma unroll
-                for (int k = 1; k < NHJ; k += 2) {
-                    if (jg[k] < 0 || jh[k] != 1) continue;
-                    if (pmf[Cfg::geom_of(k)] & 2) {
-                        uint16_t* yp = a.y2_out + (int64_t)(pmf[Cfg::geom_of(k)] >> 2) * a.y2_cs + 8 * hi;
+                for (int k = 0; k < NC; ++k) {
+                    if (pmf[k] & 2) {
+                        uint16_t* yp = a.y2_out + (int64_t)(pmf[k] >> 2) * a.y2_cs + 8 * hi;
 #pragma unroll
                         for (int i = 0; i < NP; ++i)
 #pragma unroll
-                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = pk[k][i][p];
+                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = pk2[k][i][p];
                     }
                     st_pending = true;
                 }
@@ -314,53 +482,75 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
         } else {
             // MID / TAIL: the Bottleneck's input (and, TAIL, cv2(x)) arrive from memory in packet form
 #pragma unroll
-            for (int k = 0; k < NHJ; ++k) {
-                if (jg[k] < 0) continue;
-                if (jh[k] == 1 && !has_d) continue;
-                const int64_t m = pmf[Cfg::geom_of(k)] >> 2;
-                const uint16_t* src = jh[k] == 1 ? a.y2_in + m * a.y2_cs : a.y1_in + m * a.y1i_cs;
+            for (int k = 0; k < NG; ++k) {
+                const uint16_t* src = a.y1_in + (int64_t)(pmf[k] >> 2) * a.y1i_cs + 8 * hi;
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) pk[k][i][p] = *reinterpret_cast<const u32x4*>(src + i * 32 + p * 16 + 8 * hi);
+                    for (int p = 0; p < 2; ++p) pk1[k][i][p] = *reinterpret_cast<const u32x4*>(src + i * 32 + p * 16);
             }
+            if (has_d) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const uint16_t* src = a.y2_in + (int64_t)(pmf[k] >> 2) * a.y2_cs + 8 * hi;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) pk2[k][i][p] = *reinterpret_cast<const u32x4*>(src + i * 32 + p * 16);
+                }
+            }
+            vseq += NG * NP * 2 + (has_d ? NC * NP * 2 : 0);
         }
 
-        // ---------------- phase B: t = m.cv1(x1) for every group of this wave, K = CH from the packets; t -> the LDS patch, zero outside the image ----------------
+        C3T_STAMP(9);
+        // ---------------- phase B: t = m.cv1(x1) for every group of this wave, K = CH from the packets (ONE stage); t -> the LDS patch, zero outside the image ----------------
         {
-            f32x16 accb[NHJ][NP];
+            f32x16 accb[NG][NP];
 #pragma unroll
-            for (int k = 0; k < NHJ; ++k)
+            for (int k = 0; k < NG; ++k)
 #pragma unroll
                 for (int i = 0; i < NP; ++i) accb[k][i] = c3t_bias_acc(bl, BG_M1 + i, hi);
-            static_for<0, NP>([&](auto jt) {
-                constexpr int j = decltype(jt)::value;
-                step_wait();
-                step_issue(more);
-                const unsigned char* const ws = ring + cur * SLOT + lane * 16;
+            step_sync();
+            {
+                // (the k64 groups are compile-time: the packet index is)
+                const unsigned char* ws = ring + cur * SLOT + l16;
+                const unsigned ws_lds = ring_lds + (unsigned)(cur * SLOT) + l16;
+                frag w[2][NP];
+                auto rd = [&](auto subt) {
+                    constexpr int sub = decltype(subt)::value;
+                    static_for<0, NP>([&](auto it) {
+                        constexpr int i = decltype(it)::value;
+                        c3t_lds_read<(sub / 4) * CB + C3TOffB<NP>::at(sub % 4, i)>(w[sub % 2][i], ws, ws_lds);
+                    });
+                };
+                rd(std::integral_constant<int, 0>{});
+                rd(std::integral_constant<int, 1>{});
+                static_for<0, 4 * NGB>([&](auto subt) {
+                    constexpr int sub = decltype(subt)::value;
+                    constexpr int s4 = sub % 4, j = 2 * (sub / 4) + (s4 >> 1), s = s4 & 1;
+                    c3t_lds_wait<(sub + 1 < 4 * NGB ? NP : 0)>(w[sub % 2][0]);
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                    for (int i = 1; i < NP; ++i) c3t_lds_dep(w[sub % 2][i]);
 #pragma unroll
-                    for (int k = 0; k < NHJ; ++k) {
-                        if (!Cfg::maybe_w1(k)) continue;
-                        if (jg[k] < 0 || jh[k] != 0) continue;   // wave-uniform
-                        const frag xb = c3t_frag<DT>(pk[k][j][s]);
+                    for (int k = 0; k < NG; ++k)
 #pragma unroll
-                        for (int i = 0; i < NP; ++i) accb[k][i] = Mfma<DT>::run(*reinterpret_cast<const frag*>(ws + (i * 2 + s) * 1024), xb, accb[k][i]);
-                    }
-                step_done();
-            });
+                        for (int i = 0; i < NP; ++i) accb[k][i] = C3T_MMA(w[sub % 2][i], c3t_frag<DT>(pk1[k][j][s]), accb[k][i]);
+                    if constexpr (sub + 2 < 4 * NGB) rd(std::integral_constant<int, sub + 2>{});
+                    if constexpr (sub == 0) send_stage();   // behind the first MFMAs: the packets may have come through vector memory (MID / TAIL)
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            step_end();
 #pragma unroll
-            for (int k = 0; k < NHJ; ++k) {
-                if (!Cfg::maybe_w1(k)) continue;
-                if (jg[k] < 0 || jh[k] != 0) continue;
+            for (int k = 0; k < NG; ++k) {
+                if (jg[k] < 0) continue;   // wave-uniform: a job without a group writes nothing
                 const int q = jg[k] * 32 + frow;
                 unsigned char* const tq = T + q * 64;
                 const int swz = (q >> 2) & 3;
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
                     u32x4 o[2];
-                    silu_pack_subtile<DT, false, true>(accb[k][i], none, o);
+                    silu_pack_subtile<DT, false, C3T_SILU>(accb[k][i], none, o);
                     if (!(pmf[k] & 1)) o[0] = o[1] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(tq + i * plane_b + (((2 * p + hi) ^ swz) * 16)) = o[p];
@@ -368,140 +558,203 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
             }
         }
 
-        // ---------------- phase C: u = m.cv2(t) (3x3) (+ x1) for the centre groups; stages = (32-channel chunk, kernel row), conv_halo8.hip's order ----------------
-        bool cj[GC];
-#pragma unroll
-        for (int c = 0; c < GC; ++c) cj[c] = jg[2 * c + 1] >= 0 && jh[2 * c + 1] == 1;   // wave-uniform
-        {
+        C3T_STAMP(10);
+        // ---------------- phase C: u = m.cv2(t) (3x3) (+ x1) for the centre groups; taps in conv_halo8.hip's order (32-channel chunk, dy, dx), k16 halves inside ----------------
+        if constexpr (NC == 0) {
+            for (int j = 0; j < NSTC; ++j) {
+                step_sync();
+                send_stage();
+                step_end();
+            }
+        } else {
             // LDS byte offsets of the nine taps' fragments (k16 half 0; half 1 = ^ 32) inside a plane.  Slot q' = q + (dy - 1) pw + (dx - 1) holds its four 16-byte channel
             // octets at q' * 64 + ((octet ^ ((q' >> 2) & 3)) * 16): 32 CONSECUTIVE slots under any constant shift cover every 16-byte bank slot once per ds_read_b128 lane
             // group (MI355X_MICROARCH.md, LDS).  Lanes whose slot is no output pixel read a safe slot (results never stored).  Recomputed per tile on purpose (the
-            // opaque `fr`): kept across the other phases the 9 GC offsets cost registers the 1x1 phases do not have.
+            // opaque `fr`): kept across the other phases the 9 NC offsets cost registers the 1x1 phases do not have.
             int fr = frow;
             asm volatile("" : "+v"(fr));
-            int ea[GC][9];
+            int ea[NC][9];
 #pragma unroll
-            for (int c = 0; c < GC; ++c) {
-                const int r = (jrc[2 * c] >> 16) - 8, cc = jrc[2 * c] & 0xffff;
-                const bool out_px = jg[2 * c] >= 0 && r >= 1 && r <= g.R && cc < a.w;
-                const int q = out_px ? jg[2 * c] * 32 + fr : g.delta + g.pw;
+            for (int c = 0; c < NC; ++c) {
+                const int r = (jrc[c] >> 16) - 8, cc = jrc[c] & 0xffff;
+                const bool out_px = jg[c] >= 0 && r >= 1 && r <= g.R && cc < a.w;
+                const int q = out_px ? jg[c] * 32 + fr : g.delta + g.pw;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int qs = q + (t / 3 - 1) * g.pw + (t % 3 - 1);
                     ea[c][t] = qs * 64 + ((hi ^ ((qs >> 2) & 3)) * 16);
                 }
             }
-            f32x16 acc[GC][NP];
+            f32x16 acc[NC][NP];
 #pragma unroll
-            for (int c = 0; c < GC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int i = 0; i < NP; ++i) acc[c][i] = c3t_bias_acc(bl, BG_M2 + i, hi);
-            for (int j = 0; j < NP; ++j) {
-                const unsigned char* const tp = T + j * plane_b;
-                static_for<0, 3>([&](auto dyt) {
-                    constexpr int dy = decltype(dyt)::value;
-                    step_wait();
-                    step_issue(more);
-                    const unsigned char* const ws = ring + cur * SLOT + lane * 16;
+            const unsigned t_lds = c3t_lds_addr(T);
+            static_for<0, NSTC>([&](auto stt) {
+                constexpr int st = decltype(stt)::value;
+                step_sync();
+                const unsigned char* const ws = ring + cur * SLOT + l16;
+                const unsigned ws_lds = ring_lds + (unsigned)(cur * SLOT) + l16;
+                constexpr int RPS = NP + NC;      // fragment reads per sub-step
+                constexpr int NSUB = 2 * TPS;     // sub-step = (tap of this stage, k16 half)
+                frag wf[3][NP], tf[3][NC];        // three-deep: a buffer is refilled one whole MFMA group after its last use
+                auto read_frags = [&](auto subt) {
+                    constexpr int sub = decltype(subt)::value;
+                    constexpr int tl = sub >> 1, s = sub & 1, b = sub % 3;
+                    constexpr int tg = st * TPS + tl;            // tap in sending order
+                    constexpr int j = tg / 9, t9 = tg % 9;       // its 32-channel chunk (= plane of the patch), its (dy, dx)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
+                    for (int c = 0; c < NC; ++c) {
+                        const int e = j * plane_b + (s ? (ea[c][t9] ^ 32) : ea[c][t9]);
+                        c3t_lds_read<0>(tf[b][c], T + e, t_lds + (unsigned)e);
+                    }
+                    static_for<0, NP>([&](auto it) {
+                        constexpr int i = decltype(it)::value;
+                        c3t_lds_read<tl * TAPB + (i * 2 + s) * 1024>(wf[b][i], ws, ws_lds);
+                    });
+                };
+                read_frags(std::integral_constant<int, 0>{});
+                read_frags(std::integral_constant<int, 1>{});
+                static_for<0, NSUB>([&](auto subt) {
+                    constexpr int sub = decltype(subt)::value;
+                    constexpr int b = sub % 3;
+                    c3t_lds_wait<(sub + 1 < NSUB ? RPS : 0)>(tf[b][0]);   // this sub-step's fragments are in; the next one's may still be in flight
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            frag wf[NP];
+                    for (int c = 1; c < NC; ++c) c3t_lds_dep(tf[b][c]);
 #pragma unroll
-                            for (int i = 0; i < NP; ++i) wf[i] = *reinterpret_cast<const frag*>(ws + ((dx * NP + i) * 2 + s) * 1024);
+                    for (int i = 0; i < NP; ++i) c3t_lds_dep(wf[b][i]);
 #pragma unroll
-                            for (int c = 0; c < GC; ++c) {
-                                if (!cj[c]) continue;
-                                const frag tf = *reinterpret_cast<const frag*>(tp + (s ? (ea[c][dy * 3 + dx] ^ 32) : ea[c][dy * 3 + dx]));
+                    for (int c = 0; c < NC; ++c)
 #pragma unroll
-                                for (int i = 0; i < NP; ++i) acc[c][i] = Mfma<DT>::run(wf[i], tf, acc[c][i]);
-                            }
-                        }
-                    step_done();
+                        for (int i = 0; i < NP; ++i) acc[c][i] = C3T_MMA(wf[b][i], tf[b][c], acc[c][i]);
+                    if constexpr (sub + 2 < NSUB) read_frags(std::integral_constant<int, sub + 2>{});
+                    if constexpr (sub == 0) send_stage();
+                    __builtin_amdgcn_sched_barrier(0);   // (the next sub-step's wait names other registers: without the fence hipcc sinks this group's MFMAs below it)
                 });
-            }
+                step_end();
+            });
+            if (!has_d) prefetch_next_x();
 #pragma unroll
-            for (int c = 0; c < GC; ++c) {
-                if (!cj[c]) continue;
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
                     u32x4 o[2];
                     if (a.shortcut) {   // x1 + ...: the shortcut is phase A's packet, un-swapped into accumulator order (conv_common.hpp lean_load_residual)
                         u32x2 rv[4];
-                        unswap_residual_packet(pk[2 * c][i][0], rv, 0);
-                        unswap_residual_packet(pk[2 * c][i][1], rv, 2);
-                        silu_pack_subtile<DT, true, true>(acc[c][i], rv, o);
+                        unswap_residual_packet(pk1[c][i][0], rv, 0);
+                        unswap_residual_packet(pk1[c][i][1], rv, 2);
+                        silu_pack_subtile<DT, true, C3T_SILU>(acc[c][i], rv, o);
                     } else {
-                        silu_pack_subtile<DT, false, true>(acc[c][i], none, o);
+                        silu_pack_subtile<DT, false, C3T_SILU>(acc[c][i], none, o);
                     }
-                    pk[2 * c][i][0] = o[0];
-                    pk[2 * c][i][1] = o[1];
+                    pk1[c][i][0] = o[0];
+                    pk1[c][i][1] = o[1];
                 }
                 if (!has_d) {   // HEAD / MID: the Bottleneck's output goes to memory
-                    if (pmf[2 * c] & 2) {
-                        uint16_t* yp = a.y1_out + (int64_t)(pmf[2 * c] >> 2) * a.y1o_cs + 8 * hi;
+                    if (pmf[c] & 2) {
+                        uint16_t* yp = a.y1_out + (int64_t)(pmf[c] >> 2) * a.y1o_cs + 8 * hi;
 #pragma unroll
                         for (int i = 0; i < NP; ++i)
 #pragma unroll
-                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = pk[2 * c][i][p];
+                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = pk1[c][i][p];
                     }
                     st_pending = true;
                 }
             }
         }
 
-        // ---------------- phase D: y = cv3([u | cv2(x)]), K = 2 CH from the packets ----------------
+        C3T_STAMP(11);
+        // ---------------- phase D: y = cv3([u | cv2(x)]), K = 2 CH from the packets; sub-step = (k16 half s, lower / upper half of the couts): NP weight fragments ----------------
         if (has_d) {
-            f32x16 acc[GC][2 * NP];
-#pragma unroll
-            for (int c = 0; c < GC; ++c)
-#pragma unroll
-                for (int i = 0; i < 2 * NP; ++i) acc[c][i] = c3t_bias_acc(bl, BG_3 + i, hi);
-            static_for<0, 2 * NP>([&](auto jt) {
-                constexpr int j = decltype(jt)::value;
-                step_wait();
-                if constexpr (j == 2 * NP - 1) {   // the tile's last step: the next tile's first activation fragments go ahead of its stage 1
-                    if (more && has_a) {
-                        int pmn[NHJ];
-                        tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
-                        load_x(0, pmn);
-                    }
+            if constexpr (NC == 0) {
+                for (int j = 0; j < NSTD; ++j) {
+                    step_sync();
+                    send_stage();
+                    step_end();
                 }
-                step_issue(more);
-                const unsigned char* const ws = ring + cur * SLOT + lane * 16;
+            } else {
+                f32x16 acc[NC][2 * NP];
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int c = 0; c < GC; ++c) {
-                        if (!cj[c]) continue;
-                        const frag xb = c3t_frag<DT>(j < NP ? pk[2 * c][j < NP ? j : 0][s] : pk[2 * c + 1][j < NP ? 0 : j - NP][s]);
+                    for (int i = 0; i < 2 * NP; ++i) acc[c][i] = c3t_bias_acc(bl, BG_3 + i, hi);
+                static_for<0, NSTD>([&](auto stt) {
+                    constexpr int st = decltype(stt)::value;
+                    step_sync();
+                    const unsigned char* ws = ring + cur * SLOT + l16;
+                    const unsigned ws_lds = ring_lds + (unsigned)(cur * SLOT) + l16;
+                    frag w[2][NP];
+                    auto rd = [&](auto subt) {
+                        constexpr int sub = decltype(subt)::value;
+                        static_for<0, NP>([&](auto it) {
+                            constexpr int i = decltype(it)::value;
+                            c3t_lds_read<(sub / 4) * CB + C3TOffAD<NP>::at(sub % 4, i)>(w[sub % 2][i], ws, ws_lds);
+                        });
+                    };
+                    rd(std::integral_constant<int, 0>{});
+                    rd(std::integral_constant<int, 1>{});
+                    static_for<0, 4 * KC>([&](auto subt) {
+                        constexpr int sub = decltype(subt)::value;
+                        constexpr int j = st * KC + sub / 4, s = (sub % 4) >> 1, half = sub & 1;   // k32 chunk of K = [u | cv2(x)], k16 half, lower / upper CH couts
+                        c3t_lds_wait<(sub + 1 < 4 * KC ? NP : 0)>(w[sub % 2][0]);
 #pragma unroll
-                        for (int i = 0; i < 2 * NP; ++i) acc[c][i] = Mfma<DT>::run(*reinterpret_cast<const frag*>(ws + (i * 2 + s) * 1024), xb, acc[c][i]);
+                        for (int i = 1; i < NP; ++i) c3t_lds_dep(w[sub % 2][i]);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const frag xb = c3t_frag<DT>(j < NP ? pk1[c][j < NP ? j : 0][s] : pk2[c][j < NP ? 0 : j - NP][s]);
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) acc[c][half * NP + i] = C3T_MMA(w[sub % 2][i], xb, acc[c][half * NP + i]);
+                        }
+                        if constexpr (sub + 2 < 4 * KC) rd(std::integral_constant<int, sub + 2>{});
+                        if constexpr (sub == 0) send_stage();
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    step_end();
+                });
+                prefetch_next_x();
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    uint16_t* yp = a.y + (int64_t)(pmf[c] >> 2) * a.y_cs + 8 * hi;
+#pragma unroll
+                    for (int i = 0; i < 2 * NP; ++i) {
+                        u32x4 o[2];
+                        silu_pack_subtile<DT, false, C3T_SILU>(acc[c][i], none, o);
+                        if (pmf[c] & 2) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = o[p];
+                        }
                     }
-                step_done();
-            });
-#pragma unroll
-            for (int c = 0; c < GC; ++c) {
-                if (!cj[c]) continue;
-                uint16_t* yp = a.y + (int64_t)(pmf[2 * c] >> 2) * a.y_cs + 8 * hi;
-#pragma unroll
-                for (int i = 0; i < 2 * NP; ++i) {
-                    u32x4 o[2];
-                    silu_pack_subtile<DT, false, true>(acc[c][i], none, o);
-                    if (pmf[2 * c] & 2) {
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(yp + i * 32 + p * 16) = o[p];
-                    }
+                    st_pending = true;
                 }
-                st_pending = true;
             }
-        } else if (more && has_a) {
-            // HEAD: the next tile's first activation fragments (issued after this tile's stores: the next wait is vmcnt(0) anyway)
-            int pmn[NHJ];
-            tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
-            load_x(0, pmn);
         }
+        if constexpr (NC == 0) prefetch_next_x();   // (a halo-only role has no epilogue to hide it behind)
+        C3T_STAMP(12);
+    }
+    wait_vmcnt<0>();   // the pieces sent behind the last tile's last stages must not land in another block's LDS
+}
+
+template <int DT, int CH>
+__global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3TGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char c3t_sm[];
+    constexpr int BIAS_BYTES = 6 * (CH / 32) * 32 * 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef YMI_STAMPS
+    int st_n = 0;
+#endif
+    C3T_STAMP(0);
+    if ((int)blockIdx.x >= g.ntiles) return;
+    f32x4* const bl = reinterpret_cast<f32x4*>(c3t_sm);
+    for (int i = tid; i < BIAS_BYTES / 16; i += 512) bl[i] = *reinterpret_cast<const f32x4*>(a.blob + a.bias_off + i * 16);
+    __syncthreads();   // the biases are in LDS
+    if constexpr (CH == 128) {
+        if (g.role[wave] == 0) c3t_run<DT, 128, 0>(a, g, c3t_sm, wave, lane);   // wave-uniform; every role runs the same sequence of barriers
+        else c3t_run<DT, 128, 1>(a, g, c3t_sm, wave, lane);
+    } else {
+        c3t_run<DT, 64, 0>(a, g, c3t_sm, wave, lane);
     }
 }
 
@@ -509,7 +762,7 @@ __global__ __launch_bounds__(512) void c3_tile_kernel(const C3TArgs a, const C3T
 // ymi_c3_pack: the four folded weight matrices [rows][k_pad] (ymi_conv_desc.w layout) -> the stage stream.  Piece = one MFMA weight fragment (32 cout rows x 16 k):
 // lane l's 16 bytes = row r0 + (l & 31), k = k0 + 8 (l >> 5) .. + 7.
 //   A stage j          pieces (group i of [cv1 | cv2] rows, k16 half s) = i * 2 + s:          k0 = 32 j + 16 s
-//   B stage j          pieces (group i of m.cv1, s):                                          k0 = 32 j + 16 s
+//   B stage j          pieces (group i of m.cv1, k16 step s of the stage's 64 k) = i * 4 + s:  k0 = 64 j + 16 s
 //   C stage 3 j + dy   pieces (dx, group i of m.cv2, s) = (dx * NP + i) * 2 + s:              k0 = (dy * 3 + dx) * CH + 32 j + 16 s
 //   D stage j          pieces (group i of cv3, s):                                            k0 = 32 j + 16 s   (k < CH: the Bottleneck's output, then cv2's)
 // then the biases as fp32: b12 (2 CH) | bm1 (CH) | bm2 (CH) | b3 (2 CH).
@@ -546,13 +799,17 @@ __global__ void c3_pack_kernel(const C3PackArgs p) {
     if (byte < p.off_b) {
         rel = byte;
         const int j = (int)(rel / (4 * np * 1024));
+        if (j >= p.nst_a) {   // padding chunk of phase A: zero weights
+            *reinterpret_cast<u32x4*>(p.blob + byte) = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
         piece = (int)((rel - (int64_t)j * 4 * np * 1024) / 1024);
         w = p.w12; kstride = p.k12; row0 = (piece >> 1) * 32; k0 = 32 * j + 16 * (piece & 1);
     } else if (byte < p.off_c) {
         rel = byte - p.off_b;
-        const int j = (int)(rel / (2 * np * 1024));
-        piece = (int)((rel - (int64_t)j * 2 * np * 1024) / 1024);
-        w = p.wm1; kstride = p.km1; row0 = (piece >> 1) * 32; k0 = 32 * j + 16 * (piece & 1);
+        const int j = (int)(rel / (4 * np * 1024));
+        piece = (int)((rel - (int64_t)j * 4 * np * 1024) / 1024);
+        w = p.wm1; kstride = p.km1; row0 = (piece >> 2) * 32; k0 = 64 * j + 16 * (piece & 3);
     } else if (byte < p.off_d) {
         rel = byte - p.off_c;
         const int st = (int)(rel / (6 * np * 1024));
@@ -572,7 +829,7 @@ __global__ void c3_pack_kernel(const C3PackArgs p) {
 }
 
 struct C3TLayout {
-    int np, nst_a, nst_d;
+    int np, nst_a, nst_ap, nst_d;
     int64_t off_b, off_c, off_d, bias_off, total;
 };
 static bool c3t_layout(const ymi_c3_desc* d, C3TLayout& L) {
@@ -580,8 +837,9 @@ static bool c3t_layout(const ymi_c3_desc* d, C3TLayout& L) {
     if (d->mode < 0 || d->mode > 3) return false;
     L.np = d->c_hidden / 32;
     L.nst_a = (d->mode == 0 || d->mode == 1) ? d->c_in / 32 : 0;
+    L.nst_ap = (L.nst_a + 3) / 4 * 4;
     L.nst_d = (d->mode == 0 || d->mode == 3) ? 2 * L.np : 0;
-    L.off_b = (int64_t)L.nst_a * 4 * L.np * 1024;
+    L.off_b = (int64_t)L.nst_ap * 4 * L.np * 1024;
     L.off_c = L.off_b + (int64_t)L.np * 2 * L.np * 1024;
     L.off_d = L.off_c + (int64_t)3 * L.np * 6 * L.np * 1024;
     L.bias_off = L.off_d + (int64_t)L.nst_d * 4 * L.np * 1024;
@@ -632,11 +890,10 @@ int c3_pack_launch(const ymi_c3_desc* d, void* blob, hipStream_t s) {
 // Cost model: rounds of tiles over 256 CUs x per-tile time (a centre group ~6x a halo-only group: the 3x3 and cv3 dominate).
 template <int CH>
 static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
-    typedef C3TCfg<CH> Cfg;
-    constexpr int NP = Cfg::NP, GC = Cfg::GC;
+    constexpr int NP = CH / 32, GC = CH == 128 ? 1 : 2;   // centre groups per wave
     const int pw = w + 1;
     const int lds_max = 160 * 1024;
-    const int fixed = 6 * NP * 32 * 4 + 3 * 6 * NP * 1024;
+    const int fixed = 6 * NP * 32 * 4 + 2 * 36 * 1024;
     const int max_groups = (lds_max - fixed) / (NP * 32 * 64);
     double best = 1e30;
     int bR = 0, bD = 0;
@@ -678,14 +935,16 @@ static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
     g.ntiles = n * g.tiles_per_img;
     const uint64_t mg = (((uint64_t)1 << 32) / (uint64_t)pw) + 1u;
     g.magic_pw = (unsigned)(mg > 0xffffffffull ? 0xffffffffull : mg);
-    for (int wv = 0; wv < 8; ++wv)
-        for (int k = 0; k < C3T_MAXHJ; ++k) { g.grp[wv][k] = -1; g.half[wv][k] = 0; }
-    // centre groups: GC per wave in order; halo-only groups: the spare jobs, waves with the fewest centre groups first
+    for (int wv = 0; wv < 8; ++wv) {
+        g.role[wv] = 0;
+        for (int k = 0; k < 3; ++k) g.grp[wv][k] = -1;
+    }
+    // centre groups: GC per wave in order; halo-only groups: the spare jobs (hidden width 128: the waves without a centre group take two each, role 1;
+    // hidden width 64: every wave has one halo-only job, the waves with the fewest centre groups first)
     int ncw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < ncen; ++i) {
         const int wv = (GC == 1) ? i : i / 2, c = (GC == 1) ? 0 : i % 2;
-        g.grp[wv][2 * c] = (signed char)(gc0 + i); g.half[wv][2 * c] = 0;
-        g.grp[wv][2 * c + 1] = (signed char)(gc0 + i); g.half[wv][2 * c + 1] = 1;
+        g.grp[wv][c] = (signed char)(gc0 + i);
         ++ncw[wv];
     }
     int hq[128], nh = 0;
@@ -693,22 +952,23 @@ static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
         if (gi < gc0 || gi >= gc0 + ncen) hq[nh++] = gi;
     int hi_ = 0;
     if (GC == 1) {
-        for (int wv = 7; wv >= 0 && hi_ < nh; --wv) {
+        for (int wv = 7; wv >= 0; --wv) {
             if (ncw[wv]) continue;
-            for (int k = 0; k < 2 && hi_ < nh; ++k) { g.grp[wv][k] = (signed char)hq[hi_++]; g.half[wv][k] = 0; }
+            g.role[wv] = 1;
+            for (int k = 0; k < 2 && hi_ < nh; ++k) g.grp[wv][k] = (signed char)hq[hi_++];
         }
     } else {
         for (int pass = 0; pass <= 2 && hi_ < nh; ++pass)
             for (int wv = 7; wv >= 0 && hi_ < nh; --wv)
-                if (ncw[wv] == pass && g.grp[wv][4] < 0) { g.grp[wv][4] = (signed char)hq[hi_++]; g.half[wv][4] = 0; }
+                if (ncw[wv] == pass && g.grp[wv][2] < 0) g.grp[wv][2] = (signed char)hq[hi_++];
     }
     return hi_ == nh;
 }
 
 template <int DT, int CH>
 static int launch_c3_tile(const C3TArgs& a, const C3TGeom& g, hipStream_t s) {
-    constexpr int NP = C3TCfg<CH>::NP;
-    const size_t lds = (size_t)6 * NP * 32 * 4 + (size_t)NP * g.nslot * 64 + (size_t)3 * 6 * NP * 1024;
+    constexpr int NP = CH / 32;
+    const size_t lds = (size_t)6 * NP * 32 * 4 + (size_t)NP * g.nslot * 64 + (size_t)2 * 36 * 1024;
     auto kfn = c3_tile_kernel<DT, CH>;
     if (lds > 64 * 1024) { const int rc = allow_big_lds((const void*)kfn, (int)lds); if (rc != YMI_OK) return rc; }
     int grid = g.ntiles < 256 ? g.ntiles : 256;   // persistent: one block per CU
@@ -738,7 +998,8 @@ int c3_tile_launch(const ymi_c3_desc* d, hipStream_t s) {
     if (d->mode == 1 || d->mode == 3) YMI_REQUIRE(d->y2 && d->y2_cstride % 8 == 0 && d->y2_cstride >= ch, "ymi_c3_fused: modes 1 / 3 write / read cv2(x) through y2");
     const int64_t cs_max = std::max(std::max((int64_t)d->x_cstride, (int64_t)d->y_cstride), std::max(std::max((int64_t)d->y1_in_cstride, (int64_t)d->y1_out_cstride), (int64_t)d->y2_cstride));
     YMI_REQUIRE((int64_t)d->n * d->h * d->w * cs_max < ((int64_t)1 << 40), "ymi_c3_fused: tensor too large");
-    YMI_REQUIRE((int64_t)d->n * d->h * d->w < ((int64_t)1 << 31), "ymi_c3_fused: pixel index must fit 31 bits");
+    YMI_REQUIRE((int64_t)d->n * d->h * d->w < ((int64_t)1 << 29), "ymi_c3_fused: pixel index must fit 29 bits");
+    YMI_REQUIRE(!has_a || (int64_t)d->n * d->h * d->w * d->x_cstride < ((int64_t)1 << 30), "ymi_c3_fused: x must stay below 2 GiB (32-bit byte offsets)");
     C3TLayout L;
     c3t_layout(d, L);
     C3TArgs a;
@@ -749,7 +1010,7 @@ int c3_tile_launch(const ymi_c3_desc* d, hipStream_t s) {
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c_in;
     a.x_cs = d->x_cstride; a.y_cs = d->y_cstride; a.y1i_cs = d->y1_in_cstride; a.y1o_cs = d->y1_out_cstride; a.y2_cs = d->y2_cstride;
     a.mode = d->mode; a.shortcut = d->shortcut ? 1 : 0;
-    a.nst_a = L.nst_a; a.nst_d = L.nst_d; a.bias_off = (int)L.bias_off;
+    a.nst_a = L.nst_a; a.nst_ap = L.nst_ap; a.nst_d = L.nst_d; a.bias_off = (int)L.bias_off;
     C3TGeom g;
     const bool ok = ch == 128 ? c3t_geometry<128>(d->n, d->h, d->w, g) : c3t_geometry<64>(d->n, d->h, d->w, g);
     YMI_REQUIRE(ok, "ymi_c3_fused: no strip geometry for a %d x %d map at hidden width %d (the halo strip of whole rows must fit the LDS patch)", d->h, d->w, ch);
@@ -759,6 +1020,15 @@ int c3_tile_launch(const ymi_c3_desc* d, hipStream_t s) {
 
 }  // namespace ymi
 
+#ifdef YMI_STAMPS
+extern "C" int ymi_debug_stamps_c3t(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ymi::ymi_stamps_c3t), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int ymi_debug_stamps_c3t_clear(void) {
+    static unsigned long long z[256 * 8 * ymi::C3T_NSTAMP];
+    return hipMemcpyToSymbol(HIP_SYMBOL(ymi::ymi_stamps_c3t), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int64_t ymi_c3_blob_bytes(const ymi_c3_desc* d) { return ymi::c3_blob_bytes(d); }
 extern "C" int ymi_c3_pack(const ymi_c3_desc* d, void* blob, void* stream) { return ymi::c3_pack_launch(d, blob, (hipStream_t)stream); }
 extern "C" int ymi_c3_tile_supported(const ymi_c3_desc* d) { return ymi::c3_tile_supported(d); }
