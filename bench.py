@@ -799,8 +799,10 @@ def main():
         n_conv = len(conv_meta) - (1 if (e.plan.stem_body1_fusable() and (args.shapes == "fixed" or e.plan.fuse_stem)) else 0)   # stem + body.1 run as one launch
         bytes_step = sum(m["bytes"] for m in conv_meta)
         flops_step = sum(m["flops"] for m in conv_meta)
-        bound_s = sum(max(m["flops"] / MFMA_PEAK, m["bytes"] / HBM_PEAK) for m in conv_meta)
-        bound_meas_s = sum(max(m["flops"] / MFMA_MEASURED, m["bytes"] / HBM_MEASURED) for m in conv_meta)
+        # one bound per REFERENCE conv: a launch that stands for several (the strip kernel, engine.Plan.c3_tile) carries them as `layers`
+        per_layer = [fb for m in conv_meta for fb in (m.get("layers") or [(m["flops"], m["bytes"])])]
+        bound_s = sum(max(f / MFMA_PEAK, b / HBM_PEAK) for f, b in per_layer)
+        bound_meas_s = sum(max(f / MFMA_MEASURED, b / HBM_MEASURED) for f, b in per_layer)
         conv_s = mean(excl["conv"]) * 1e-3                 # serial duration of the conv launches of one step
         conv_s_region = mean(region["conv"]) * 1e-3
         step_s = elapsed / args.steps

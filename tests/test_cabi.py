@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_channel(lib):
-    assert lib.ymi_abi_version() == 5
+    assert lib.ymi_abi_version() == 6
     # a host-side argument error must come back as a code + message, never as an exception/abort
     t = (C.c_int32 * 8)()
     rc = lib.ymi_conv_build_ktab(7, 3, 3, 10, 8, 32, t)   # cin not a multiple of 8
@@ -50,6 +50,24 @@ def test_abi_version_and_error_channel(lib):
         assert lib.ymi_plan_num_ops(p) == 1
     finally:
         lib.ymi_plan_destroy(p)
+    # ABI 6, the strip kernel's entry points (csrc/c3_tile.hip): layout query and validation are host code
+    from yolort_amd._lib import C3Desc
+    d = C3Desc()
+    d.c_in, d.c_hidden, d.c_out, d.mode, d.n, d.h, d.w = 256, 128, 256, 0, 32, 40, 40
+    full = lib.ymi_c3_blob_bytes(C.byref(d))
+    assert full == (8 * 16 + 32 + 36 * 8 + 8 * 16) * 1024 + 6 * 128 * 4          # [cv1 | cv2: 8 k32 chunks][m.cv1][the 3x3's 36 taps][cv3: 8 chunks] + the fp32 biases
+    d.mode = 2
+    assert lib.ymi_c3_blob_bytes(C.byref(d)) == (32 + 36 * 8) * 1024 + 6 * 128 * 4   # one Bottleneck
+    d.c_in, d.mode = 96, 1
+    assert lib.ymi_c3_blob_bytes(C.byref(d)) == (4 * 16 + 32 + 36 * 8) * 1024 + 6 * 128 * 4   # 3 chunks padded to 4 (whole stages)
+    d.c_hidden = 96
+    assert lib.ymi_c3_blob_bytes(C.byref(d)) == 0 and lib.ymi_c3_tile_supported(C.byref(d)) == 0
+    d.c_hidden, d.c_out = 128, 256
+    assert lib.ymi_c3_tile_supported(C.byref(d)) == 1
+    d.h, d.w = 320, 320
+    assert lib.ymi_c3_tile_supported(C.byref(d)) == 0                              # a 322-slot row does not leave room for three of them in the LDS patch
+    assert lib.ymi_c3_pack(C.byref(d), None, None) == -1 and b"ymi_c3_pack" in lib.ymi_last_error()
+    assert lib.ymi_c3_fused(C.byref(d), None) == -1 and b"ymi_c3" in lib.ymi_last_error()   # (no weights: refused before anything is launched)
     assert lib.ymi_act(None, 8, 4, 8, 0, 2, None, 0, None) == -1 and b"ymi_act" in lib.ymi_last_error()
     buf = (C.c_uint16 * 64)()
     assert lib.ymi_act(buf, 8, 4, 8, 0, 1, None, 0, None) == -1 and b"HARDSWISH" in lib.ymi_last_error()     # SiLU belongs to the convolution's epilogue

@@ -400,6 +400,54 @@ def test_pinned_resident_weight_tiles_are_validated_against_the_launch():
     assert not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 133) and not p._pinned_ok(desc(64, 64, 1, ACT_SILU), 132) and not p._pinned_ok(desc(64, 128, 2, ACT_SILU), 134)
 
 
+def test_a_rejected_pinned_tile_does_not_come_back_through_the_table_fallback(monkeypatch):
+    """Plan.conv's last branch (`elif self.use_tile_table: d.tile = pinned`) re-assigned a table entry >= 132 that _pinned_ok had just rejected.  The concrete
+    case: yolov5s r3.1, fp16, bs 32, 640 x 640 -- body.3 = Conv(64, 128, 3, 2) runs with YMI_ACT_NONE (its Hardswish is a launch of its own) on a key the table pins
+    to tile 138 (SiLU only): the launch must take the library heuristic (tile 0) instead.  Driven through the whole rule chain of Plan.conv, not _pinned_ok alone."""
+    import ctypes as C
+    from yolort_amd import _lib, engine
+    from yolort_amd._lib import ACT_NONE, ACT_SILU
+
+    class Lib:   # records the descriptor instead of a launch
+        def __init__(self):
+            self.real, self.tiles = _lib.load(require_gpu=False), []
+
+        def ymi_plan_add_conv(self, h, dref):
+            self.tiles.append(int(dref._obj.tile))
+            return len(self.tiles) - 1
+
+        def ymi_plan_num_ops(self, h):
+            return len(self.tiles)
+
+        def ymi_conv_build_ktab(self, *a):
+            return self.real.ymi_conv_build_ktab(*a)
+
+    def plan():
+        p = engine.Plan.__new__(engine.Plan)
+        p.lib, p.device, p.dtype, p.handle = Lib(), torch.device("cpu"), torch.float16, C.c_void_p(1)
+        p.keep, p.names, p.meta, p.bytes_allocated, p.stream = [], [], [], 0, None
+        p.conv_descs, p.io = {}, {}
+        p.chain_1x1, p.chain_cv3, p.use_v1, p.fuse_c3, p.c3_tile_on, p.chain_next = True, False, False, True, True, False
+        p.autotune, p.use_tile_table, p.fp32, p.fuse_stem = False, True, False, False
+        p.res3x3, p.rw2, p.rw3, p.rs = 2, 1, False, False
+        return p
+
+    w = torch.randn(128, 64, 3, 3)
+    seen = {}
+    for act, name in ((ACT_SILU, "silu"), (ACT_NONE, "none")):
+        p = plan()
+        x = p.alloc(32, 160, 160, 64)
+        pc = engine.PackedConv(w, None, None, torch.float16, torch.device("cpu"))
+        y = p.alloc(32, 80, 80, 128)
+        key = engine.tile_key_str((32, 160, 160, 64, 128, 3, 3, (2, 2), (1, 1), 64, 128, _lib.dtype_code(torch.float16), False, 0, False, 0), torch.float16)
+        monkeypatch.setattr(engine, "_TILE_TABLE", {key: 138})
+        p.conv(x, pc, 2, 1, act, out=y, name="body.3")
+        seen[name] = p.lib.tiles[-1]
+        p.handle = None
+    assert seen["silu"] == 138          # the entry applies to the SiLU launch it was tuned for
+    assert seen["none"] == 0, seen      # ... and is NOT forced onto the activation-free launch (conv3x3_rs_launch would refuse it: YMI_EINVAL at plan build)
+
+
 @pytest.mark.parametrize("walk", ["python", "c"])
 def test_weights_signature_sees_every_way_a_module_tree_can_change(walk, monkeypatch):
     """(both forms of the walk: the interpreter-level one and torch_ext/sig_ext.cpp, skipped when `_ymi_sig.so` is not built)

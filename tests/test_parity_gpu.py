@@ -126,6 +126,19 @@ def _err_vs(view, ref_nchw):
     # round 5, the legacy releases: Focus stem through the 6 x 6 stride-2 stem kernels; r3.1: Hardswish / LeakyReLU(0.1) in the general epilogues, BottleneckCSP's shared BatchNorm folded by halves
     ("yolov5_darknet_pan_s_r40", torch.float16, 8, 640, 2e-3, False, 4),
     ("yolov5_darknet_pan_s_r31", torch.float16, 8, 640, 2e-3, False, 4),
+    # round 6: every other factory of yolort/models/yolo.py:292-834 at a small canvas -- yolov5x's widths 80 / 160 / 320 / 640 / 1280 (cin % 32 != 0:
+    # the im2col-table form at shapes nothing had run), the P6 variants' fourth level, the m / l legacy releases (BottleneckCSP with 2 / 3 Bottlenecks, padded hidden widths)
+    ("yolov5_darknet_pan_l_r60", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_x_r60", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_n6_r60", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_s6_r60", torch.bfloat16, 2, 320, 1.6e-2, False, 2),
+    ("yolov5_darknet_pan_m6_r60", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_x6_r60", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_m_r31", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_l_r31", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_m_r40", torch.bfloat16, 2, 320, 1.6e-2, False, 2),
+    ("yolov5_darknet_pan_l_r40", torch.float16, 2, 320, 2e-3, False, 2),
+    ("yolov5_darknet_pan_s_r31", torch.float16, 32, 640, 2e-3, False, 2),      # the r3.1 plan at the headline's batch -- body.3 runs with YMI_ACT_NONE on a key the table pins to a SiLU-only tile
 ])
 def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size, tol, dynamic, n_oracle):
     from oracle import yolov5_oracle as O

@@ -99,7 +99,7 @@ def main():
         if not dur[k]:
             continue
         t = sorted(dur[k])[len(dur[k]) // 2]   # median: a shared box shows 2x outliers on single launches
-        bound = max(o["flops"] / MFMA_PEAK, o["bytes"] / HBM_PEAK) * 1e6
+        bound = sum(max(f / MFMA_PEAK, b / HBM_PEAK) for f, b in (o.get("layers") or [(o["flops"], o["bytes"])])) * 1e6   # one bound per reference conv
         tot_t += t
         tot_b += bound
         cvals = []

@@ -355,7 +355,9 @@ class Plan:
             elif self.rw3 and self._rw3_ok(d):
                 d.tile = 135   # ... its K-split form for Conv(128, 128 / 256, 3, 2); YOLORT_AMD_RW3=0 keeps the table's tile
             elif self.use_tile_table:
-                d.tile = pinned
+                # a table entry >= 132 that THIS launch does not meet the preconditions of (another activation, a chained conv, an opted-out kernel: _pinned_ok said no above)
+                # must not come back through the fallback: the library's shape heuristic (tile 0) takes the launch
+                d.tile = pinned if (pinned < 132 or self._pinned_ok(d, pinned)) else 0
         esz = 4 if self.fp32 else 2
         if self.fp32 and d.tile == 0 and d.zeros:
             d.tile = int(self.lib.ymi_conv_f32_pick_tile(x.n * ho * wo, pc.cout_pad))   # what the library would choose itself: recorded so that the layer tables name the tile
@@ -602,10 +604,13 @@ class Plan:
         convs = ([(x.c, c_, 1), (x.c, c_, 1)] if has_a else []) + [(c_, c_, 1), (c_, c_, 9)] + ([(2 * c_, 2 * c_, 1)] if has_d else [])
         flops = sum(2.0 * npix * ci * co * k for ci, co, k in convs)
         nbytes = float(sum(npix * esz * (ci + co) + esz * ci * co * k for ci, co, k in convs))
+        # the launch's roofline bound stays the sum of its reference layers' own bounds (one bound per reference conv), not the bound of the summed launch:
+        # `layers` = (flops, bytes) of each reference conv this launch stands for
+        layers = [(2.0 * npix * ci * co * k, float(npix * esz * (ci + co) + esz * ci * co * k)) for ci, co, k in convs]
         self.io[self.num_ops] = {"name": name, "x": x, "y": out, "y2": y2, "split": 0, "up2": None, "res": None, "chain_y": None, "chain_x2": None,
                                  "stride": (1, 1), "pad": (0, 0), "fused_c3": True, "c3_mode": mode, "y1_in": y1_in, "y1_out": y1_out, "shortcut": bool(shortcut)}
         what = {0: "C3", 1: "C3 head", 2: "Bottleneck", 3: "C3 tail"}[mode]
-        self._record(self.lib.ymi_plan_add_c3_fused(self.handle, C.byref(d)), name, kind="conv", flops=flops, bytes=nbytes, ref_convs=len(convs), tile=-3,
+        self._record(self.lib.ymi_plan_add_c3_fused(self.handle, C.byref(d)), name, kind="conv", flops=flops, bytes=nbytes, ref_convs=len(convs), tile=-3, layers=layers,
                      shape=f"{what} {(x.c if has_a else c_)}->{2 * c_ if has_d else c_} hidden {c_} {src.h}x{src.w}")
         return out if has_d else y1_out
 
