@@ -366,7 +366,7 @@ def conditioned_parity(args, dev, fp32_only=False):
     return out
 
 
-def fp32_mode_throughput(args, dev, images_cpu, steps=30):
+def fp32_mode_throughput(args, dev, images_cpu, steps=30, checks=None):
     """throughput of the mode that meets the north-star box tolerance (fp32 storage + exact fp32 MFMA arithmetic, csrc/conv_f32.hip) on the benchmark workload itself:
     what the tolerance costs (`only the un-benchmarked fp32 parity mode meets 1 - 1e-3`)"""
     from yolort_amd.models import YOLOv5
@@ -398,9 +398,32 @@ def fp32_mode_throughput(args, dev, images_cpu, steps=30):
     run(steps)
     torch.cuda.synchronize()
     ips = len(imgs) * steps / (time.perf_counter() - t0)
+    gold = bench_golden(args)
+    if gold is not None and checks is not None:   # the mode that is timed here, on the timed workload, against the UNMODIFIED reference's detections (tests/golden/bench_<config>.npz)
+        k = len(gold["ref"])
+        got = [_npd(d) for d in m.forward(imgs[:k])]
+        checks.update(direct_checks([dict(r) for r in gold["ref"]], got, args.score_thresh, score_eps=5e-4, iou_min=1 - 1e-3))
+        checks["ground_truth"] = f"tests/golden/{gold['name']}"
+        checks["tolerance"] = "same label, IoU >= 1 - 1e-3, |dscore| <= 5e-4; `at_cut`: within 5e-4 of the threshold / the top-300 cut on one side only"
     del m
     torch.cuda.empty_cache()
     return round(ips, 1)
+
+
+def bench_golden(args):
+    """the committed golden of the timed workload, when this run IS that workload: same architecture, size, threshold, head gain, fixed-size seeded images"""
+    import json
+
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", f"bench_{args.config}.npz") if getattr(args, "config", None) else None
+    if not path or not os.path.exists(path):
+        return None
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    if (meta["arch"], meta["size"], meta["thr"], meta["head_gain"]) != (args.arch, args.size, args.score_thresh, args.head_gain) or args.shapes != "fixed":
+        return None
+    return {"name": os.path.basename(path), "meta": meta, "ref": [{k: z[f"det{i}_{k}"] for k in ("boxes", "scores", "labels")} for i in range(len(meta["dets"]))]}
 
 
 def parity_sample(args, model, images_gpu, images_cpu, sd, k):
@@ -414,10 +437,15 @@ def parity_sample(args, model, images_gpu, images_cpu, sd, k):
 
     kw = dict(size_divisible=64) if args.arch.endswith("6_r60") else {}
     thr = args.score_thresh
+    # round 6: when the timed workload has a committed golden (tests/golden/bench_<config>.npz: detections of the UNMODIFIED reference on exactly these weights and
+    # images, tests/golden/make_golden.py bench), the ground truth is the reference itself, not the oracle
+    gold = bench_golden(args)
+    if gold is not None:
+        k = min(k, len(gold["ref"]))
     cpu = [im.float() for im in images_cpu[:k]]
     dt16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     with torch.no_grad():
-        ref = O.yolov5_forward(cpu, sd, size=(args.size, args.size), score_thresh=thr, **kw)
+        ref = gold["ref"][:k] if gold is not None else O.yolov5_forward(cpu, sd, size=(args.size, args.size), score_thresh=thr, **kw)
         emu = None
         if args.size <= 640:
             # the same oracle with 16-bit STORAGE emulated between layers (fp32 arithmetic): what any 16-bit-storage implementation
@@ -428,7 +456,7 @@ def parity_sample(args, model, images_gpu, images_cpu, sd, k):
             finally:
                 O.EMULATE.dtype = None
     got = model.forward(images_gpu[:k])
-    refs, gots = [_npd(r) for r in ref], [_npd(d) for d in got]
+    refs, gots = ([dict(r) for r in ref] if gold is not None else [_npd(r) for r in ref]), [_npd(d) for d in got]
     ious, matched, total = [], 0, 0
     for r, d in zip(refs, gots):
         total += len(r["labels"])
@@ -449,7 +477,11 @@ def parity_sample(args, model, images_gpu, images_cpu, sd, k):
     out = {"images": k, "ref_dets": total, "matched_iou50": round(matched / max(total, 1), 4),
            "median_iou": round(float(np.median(ious)), 4) if ious else None,
            "map_vs_ref_50_95": round(ap, 4) if ap is not None else None,
-           "note": f"benchmark (saturated noise-image) workload, oracle (fp32 CPU restatement of the reference) detections as ground truth; the production path stores {args.dtype}"}
+           "ground_truth": (f"tests/golden/{gold['name']}: detections of the UNMODIFIED reference on this workload (make_golden.py bench)" if gold is not None
+                            else "oracle (fp32 CPU restatement of the reference)"),
+           "note": f"benchmark (saturated noise-image) workload; the production path stores {args.dtype}"}
+    if gold is not None:   # the direct checks of SURVEY.md 8d of the production path against the reference at the tolerance the conditioned goldens carry for 16-bit storage
+        out["direct_checks_iou98_ds1e-2"] = direct_checks(refs, gots, thr, score_eps=1e-2, iou_min=0.98)
     if emu is not None:
         ap_emu = coco_ap(refs, [_npd(r) for r in emu])
         out["map_of_oracle_with_emulated_16bit_storage"] = round(ap_emu, 4) if ap_emu is not None else None
@@ -911,7 +943,10 @@ def main():
                 out["parity"]["north_star_tolerance"] = ("boxes within 1e-3 IoU: met by the fp32 mode on every golden, at fp32_parity_mode_images_per_s (>= 4000 on C2); the production 16-bit "
                                                          "path is held to stated constant tolerances (cond / spread / lin) and reported against the reference's OWN 16-bit run (reference_own_*): "
                                                          "a per-layer budget (profiles/r04_error_budget_*.csv) shows no 16-bit-storage path can meet 1e-3")
-                out["parity"]["fp32_parity_mode_images_per_s"] = fp32_mode_throughput(args, dev, images_cpu)
+                fp32_checks = {}
+                out["parity"]["fp32_parity_mode_images_per_s"] = fp32_mode_throughput(args, dev, images_cpu, checks=fp32_checks)
+                if fp32_checks:
+                    out["parity"]["fp32_parity_mode_on_benchmark_workload"] = fp32_checks
             out["parity"]["benchmark_workload"] = parity_sample(args, model, images_gpu, images_cpu, sd_cpu, min(k_par, args.batch))
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, images_cpu)
         if args.per_op and world == 1:

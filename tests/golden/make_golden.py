@@ -509,7 +509,37 @@ def cond_gap_golden(arch, seeds, force_last=True, variant="cond", min_dets=12):
     raise RuntimeError(f"no usable seed for {arch} in {seeds}")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 6: the TIMED workload as a golden.  bench.py's headline configuration -- yolov5s, `synth_weights(seed 0, head_gain 0.4)`, the first
+# images of `synth_images(32, 640, 640, seed=1)`, score_thresh 0.25 -- through the UNMODIFIED reference: bench.py's parity block and the tests score the HIP path of
+# the benchmark against these detections instead of the oracle's.
+# ---------------------------------------------------------------------------------------------------------------------------
+BENCH_CONFIGS = {"c2": dict(arch="yolov5_darknet_pan_s_r60", size=640, batch=32, thr=0.25, head_gain=0.4, images=8)}
+
+
+def bench_golden(config="c2"):
+    c = BENCH_CONFIGS[config]
+    model = YOLOv5(arch=c["arch"], size=(c["size"], c["size"]), score_thresh=c["thr"], nms_thresh=0.45)
+    model.load_state_dict(synth_weights(model.state_dict(), c["arch"], seed=0, head_gain=c["head_gain"]))
+    model.eval()
+    imgs = list(synth_images(c["batch"], c["size"], c["size"], seed=1))[: c["images"]]
+    with torch.no_grad():
+        dets = _np_dets(model.predict(imgs))
+        d64 = _np_dets(model.double().predict([im.double() for im in imgs]))   # the reference against its own float64 evaluation: what fp32 summation order alone moves
+    out = {"meta": json.dumps({"config": config, **c, "seed": 0, "image_seed": 1, "dets": [int(len(d["scores"])) for d in dets],
+                               "what": "detections of the UNMODIFIED reference (yolort.models.YOLOv5.predict, fp32 CPU) on bench.py's timed workload"})}
+    for i, (d, e) in enumerate(zip(dets, d64)):
+        for k in ("boxes", "scores", "labels"):
+            out[f"det{i}_{k}"] = d[k]
+            out[f"f64_{i}_{k}"] = e[k].astype(d[k].dtype) if k != "labels" else e[k]
+        print(config, "image", i, "detections", len(d["scores"]), "(float64 evaluation:", len(e["scores"]), ")")
+    np.savez_compressed(os.path.join(HERE, f"bench_{config}.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":   # usage: bench [config]
+        bench_golden(*(sys.argv[2:3] or ["c2"]))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cond-gap":   # usage: cond-gap arch seed [seed ...]
         cond_gap_golden(sys.argv[2], [int(a) for a in sys.argv[3:]])
         sys.exit(0)
