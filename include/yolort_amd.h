@@ -375,6 +375,39 @@ int ymi_plan_submit(ymi_plan* p, int first, int n_conv, int use_graph, void* mai
                     size_t result_bytes, int main_waits_done);
 int ymi_plan_done_query(ymi_plan* p);
 int ymi_plan_done_sync(ymi_plan* p);
+
+/* ------------------------------------------------------------------------------------------
+ * ABI 6 -- plan export / import: a recorded plan as a self-contained file, for consumers without Python (the role the
+ * reference's TorchScript / ONNX artefacts of yolort/relay + yolort/runtime play).
+ *   ymi_plan_export   `regions` lists every device allocation the plan's descriptors point into (base, bytes):
+ *                     YMI_REGION_CONST  contents are saved (packed weights, biases, im2col tables, weight streams)
+ *                     YMI_REGION_SCRATCH zero-filled at import (activation buffers with their zero tails, workspaces)
+ *                     YMI_REGION_IO     zero-filled at import; the consumer finds it by `tag` (YMI_TAG_*)
+ *                     Every non-NULL pointer of every recorded op must lie inside one region (else YMI_EINVAL, the op and
+ *                     field named in ymi_last_error).  Synchronises `stream` and reads the constant regions back.
+ *   ymi_plan_import   allocates the regions (hipMalloc), uploads the constants, rebuilds the ops; the plan owns the
+ *                     memory (ymi_plan_destroy frees it).  regions_out[0 .. min(n, max_regions)) receives the new
+ *                     bases with the sizes / kinds / tags of the file.  Run with ymi_plan_run as usual.
+ * The file is tied to the ABI version and build it was written by (descriptor layouts, tile ids).
+ * ---------------------------------------------------------------------------------------- */
+#define YMI_REGION_CONST 1
+#define YMI_REGION_SCRATCH 2
+#define YMI_REGION_IO 3
+#define YMI_TAG_NONE 0
+#define YMI_TAG_INPUT 1      /* the letterboxed batch: NHWC4 canvas (n, h, w, 4) of the compute dtype, channel 3 zero (ymi_letterbox writes it) */
+#define YMI_TAG_RESCALE 2    /* ymi_post_desc.rescale: fp32 (n, 3) {gain, pad_x, pad_y} per image, written by the consumer per batch (zeros: boxes stay in canvas coordinates) */
+#define YMI_TAG_BOXES 3      /* fp32 (n, K, 4) */
+#define YMI_TAG_SCORES 4     /* fp32 (n, K) */
+#define YMI_TAG_LABELS 5     /* int64 (n, K) */
+#define YMI_TAG_STATUS_COUNT 6 /* int32 [8 status words | n counts] (ymi_post_desc.status / out_count share it) */
+#define YMI_TAG_SLAB 7       /* fp32 (n, 6K + 1) wire slab */
+typedef struct ymi_plan_region {
+    const void* base;
+    int64_t bytes;
+    int32_t kind, tag;
+} ymi_plan_region;
+int ymi_plan_export(const ymi_plan* p, const ymi_plan_region* regions, int n_regions, const char* path, void* stream);
+int ymi_plan_import(const char* path, ymi_plan** out_plan, ymi_plan_region* regions_out, int max_regions, int* n_regions_out);
 /* per-op timing with HIP events on `stream`: ms_out[num_ops], averaged over iters */
 int ymi_plan_profile(ymi_plan* p, int iters, float* ms_out, void* stream);
 

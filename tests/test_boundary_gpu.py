@@ -475,3 +475,62 @@ def test_bench_two_ranks_control_flow_on_one_gpu(dev):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"].startswith("dp2") and d["config"]["gather_second_rounds_rank0"] == 0
     assert "cpu_baseline" not in d   # rank 0 at N = 1 only
+
+
+def test_exported_plan_replays_without_python_objects(dev, tmp_path):
+    """round 6: `YOLO.export_plan` writes the recorded plan -- descriptors with (region, offset) pointers + the constant regions'
+    contents -- and `ymi_plan_import` rebuilds it in fresh device memory with nothing but the C ABI: the replay on the same letterboxed canvas returns the same detection
+    arrays bit for bit.  (A C++ consumer does exactly what this test does through ctypes: INTEGRATION.md section 5.)"""
+    import ctypes as C
+    from yolort_amd import _lib
+    from yolort_amd._lib import PlanRegion, TAG_BOXES, TAG_INPUT, TAG_LABELS, TAG_RESCALE, TAG_SCORES, TAG_STATUS_COUNT
+    from yolort_amd.models import YOLOv5
+    from workloads.synth import synth_images, synth_weights
+    lib = _lib.load(require_gpu=True)
+    for arch, S in (("yolov5_darknet_pan_n_r60", 160), ("yolov5_darknet_pan_s_r60", 320)):   # (s at 320: its C3 blocks of 64 / 128 hidden channels run through the strip kernel's weight streams)
+        m = YOLOv5(arch=arch, size=(S, S), score_thresh=0.1)
+        m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=0.8))
+        m = m.to(dev).half().eval()
+        imgs = [synth_images(1, S - 40, S, seed=21)[0].to(dev).half(), synth_images(1, S, S - 64, seed=22)[0].to(dev).half()]   # ragged sizes: the letterbox path (canvas input)
+        dets = m.predict(imgs)
+        torch.cuda.synchronize()
+        e = next(iter(m.model._entries.values()))
+        assert sum(len(d["scores"]) for d in dets) > 0
+        path = str(tmp_path / f"{arch}.ymiplan")
+        info = m.model.export_plan(path, e.x.n, e.x.h, e.x.w, dev)
+        assert os.path.getsize(path) > 1000 and info["ops"] == e.plan.num_ops
+        # ---- the consumer: C ABI only ----
+        plan2 = C.c_void_p()
+        regs = (PlanRegion * 4096)()
+        nreg = C.c_int(0)
+        assert lib.ymi_plan_import(path.encode(), C.byref(plan2), regs, 4096, C.byref(nreg)) == 0, lib.ymi_last_error()
+        assert nreg.value == info["regions"]
+        by_tag = {regs[i].tag: regs[i] for i in range(nreg.value) if regs[i].tag}
+        assert set(by_tag) >= {TAG_INPUT, TAG_RESCALE, TAG_BOXES, TAG_SCORES, TAG_LABELS, TAG_STATUS_COUNT}
+
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes, hip.hipMemcpy.restype = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int], C.c_int
+
+        def dev_copy(dst_ptr, src):   # device -> device, as the consumer would
+            torch.cuda.synchronize()
+            assert hip.hipMemcpy(dst_ptr, src.data_ptr(), src.numel() * src.element_size(), 3) == 0   # hipMemcpyDeviceToDevice
+
+        dev_copy(by_tag[TAG_INPUT].base, e.x.base)        # the letterboxed canvas of the batch above
+        dev_copy(by_tag[TAG_RESCALE].base, e.rescale)
+        s = torch.cuda.Stream()
+        assert lib.ymi_plan_run(plan2, 0, -1, 0, C.c_void_p(s.cuda_stream)) == 0, lib.ymi_last_error()
+        s.synchronize()
+
+        def read(tag, like):
+            out = torch.empty_like(like)
+            assert hip.hipMemcpy(out.data_ptr(), by_tag[tag].base, out.numel() * out.element_size(), 3) == 0
+            return out
+
+        boxes, scores, labels, sc = read(TAG_BOXES, e.post.boxes), read(TAG_SCORES, e.post.scores), read(TAG_LABELS, e.post.labels), read(TAG_STATUS_COUNT, e.post.status_count)
+        torch.cuda.synchronize()
+        cnt = sc[8:].tolist()
+        assert cnt == [len(d["scores"]) for d in dets], (cnt, [len(d["scores"]) for d in dets])
+        for i, d in enumerate(dets):
+            k = cnt[i]
+            assert torch.equal(boxes[i, :k], d["boxes"]) and torch.equal(scores[i, :k], d["scores"]) and torch.equal(labels[i, :k], d["labels"])
+        lib.ymi_plan_destroy(plan2)

@@ -55,6 +55,12 @@ class C3Desc(C.Structure):
     ]
 
 
+class PlanRegion(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("bytes", C.c_int64), ("kind", C.c_int32), ("tag", C.c_int32)]
+
+
+REGION_CONST, REGION_SCRATCH, REGION_IO = 1, 2, 3
+TAG_NONE, TAG_INPUT, TAG_RESCALE, TAG_BOXES, TAG_SCORES, TAG_LABELS, TAG_STATUS_COUNT, TAG_SLAB = range(8)
 ABI_VERSION = 6   # include/yolort_amd.h YMI_ABI_VERSION
 POST_EXACT_FULL = 1
 
@@ -129,6 +135,8 @@ _SIGS = {
     "ymi_plan_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "ymi_plan_done_query": (C.c_int, [C.c_void_p]),
     "ymi_plan_done_sync": (C.c_int, [C.c_void_p]),
+    "ymi_plan_export": (C.c_int, [C.c_void_p, C.POINTER(PlanRegion), C.c_int, C.c_char_p, C.c_void_p]),
+    "ymi_plan_import": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(PlanRegion), C.c_int, C.POINTER(C.c_int)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -104,6 +104,7 @@ struct ymi_plan {
     // ymi_plan_begin / ymi_plan_submit: inputs ready (caller's stream), conv stack done (main stream), batch done (side stream); created at first use
     hipEvent_t ev_in = nullptr, ev_conv = nullptr, ev_done = nullptr;
     bool submitted = false;
+    std::vector<void*> owned;   // device memory of an imported plan (ymi_plan_import): freed with it
 };
 
 using namespace ymi;
@@ -160,6 +161,7 @@ extern "C" void ymi_plan_destroy(ymi_plan* p) {
     drop_graph(p);
     for (hipEvent_t e : {p->ev_in, p->ev_conv, p->ev_done})
         if (e) (void)hipEventDestroy(e);
+    for (void* m : p->owned) (void)hipFree(m);
     delete p;
 }
 
@@ -436,4 +438,173 @@ extern "C" int ymi_plan_profile(ymi_plan* p, int iters, float* ms_out, void* str
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Plan export / import (include/yolort_amd.h): a recorded plan as a self-contained file -- the launch descriptors with every pointer rewritten as
+// (memory region, offset), the regions' sizes and roles, and the contents of the constant ones (packed weights, biases, im2col tables, weight streams).
+// A consumer without Python (a C++ server; the role yolort/runtime's TorchScript / ONNX artefacts play for the reference) calls ymi_plan_import, copies its
+// letterboxed batch into the INPUT region, runs ymi_plan_run and reads the OUTPUT regions.
+// ---------------------------------------------------------------------------------------------------
+namespace ymi {
+template <class F>
+static void for_each_pointer(Op& op, F&& f) {   // every device-pointer field of an op (unused ones are NULL: ops are zero-initialised)
+    auto conv = [&](ymi_conv_desc& c) {
+        f((void**)&c.x); f((void**)&c.w); f((void**)&c.bias); f((void**)&c.ktab); f((void**)&c.y); f((void**)&c.res); f((void**)&c.y2);
+        f((void**)&c.chain_w); f((void**)&c.chain_bias); f((void**)&c.chain_y); f((void**)&c.chain_x2); f((void**)&c.zeros);
+    };
+    conv(op.conv);
+    for (int l = 0; l < YMI_MAX_LEVELS; ++l) conv(op.convs[l]);
+    ymi_post_desc& q = op.post;
+    for (int l = 0; l < YMI_MAX_LEVELS; ++l) f((void**)&q.logits[l]);
+    f((void**)&q.rescale); f((void**)&q.out_boxes); f((void**)&q.out_scores); f((void**)&q.out_labels); f((void**)&q.out_count); f((void**)&q.status);
+    f((void**)&q.ws); f((void**)&q.out_slab);
+    ymi_c3_desc& c3 = op.c3;
+    f((void**)&c3.x); f((void**)&c3.y); f((void**)&c3.w12); f((void**)&c3.b12); f((void**)&c3.wm1); f((void**)&c3.bm1); f((void**)&c3.wm2); f((void**)&c3.bm2);
+    f((void**)&c3.w3); f((void**)&c3.b3); f((void**)&c3.wblob); f((void**)&c3.y1_in); f((void**)&c3.y1_out); f((void**)&c3.y2);
+    f((void**)&op.x); f((void**)&op.y);
+}
+struct PlanFileHeader {
+    char magic[8];            // "YMIPLAN1"
+    int32_t abi, n_regions, n_ops, fuse_stem;
+    int64_t op_bytes;         // sizeof(Op) of the writer: a reader built from other sources refuses the file
+};
+struct PlanFileRegion {
+    int64_t bytes;
+    int32_t kind, tag;
+};
+struct PlanFileReloc {
+    int32_t field;            // index of the pointer field in for_each_pointer order
+    int32_t region;
+    int64_t offset;
+};
+}  // namespace ymi
+
+extern "C" int ymi_plan_export(const ymi_plan* p, const ymi_plan_region* regions, int n_regions, const char* path, void* stream) {
+    YMI_REQUIRE(p && regions && n_regions > 0 && path, "ymi_plan_export: null argument");
+    for (int r = 0; r < n_regions; ++r)
+        YMI_REQUIRE(regions[r].base && regions[r].bytes > 0 && regions[r].kind >= YMI_REGION_CONST && regions[r].kind <= YMI_REGION_IO, "ymi_plan_export: region %d is empty or of unknown kind", r);
+    YMI_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));   // the constant regions are read back: whatever fills them has to be done
+    FILE* f = fopen(path, "wb");
+    YMI_REQUIRE(f != nullptr, "ymi_plan_export: cannot open %s for writing", path);
+    PlanFileHeader h;
+    memcpy(h.magic, "YMIPLAN1", 8);
+    h.abi = YMI_ABI_VERSION; h.n_regions = n_regions; h.n_ops = (int)p->ops.size(); h.fuse_stem = p->fuse_stem ? 1 : 0; h.op_bytes = (int64_t)sizeof(Op);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    for (int r = 0; r < n_regions && ok; ++r) {
+        PlanFileRegion fr = {regions[r].bytes, regions[r].kind, regions[r].tag};
+        ok = fwrite(&fr, sizeof(fr), 1, f) == 1;
+    }
+    std::vector<unsigned char> host;
+    for (int r = 0; r < n_regions && ok; ++r) {
+        if (regions[r].kind != YMI_REGION_CONST) continue;
+        host.resize((size_t)regions[r].bytes);
+        if (hipMemcpy(host.data(), regions[r].base, host.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+            fclose(f);
+            set_error("ymi_plan_export: reading region %d back failed", r);
+            return YMI_EHIP;
+        }
+        ok = fwrite(host.data(), 1, host.size(), f) == host.size();
+    }
+    int rc = YMI_OK;
+    for (size_t i = 0; i < p->ops.size() && ok && rc == YMI_OK; ++i) {
+        Op op = p->ops[i];
+        std::vector<PlanFileReloc> rel;
+        int field = 0;
+        for_each_pointer(op, [&](void** pp) {
+            const char* v = (const char*)*pp;
+            if (v != nullptr) {
+                int hit = -1;
+                for (int r = 0; r < n_regions; ++r) {
+                    const char* b = (const char*)regions[r].base;
+                    if (v >= b && v <= b + regions[r].bytes) { hit = r; break; }   // (<=: a zero page may sit at the very end of its buffer)
+                }
+                if (hit < 0) {
+                    if (rc == YMI_OK) set_error("ymi_plan_export: op %d, pointer field %d (%p) lies in none of the %d regions", (int)i, field, (const void*)v, n_regions);
+                    rc = YMI_EINVAL;
+                } else {
+                    rel.push_back({field, hit, (int64_t)(v - (const char*)regions[hit].base)});
+                }
+                *pp = nullptr;
+            }
+            ++field;
+        });
+        const int32_t nrel = (int32_t)rel.size();
+        ok = fwrite(&op, sizeof(op), 1, f) == 1 && fwrite(&nrel, sizeof(nrel), 1, f) == 1 && (nrel == 0 || fwrite(rel.data(), sizeof(PlanFileReloc), rel.size(), f) == rel.size());
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (rc != YMI_OK) return rc;
+    YMI_REQUIRE(ok, "ymi_plan_export: writing %s failed", path);
+    return YMI_OK;
+}
+
+extern "C" int ymi_plan_import(const char* path, ymi_plan** out_plan, ymi_plan_region* regions_out, int max_regions, int* n_regions_out) {
+    YMI_REQUIRE(path && out_plan, "ymi_plan_import: null argument");
+    *out_plan = nullptr;
+    FILE* f = fopen(path, "rb");
+    YMI_REQUIRE(f != nullptr, "ymi_plan_import: cannot open %s", path);
+    PlanFileHeader h;
+    std::vector<PlanFileRegion> fr;
+    ymi_plan* p = nullptr;
+    std::vector<void*> base;
+    auto fail = [&](const char* why) {
+        fclose(f);
+        if (p) ymi_plan_destroy(p);
+        else for (void* m : base) (void)hipFree(m);
+        set_error("ymi_plan_import: %s (%s)", why, path);
+        return YMI_EINVAL;
+    };
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "YMIPLAN1", 8) != 0) return fail("not a plan file");
+    if (h.abi != YMI_ABI_VERSION || h.op_bytes != (int64_t)sizeof(Op)) return fail("written by another ABI version of the library");
+    if (h.n_regions <= 0 || h.n_regions > (1 << 20) || h.n_ops < 0 || h.n_ops > (1 << 20)) return fail("corrupt header");
+    fr.resize(h.n_regions);
+    if (fread(fr.data(), sizeof(PlanFileRegion), fr.size(), f) != fr.size()) return fail("truncated region table");
+    std::vector<unsigned char> host;
+    for (int r = 0; r < h.n_regions; ++r) {
+        if (fr[r].bytes <= 0) return fail("corrupt region table");
+        void* m = nullptr;
+        if (hipMalloc(&m, (size_t)fr[r].bytes) != hipSuccess) return fail("out of device memory");
+        base.push_back(m);
+        if (fr[r].kind == YMI_REGION_CONST) {
+            host.resize((size_t)fr[r].bytes);
+            if (fread(host.data(), 1, host.size(), f) != host.size()) return fail("truncated region contents");
+            if (hipMemcpy(m, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
+        } else if (hipMemset(m, 0, (size_t)fr[r].bytes) != hipSuccess) {   // scratch / IO regions start zeroed (zero tails, zero-initialised concat buffers)
+            return fail("memset failed");
+        }
+    }
+    p = ymi_plan_create();
+    if (!p) return fail("out of memory");
+    p->owned = base;
+    p->fuse_stem = h.fuse_stem != 0;
+    for (int i = 0; i < h.n_ops; ++i) {
+        Op op;
+        int32_t nrel = 0;
+        if (fread(&op, sizeof(op), 1, f) != 1 || fread(&nrel, sizeof(nrel), 1, f) != 1 || nrel < 0 || nrel > 256) return fail("truncated op list");
+        std::vector<PlanFileReloc> rel((size_t)nrel);
+        if (nrel && fread(rel.data(), sizeof(PlanFileReloc), rel.size(), f) != rel.size()) return fail("truncated relocation list");
+        int field = 0;
+        size_t k = 0;
+        bool bad = false;
+        for_each_pointer(op, [&](void** pp) {
+            *pp = nullptr;
+            if (k < rel.size() && rel[k].field == field) {
+                const PlanFileReloc& q = rel[k++];
+                if (q.region < 0 || q.region >= h.n_regions || q.offset < 0 || q.offset > fr[q.region].bytes) bad = true;
+                else *pp = (char*)base[q.region] + q.offset;
+            }
+            ++field;
+        });
+        if (bad || k != rel.size()) return fail("corrupt relocation");
+        p->ops.push_back(op);
+    }
+    fclose(f);
+    if (n_regions_out) *n_regions_out = h.n_regions;
+    if (regions_out)
+        for (int r = 0; r < h.n_regions && r < max_regions; ++r) {
+            regions_out[r].base = base[r]; regions_out[r].bytes = fr[r].bytes; regions_out[r].kind = fr[r].kind; regions_out[r].tag = fr[r].tag;
+        }
+    *out_plan = p;
+    return YMI_OK;
 }

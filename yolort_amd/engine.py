@@ -598,6 +598,9 @@ class Plan:
         blob = torch.empty(nb, device=self.device, dtype=torch.uint8)
         check(self.lib.ymi_c3_pack(C.byref(d), blob.data_ptr(), _lib.stream_ptr() if self.device.type == "cuda" else None), "ymi_c3_pack")
         d.wblob = blob.data_ptr()
+        if not hasattr(self, "_const_tensors"):
+            self._const_tensors = set()
+        self._const_tensors.add(id(blob))   # (Plan.export: a constant region, its contents are part of the file)
         self.keep.extend([pc12, pcm1, pcm2, pc3, blob, d])
         npix, esz = src.n * src.h * src.w, 2
         # the reference convolutions this launch stands for: (cin, cout, taps); every one reads its input once and writes its output once
@@ -763,6 +766,57 @@ class Plan:
             return scan[3] == (3, hb, wb) and scan[5] and scan[6] and scan[1] == self.device.index and images[0].dtype == self.dtype
         return all(im.device == self.device and im.dtype == self.dtype and tuple(im.shape) == (3, hb, wb) and im.is_contiguous() and im.data_ptr() % 16 == 0
                    for im in images)
+
+    # ---- export ----
+    def export(self, path: str, io: Optional[Dict[int, Tensor]] = None) -> int:
+        """Writes the recorded plan as a self-contained file (ymi_plan_export, include/yolort_amd.h): every launch descriptor with its pointers rewritten as (region,
+        offset), and the contents of the constant regions -- packed weights, biases, im2col tables, the strip kernel's weight streams.  A consumer without Python loads
+        it with ymi_plan_import and replays it with ymi_plan_run.  `io`: {YMI_TAG_*: tensor} names the regions the consumer talks to
+        (the input canvas, the rescale rows, the detection arrays).  Returns the number of regions.  The reference's counterpart is the TorchScript / ONNX export of
+        yolort/relay + yolort/runtime (out of scope: SURVEY.md 8 row f3 asks for the in-scope equivalent)."""
+        from ._lib import PlanRegion, REGION_CONST, REGION_IO, REGION_SCRATCH
+        tensors: List[Tuple[Tensor, int]] = []   # (tensor, kind)
+
+        def add(t, kind):
+            if isinstance(t, Tensor) and t.numel() > 0 and t.device.type == self.device.type:
+                tensors.append((t, kind))
+
+        def walk(o):
+            if isinstance(o, Tensor):
+                add(o, REGION_SCRATCH)
+            elif isinstance(o, PackedConv):
+                add(o.w, REGION_CONST)
+                add(o.bias, REGION_CONST)
+                for kt in o._ktabs.values():
+                    add(kt, REGION_CONST)
+            elif isinstance(o, PostBuffers):
+                for t in (o.boxes, o.scores, o.labels, o.status_count, o.slab, o.ws, o.rescale):
+                    add(t, REGION_SCRATCH)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+
+        walk(self.keep)
+        add(self.zeros, REGION_SCRATCH)
+        const_ids = getattr(self, "_const_tensors", set())
+        tags = {int(t.untyped_storage().data_ptr()): tag for tag, t in (io or {}).items()}
+        seen: Dict[int, Tuple[int, int, int]] = {}   # storage base -> (bytes, kind, tag)
+        for t, kind in tensors:
+            st = t.untyped_storage()
+            base, nbytes = int(st.data_ptr()), int(st.nbytes())
+            if id(t) in const_ids:
+                kind = REGION_CONST
+            tag = tags.get(base, 0)
+            if tag:
+                kind = REGION_IO
+            old = seen.get(base)
+            if old is None or kind == REGION_CONST or (kind == REGION_IO and old[1] == REGION_SCRATCH):
+                seen[base] = (max(nbytes, old[0]) if old else nbytes, kind, tag or (old[2] if old else 0))
+        regs = (PlanRegion * len(seen))()
+        for i, (base, (nbytes, kind, tag)) in enumerate(sorted(seen.items())):
+            regs[i].base, regs[i].bytes, regs[i].kind, regs[i].tag = base, nbytes, kind, tag
+        check(self.lib.ymi_plan_export(self.handle, regs, len(seen), path.encode(), _lib.stream_ptr()), "ymi_plan_export")
+        return len(seen)
 
     # ---- execution ----
     @property

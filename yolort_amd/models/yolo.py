@@ -243,6 +243,21 @@ class YOLO(nn.Module):
         self._frozen_signature = weights_signature(self) if frozen else None
         return self
 
+    def export_plan(self, path: str, n: int, h: int, w: int, device: Optional[torch.device] = None) -> Dict[str, object]:
+        """Records (or reuses) the plan of an (n, h, w) canvas and writes it to `path` as a self-contained file: a C++ consumer replays it with ymi_plan_import +
+        ymi_plan_run, no Python (include/yolort_amd.h; the in-scope counterpart of the reference's yolort/relay export).  The file holds the
+        canvas form of the plan (op 0 reads the letterboxed NHWC4 batch: ymi_letterbox fills it), the post-process included.  Returns a description of the IO regions."""
+        from .._lib import TAG_BOXES, TAG_INPUT, TAG_LABELS, TAG_RESCALE, TAG_SCORES, TAG_SLAB, TAG_STATUS_COUNT
+        device = device or next(self.parameters()).device
+        e = self._entry(n, h, w, device)
+        if e.post is None:
+            raise YmiError("export_plan needs the fused post-process (head, anchor generator and post-process of this package)")
+        io = {TAG_INPUT: e.x.base, TAG_RESCALE: e.rescale, TAG_BOXES: e.post.boxes, TAG_SCORES: e.post.scores, TAG_LABELS: e.post.labels,
+              TAG_STATUS_COUNT: e.post.status_count, TAG_SLAB: e.post.slab}
+        nreg = e.plan.export(path, io)
+        return {"path": path, "regions": nreg, "ops": e.plan.num_ops, "n_conv_ops": e.n_backbone_ops if hasattr(e, "n_backbone_ops") else None,
+                "input": {"shape": (n, h, w, 4), "dtype": str(e.x.dtype)}, "detections_per_img": int(e.post.k)}
+
     def fused(self) -> bool:
         return type(self.head) is YOLOHead and type(self.post_process) is PostProcess and type(self.anchor_generator) is AnchorGenerator and hasattr(self.backbone, "emit")
 
