@@ -516,10 +516,12 @@ extern "C" int ymi_plan_export(const ymi_plan* p, const ymi_plan_region* regions
             const char* v = (const char*)*pp;
             if (v != nullptr) {
                 int hit = -1;
-                for (int r = 0; r < n_regions; ++r) {
+                for (int r = 0; r < n_regions && hit < 0; ++r) {
                     const char* b = (const char*)regions[r].base;
-                    if (v >= b && v <= b + regions[r].bytes) { hit = r; break; }   // (<=: a zero page may sit at the very end of its buffer)
+                    if (v >= b && v < b + regions[r].bytes) hit = r;
                 }
+                for (int r = 0; r < n_regions && hit < 0; ++r)   // (a one-past-the-end pointer, only when no region holds the address: allocations may be adjacent)
+                    if (v == (const char*)regions[r].base + regions[r].bytes) hit = r;
                 if (hit < 0) {
                     if (rc == YMI_OK) set_error("ymi_plan_export: op %d, pointer field %d (%p) lies in none of the %d regions", (int)i, field, (const void*)v, n_regions);
                     rc = YMI_EINVAL;
@@ -563,9 +565,13 @@ extern "C" int ymi_plan_import(const char* path, ymi_plan** out_plan, ymi_plan_r
     std::vector<unsigned char> host;
     for (int r = 0; r < h.n_regions; ++r) {
         if (fr[r].bytes <= 0) return fail("corrupt region table");
+        // (slack behind every region: the exporting process carved its tensors out of an allocator's large segments, where a kernel's 16-byte chunk or padded weight
+        // row that reaches a little past a tensor's end reads neighbouring memory; here every region is an allocation of its own)
         void* m = nullptr;
-        if (hipMalloc(&m, (size_t)fr[r].bytes) != hipSuccess) return fail("out of device memory");
+        constexpr size_t SLACK = 64 * 1024;
+        if (hipMalloc(&m, (size_t)fr[r].bytes + SLACK) != hipSuccess) return fail("out of device memory");
         base.push_back(m);
+        if (hipMemset((char*)m + fr[r].bytes, 0, SLACK) != hipSuccess) return fail("memset failed");
         if (fr[r].kind == YMI_REGION_CONST) {
             host.resize((size_t)fr[r].bytes);
             if (fread(host.data(), 1, host.size(), f) != host.size()) return fail("truncated region contents");
