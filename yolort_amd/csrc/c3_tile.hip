@@ -156,39 +156,14 @@ __device__ __forceinline__ void c3t_lds_dep(F& f) {
 #endif
 }
 
-// Phase A's activation fragments come through vector memory one or two k32 chunks ahead.  As plain loads hipcc waits for them with vmcnt(0) at every control-flow
-// merge (the unit guards, the sender's branches): the whole prefetch ring drains at each chunk.  As inline assembly it neither moves nor counts them; the consumer
-// waits with a COUNTED vmcnt computed from this wave's own issue sequence numbers (loads retire in order).
-template <class F>
-__device__ __forceinline__ void c3t_gload(F& dst, const char* base_uniform, unsigned voff) {
-#ifdef YMI_HIPSIM
-    dst = *reinterpret_cast<const F*>(base_uniform + voff);
-#else
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base_uniform));
-#endif
-}
-
 __device__ __forceinline__ void c3t_wait_vmcnt(int n) {   // at most n vector-memory operations of this wave still in flight (a smaller count is always safe)
     switch (n) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;
-        case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;
-        case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break;
-        case 13: wait_vmcnt<13>(); break;
-        case 14: wait_vmcnt<14>(); break;
-        case 15: wait_vmcnt<15>(); break;
-        case 16: wait_vmcnt<16>(); break;
-        case 17: wait_vmcnt<17>(); break;
-        default: wait_vmcnt<18>(); break;
+#define C3T_VM(k) case k: wait_vmcnt<k>(); break;
+        C3T_VM(0) C3T_VM(1) C3T_VM(2) C3T_VM(3) C3T_VM(4) C3T_VM(5) C3T_VM(6) C3T_VM(7) C3T_VM(8) C3T_VM(9) C3T_VM(10) C3T_VM(11) C3T_VM(12) C3T_VM(13) C3T_VM(14) C3T_VM(15)
+        C3T_VM(16) C3T_VM(17) C3T_VM(18) C3T_VM(19) C3T_VM(20) C3T_VM(21) C3T_VM(22) C3T_VM(23) C3T_VM(24) C3T_VM(25) C3T_VM(26) C3T_VM(27) C3T_VM(28) C3T_VM(29) C3T_VM(30) C3T_VM(31)
+        C3T_VM(32) C3T_VM(33) C3T_VM(34) C3T_VM(35) C3T_VM(36) C3T_VM(37) C3T_VM(38) C3T_VM(39)
+#undef C3T_VM
+        default: wait_vmcnt<40>(); break;
     }
 }
 
@@ -201,6 +176,7 @@ template <int DT, int CH, int ROLE>
 __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsigned char* const c3t_sm, const int wave, const int lane) {
     typedef C3TRole<CH, ROLE> Role;
     constexpr int NP = CH / 32, NG = Role::NG, NC = Role::NC, NCA = NC > 0 ? NC : 1;
+    constexpr bool XL = CH == 64;   // phase A's activations come through the patch (LDS-DMA) / through a register ring: see below
     // The weight ring: TWO slots of 36 KiB.  A stage is as many whole units of its phase as fit a slot -- few, long steps: every step costs a barrier, a planning
     // pass and an exposed first LDS round trip whatever its length (measured: 34 of 56 us remained with the MFMAs removed at 30 steps per strip, profiles/r06g_dbg.txt)
     //   A / D   unit = one k32 chunk of the 2 CH stacked rows (4 NP KiB);   B   the whole of m.cv1 (2 NP^2 KiB);   C   unit = one tap of one k32 chunk (2 NP KiB)
@@ -220,7 +196,8 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
     typedef typename Mfma<DT>::frag frag;
 
     const f32x4* const bl = reinterpret_cast<const f32x4*>(c3t_sm);
-    unsigned char* const T = c3t_sm + BIAS_BYTES;
+    unsigned char* const dump = c3t_sm + BIAS_BYTES;          // 1 KiB nobody reads: where a DMA piece that must not land anywhere goes (no branch round it)
+    unsigned char* const T = dump + 1024;
     const int plane_b = g.nslot * 64;                         // one 32-channel plane of the patch
     unsigned char* const ring = T + NP * plane_b;
     const int hi = lane >> 5, frow = lane & 31;
@@ -360,20 +337,75 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
             pmf_[k] = (((img * a.h + cy) * a.w + cx) << 2) | (inside ? 1 : 0) | ((inside && r >= 1 && r <= g.R) ? 2 : 0);
         }
     };
-    // phase A's activation fragments: lane (pixel, hi) reads channels 16 t + 8 hi .. + 7 of its pixel for k16 step t.  They come straight from memory (HBM / the
-    // infinity cache: ~1.4 us per round trip under load, measured as the cost of one more k32 chunk with a one-chunk lookahead) against 0.5-0.6 us of MFMAs per
-    // chunk: a register ring of XF k16 steps per group keeps XF - 1 of them in flight -- slot t % XF is reloaded with step t + XF right after its last use.
-    // Addresses = block-uniform base (x + 32 t bytes) + a 32-bit per-lane byte offset per group (the launcher checks the tensor stays below 2 GiB).
+    // Phase A's activations.  Straight from memory into registers one k32 chunk ahead they bound the phase: ~1.4 us per round trip (HBM / the infinity cache under
+    // load) against 0.5 us of MFMAs per chunk, and a deeper register ring spills (profiles/r06i_*, r06q_*).  The patch T is idle until phase B's epilogue, so it is the
+    // prefetch ring: plane j % NP holds chunk j of this wave's OWN groups' slots in the patch layout (16-byte octet o of slot q at q * 64 + ((o ^ ((q >> 2) & 3)) * 16)),
+    // written by LDS-DMA pieces of 16 slots (lane l: slot l >> 2, position l & 3 -- the swizzle is applied on the source side), NP - 1 chunks ahead, and read back as
+    // MFMA fragments exactly like phase C reads t.  No other wave touches these slots before phase C: the only synchronisation is this wave's own counted vmcnt.
+    unsigned xqo[NG][2];        // per-lane byte offset of the lane's 16 bytes of chunk 0 for piece p of group k (the launcher checks the tensor stays below 2 GiB)
+    int xseq[NP];               // sequence number of the last piece of the chunk in each plane
+#pragma unroll
+    for (int j = 0; j < NP; ++j) xseq[j] = 0;
+    auto x_offsets = [&](int t) {
+        const int img = t / g.tiles_per_img, ty = t - img * g.tiles_per_img;
+#pragma unroll
+        for (int k = 0; k < NG; ++k)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int q = (jg[k] >= 0 ? jg[k] : 0) * 32 + p * 16 + (lane >> 2);
+                const int qq = q - g.delta;
+                const int qp = qq >= 0 ? qq : 0;
+                const int r0 = fast_div(qp, g.pw, g.magic_pw);
+                const int c = qp - r0 * g.pw;
+                const int iy = ty * g.R + (qq >= 0 ? r0 : 0) - 1;
+                const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = c < a.w ? c : a.w - 1;   // (slots outside the image read a pixel inside it: masked later)
+                const int oct = (lane & 3) ^ ((q >> 2) & 3);
+                xqo[k][p] = ((unsigned)((img * a.h + cy) * a.w + cx) * (unsigned)a.x_cs + 8u * (unsigned)oct) * 2u;
+            }
+    };
+    auto issue_x = [&](int jc, int plane, bool real) {   // chunk jc -> `plane`; !real (a refill past the last chunk): into the dump
+        const int jcc = jc < a.nst_a ? jc : a.nst_a - 1;  // (the padded chunks multiply a real chunk's finite values by zero weights)
+        const char* const xb = reinterpret_cast<const char*>(a.x) + (size_t)jcc * 64;   // block-uniform
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const bool ok = real && jg[k] >= 0;
+            unsigned char* const dst = T + plane * plane_b + (jg[k] >= 0 ? jg[k] : 0) * 2048;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) glds16(reinterpret_cast<const uint16_t*>(xb + xqo[k][p]), reinterpret_cast<uint16_t*>(ok ? dst + p * 1024 : dump));
+        }
+        vseq += 2 * NG;
+        xseq[plane] = real ? vseq : xseq[plane];
+        asm volatile("" ::: "memory");
+    };
+    auto fill_x = [&]() {   // a tile's first NP chunks
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_x(j, j, true);
+    };
+    // LDS byte offset of this lane's fragment (k16 half 0; half 1 = ^ 32) of its slot in a plane, per group
+    int xa[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int q = (jg[k] >= 0 ? jg[k] : 0) * 32 + frow;
+        xa[k] = q * 64 + ((hi ^ ((q >> 2) & 3)) * 16);
+    }
+    const unsigned t_lds0 = c3t_lds_addr(T);
+    auto wait_loads = [&](int n) {   // at most n of this wave's loads still in flight (stores in between: loads and stores retire out of order with each other -> all)
+        c3t_wait_vmcnt(st_pending ? 0 : n);
+        st_pending = false;
+        __builtin_amdgcn_wave_barrier();   // (no instruction: what the other lanes' pieces wrote is read below -- the simulator runs lanes apart between such points)
+    };
+
+    // Hidden width 128 keeps the earlier form -- straight into a register ring of XF k16 steps per group, slot t % XF reloaded with step t + XF right after its last
+    // use (block-uniform base x + 32 t bytes + a 32-bit per-lane byte offset per group): there the patch route measured 4 us SLOWER per launch (its first four
+    // chunks, 72 pieces, queue in front of the first MFMA of a block that walks a single tile; profiles/r06r_*), at hidden width 64 9 us faster.
     constexpr int XF = 2;   // (deeper rings were measured slower: with 256 registers the extra slots spill, and every scratch reload is a vmcnt(0) that drains the ring -- profiles/r06i_*)
-    constexpr int XU = (XF / 2 + KC - 1) / KC;   // stages per trip round the ring (the stage loop is unrolled by it: ring slots are compile-time)
-    static_assert((XU * KC * 2) % XF == 0 && 4 % (XU * KC) == 0, "a stage starts at a fixed ring slot; the stream pads phase A to multiples of 4 chunks");
     frag xf[NG][XF];
 #pragma unroll
     for (int k = 0; k < NG; ++k)
 #pragma unroll
         for (int t = 0; t < XF; ++t) xf[k][t] = frag{};
     unsigned xo[NG];
-    auto x_offsets = [&](const int (&pmf_)[NG]) {
+    auto xr_offsets = [&](const int (&pmf_)[NG]) {
 #pragma unroll
         for (int k = 0; k < NG; ++k) xo[k] = ((unsigned)(pmf_[k] >> 2) * (unsigned)a.x_cs + 8u * (unsigned)hi) * 2u;
     };
@@ -390,30 +422,50 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
         static_for<0, XF>([&](auto tt) { load_x(decltype(tt)::value, tt); });
     };
 
-    // prologue: the first stage, then the first tile's first activation fragments
+    // prologue: the first stage, then the first tile's first activation chunks
     send_stage();
     if (has_a) {
-        tile_geom(xcd_remap(idx, ntiles), pmf);
-        x_offsets(pmf);
-        load_x_head();
+        if constexpr (XL) {
+            x_offsets(xcd_remap(idx, ntiles));
+            fill_x();
+        } else {
+            tile_geom(xcd_remap(idx, ntiles), pmf);
+            xr_offsets(pmf);
+            load_x_head();
+        }
     }
 
     for (; idx < ntiles; idx += gridDim.x) {
         const bool more = idx + (int)gridDim.x < ntiles;
         tile_geom(xcd_remap(idx, ntiles), pmf);
-        if (has_a) x_offsets(pmf);
+        if constexpr (!XL) { if (has_a) xr_offsets(pmf); }
         C3T_STAMP(8);
 
         // packets: the rounded outputs of a 1x1 as 16-byte channel octets (cout group i, packet p: octets 2p + hi of the group) -- exactly the activation fragments
         // of the next 1x1.  pk1 = cv1's / the Bottleneck's input, later the Bottleneck's output; pk2 = cv2's (centre groups)
         u32x4 pk1[NG][NP][2], pk2[NCA][NP][2];
-        // the next tile's first activation fragments: issued behind the last MFMA of this tile (ahead of its epilogue)
+        // the next tile's first activation chunks go into the patch: once every wave is past its last read of t (behind a barrier that follows phase C)
         auto prefetch_next_x = [&]() {
             if (more && has_a) {
-                int pmn[NG];
-                tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
-                x_offsets(pmn);
-                load_x_head();
+                if constexpr (XL) {
+                    x_offsets(xcd_remap(idx + (int)gridDim.x, ntiles));
+                    fill_x();
+                } else {
+                    int pmn[NG];
+                    tile_geom(xcd_remap(idx + (int)gridDim.x, ntiles), pmn);
+                    xr_offsets(pmn);
+                    load_x_head();
+                }
+            }
+        };
+        auto head_prefetch = [&]() {   // a launch without phase D (HEAD): one more barrier behind phase C, ahead of the epilogue that hides the round trip
+            if constexpr (XL) {
+                if (more && has_a) {   // block-uniform
+                    __builtin_amdgcn_s_barrier();
+                    prefetch_next_x();
+                }
+            } else {
+                prefetch_next_x();
             }
         };
 
@@ -427,38 +479,98 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
 #pragma unroll
                 for (int k = 0; k < NCA; ++k) acc2[k][i] = c3t_bias_acc(bl, NP + i, hi);
             }
-            for (int j0 = 0; j0 < a.nst_ap; j0 += XU * KC) {   // (the stream pads phase A with zero chunks to whole stages; their activation loads are clamped to the last real k16 step)
-                static_for<0, XU>([&](auto ut) {
-                    constexpr int u = decltype(ut)::value;
-                    const int jb = j0 + u * KC;   // first chunk of this stage
-                    step_sync();
-                    auto mma = [&](auto kct, auto subt, frag (&w)[NP]) {
-                        constexpr int kc = decltype(kct)::value, sub = decltype(subt)::value;
-                        constexpr int s = NC > 0 ? sub >> 1 : sub, half = NC > 0 ? sub & 1 : 0;
-                        constexpr int slot = (2 * (u * KC + kc) + s) % XF;   // ring slot of k16 step 2 (jb + kc) + s
-                        if constexpr (half == 0) {
+            if constexpr (XL) {
+                // the stage loop is unrolled by XU stages = NP chunks: a chunk's plane is compile-time (the stream pads phase A with zero chunks to multiples of 4)
+                constexpr int XU = NP > KC ? NP / KC : 1;
+                static_assert((XU * KC) % NP == 0 && 4 % (XU * KC) == 0, "a trip of the unrolled loop starts at plane 0");
+                frag xq[NG][2];   // the activation fragments of k16 step t in xq[.][t & 1]: read one step ahead
+                wait_loads(vseq - xseq[0]);
 #pragma unroll
-                            for (int k = 0; k < NG; ++k)
+                for (int k = 0; k < NG; ++k) c3t_lds_read<0>(xq[k][0], T + xa[k], t_lds0 + (unsigned)xa[k]);
+                for (int j0 = 0; j0 < a.nst_ap; j0 += XU * KC) {
+                    static_for<0, XU>([&](auto ut) {
+                        constexpr int u = decltype(ut)::value;
+                        const int jb = j0 + u * KC;   // first chunk of this stage
+                        step_sync();
+                        auto mma = [&](auto kct, auto subt, frag (&w)[NP]) {
+                            constexpr int kc = decltype(kct)::value, sub = decltype(subt)::value;
+                            constexpr int s = NC > 0 ? sub >> 1 : sub, half = NC > 0 ? sub & 1 : 0;
+                            constexpr int plane = (u * KC + kc) % NP;
+                            if constexpr (half == 0) {
 #pragma unroll
-                                for (int i = 0; i < NP; ++i) acc1[k][i] = C3T_MMA(w[i], xf[k][slot], acc1[k][i]);
-                        } else {
+                                for (int k = 0; k < NG; ++k) c3t_lds_dep(xq[k][s]);
 #pragma unroll
-                            for (int k = 0; k < NC; ++k)
+                                for (int k = 0; k < NG; ++k)
 #pragma unroll
-                                for (int i = 0; i < NP; ++i) acc2[k][i] = C3T_MMA(w[i], xf[k][slot], acc2[k][i]);
-                        }
-                        if constexpr (half == 1 || NC == 0) load_x(2 * (jb + kc) + s + XF, std::integral_constant<int, slot>{});   // the last use of this slot: XF steps ahead
-                    };
-                    if constexpr (NC > 0) w_stage(std::integral_constant<int, 4>{}, C3TOffAD<NP>{}, mma);
-                    else w_stage(std::integral_constant<int, 2>{}, C3TOffAH<NP>{}, mma);
-                    step_end();
-                });
+                                    for (int i = 0; i < NP; ++i) acc1[k][i] = C3T_MMA(w[i], xq[k][s], acc1[k][i]);
+                                // the next k16 step's fragments (ahead of the weight reads w_stage issues next: LDS returns in order, the next wait covers them)
+                                if constexpr (s == 0) {
+#pragma unroll
+                                    for (int k = 0; k < NG; ++k) {
+                                        const int e = plane * plane_b + (xa[k] ^ 32);
+                                        c3t_lds_read<0>(xq[k][1], T + e, t_lds0 + (unsigned)e);
+                                    }
+                                } else {
+                                    constexpr int pn = (plane + 1) % NP;
+                                    wait_loads(vseq - xseq[pn]);   // the next chunk has landed (behind the last chunk: a stale plane, read and never used)
+#pragma unroll
+                                    for (int k = 0; k < NG; ++k) {
+                                        const int e = pn * plane_b + xa[k];
+                                        c3t_lds_read<0>(xq[k][0], T + e, t_lds0 + (unsigned)e);
+                                    }
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                                    for (int i = 0; i < NP; ++i) acc2[k][i] = C3T_MMA(w[i], xq[k][s], acc2[k][i]);
+                            }
+                            if constexpr ((half == 1 || NC == 0) && s == 1) {   // the chunk's last sub-step: its plane takes the chunk NP ahead
+                                const int jn = jb + kc + NP;
+                                issue_x(jn, plane, jn < a.nst_a);
+                            }
+                        };
+                        if constexpr (NC > 0) w_stage(std::integral_constant<int, 4>{}, C3TOffAD<NP>{}, mma);
+                        else w_stage(std::integral_constant<int, 2>{}, C3TOffAH<NP>{}, mma);
+                        step_end();
+                    });
+                }
+            } else {
+                constexpr int XU = (XF / 2 + KC - 1) / KC;   // stages per trip round the register ring (the stage loop is unrolled by it: ring slots are compile-time)
+                static_assert((XU * KC * 2) % XF == 0 && 4 % (XU * KC) == 0, "a stage starts at a fixed ring slot; the stream pads phase A to multiples of 4 chunks");
+                for (int j0 = 0; j0 < a.nst_ap; j0 += XU * KC) {   // (the stream pads phase A with zero chunks to whole stages; their activation loads are clamped to the last real k16 step)
+                    static_for<0, XU>([&](auto ut) {
+                        constexpr int u = decltype(ut)::value;
+                        const int jb = j0 + u * KC;   // first chunk of this stage
+                        step_sync();
+                        auto mma = [&](auto kct, auto subt, frag (&w)[NP]) {
+                            constexpr int kc = decltype(kct)::value, sub = decltype(subt)::value;
+                            constexpr int s = NC > 0 ? sub >> 1 : sub, half = NC > 0 ? sub & 1 : 0;
+                            constexpr int slot = (2 * (u * KC + kc) + s) % XF;   // ring slot of k16 step 2 (jb + kc) + s
+                            if constexpr (half == 0) {
+#pragma unroll
+                                for (int k = 0; k < NG; ++k)
+#pragma unroll
+                                    for (int i = 0; i < NP; ++i) acc1[k][i] = C3T_MMA(w[i], xf[k][slot], acc1[k][i]);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                                    for (int i = 0; i < NP; ++i) acc2[k][i] = C3T_MMA(w[i], xf[k][slot], acc2[k][i]);
+                            }
+                            if constexpr (half == 1 || NC == 0) load_x(2 * (jb + kc) + s + XF, std::integral_constant<int, slot>{});   // the last use of this slot: XF steps ahead
+                        };
+                        if constexpr (NC > 0) w_stage(std::integral_constant<int, 4>{}, C3TOffAD<NP>{}, mma);
+                        else w_stage(std::integral_constant<int, 2>{}, C3TOffAH<NP>{}, mma);
+                        step_end();
+                    });
+                }
+                pseq = vseq;   // (the surplus reloads behind the last chunk are dead and may not have been issued at all: do not count on them -- the next wait is vmcnt(0))
+#pragma unroll
+                for (int k = 0; k < NG; ++k)
+#pragma unroll
+                    for (int t = 0; t < XF; ++t) xf[k][t] = frag{};   // (the ring is dead until the next tile's head loads: say so, or its registers stay reserved through phases B - D)
             }
-            pseq = vseq;   // (the surplus reloads behind the last chunk are dead and may not have been issued at all: do not count on them -- the next wait is vmcnt(0))
-#pragma unroll
-            for (int k = 0; k < NG; ++k)
-#pragma unroll
-                for (int t = 0; t < XF; ++t) xf[k][t] = frag{};   // (the ring is dead until the next tile's head loads: say so, or its registers stay reserved through phases B - D)
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
 #pragma unroll
@@ -566,6 +678,7 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
                 send_stage();
                 step_end();
             }
+            if (!has_d) head_prefetch();
         } else {
             // LDS byte offsets of the nine taps' fragments (k16 half 0; half 1 = ^ 32) inside a plane.  Slot q' = q + (dy - 1) pw + (dx - 1) holds its four 16-byte channel
             // octets at q' * 64 + ((octet ^ ((q' >> 2) & 3)) * 16): 32 CONSECUTIVE slots under any constant shift cover every 16-byte bank slot once per ds_read_b128 lane
@@ -634,7 +747,7 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
                 });
                 step_end();
             });
-            if (!has_d) prefetch_next_x();
+            if (!has_d) head_prefetch();
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -671,6 +784,7 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
                 for (int j = 0; j < NSTD; ++j) {
                     step_sync();
                     send_stage();
+                    if (j == 0) prefetch_next_x();
                     step_end();
                 }
             } else {
@@ -707,12 +821,15 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
                             for (int i = 0; i < NP; ++i) acc[c][half * NP + i] = C3T_MMA(w[sub % 2][i], xb, acc[c][half * NP + i]);
                         }
                         if constexpr (sub + 2 < 4 * KC) rd(std::integral_constant<int, sub + 2>{});
-                        if constexpr (sub == 0) send_stage();
+                        if constexpr (sub == 0) {
+                            send_stage();
+                            if constexpr (st == 0 && XL) prefetch_next_x();   // every wave is past phase C (this stage's barrier)
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     });
                     step_end();
                 });
-                prefetch_next_x();
+                if constexpr (!XL) prefetch_next_x();   // behind the tile's last MFMA, ahead of its epilogue
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     uint16_t* yp = a.y + (int64_t)(pmf[c] >> 2) * a.y_cs + 8 * hi;
@@ -729,7 +846,6 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
                 }
             }
         }
-        if constexpr (NC == 0) prefetch_next_x();   // (a halo-only role has no epilogue to hide it behind)
         C3T_STAMP(12);
     }
     wait_vmcnt<0>();   // the pieces sent behind the last tile's last stages must not land in another block's LDS
@@ -893,7 +1009,7 @@ static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
     constexpr int NP = CH / 32, GC = CH == 128 ? 1 : 2;   // centre groups per wave
     const int pw = w + 1;
     const int lds_max = 160 * 1024;
-    const int fixed = 6 * NP * 32 * 4 + 2 * 36 * 1024;
+    const int fixed = 6 * NP * 32 * 4 + 1024 + 2 * 36 * 1024;   // biases, the dump, the weight ring
     const int max_groups = (lds_max - fixed) / (NP * 32 * 64);
     double best = 1e30;
     int bR = 0, bD = 0;
@@ -968,7 +1084,7 @@ static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
 template <int DT, int CH>
 static int launch_c3_tile(const C3TArgs& a, const C3TGeom& g, hipStream_t s) {
     constexpr int NP = CH / 32;
-    const size_t lds = (size_t)6 * NP * 32 * 4 + (size_t)NP * g.nslot * 64 + (size_t)2 * 36 * 1024;
+    const size_t lds = (size_t)6 * NP * 32 * 4 + 1024 + (size_t)NP * g.nslot * 64 + (size_t)2 * 36 * 1024;
     auto kfn = c3_tile_kernel<DT, CH>;
     if (lds > 64 * 1024) { const int rc = allow_big_lds((const void*)kfn, (int)lds); if (rc != YMI_OK) return rc; }
     int grid = g.ntiles < 256 ? g.ntiles : 256;   // persistent: one block per CU
