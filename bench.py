@@ -141,7 +141,7 @@ def reference_cpu_baseline(args, sd, images_cpu, budget_s=14.0, cores=0):
     stages = {k: round(v / (passes * n_sample) * 1e3, 2) for k, v in t.items()}
     stages["post_process"] = round((dt - sum(t.values())) / (passes * n_sample) * 1e3, 2)
     return {"value": round(passes * n_sample / dt, 3), "unit": "images/s", "cores": cores, "host_cpus": host, "kind": "reference",
-            "stages_ms_per_image": stages, "detections_per_image": round(n_det / n_sample, 1),
+            "measured_on": "build container (the only host that holds /root/reference)", "stages_ms_per_image": stages, "detections_per_image": round(n_det / n_sample, 1),
             "sample": f"{passes} pass(es) of model.predict over {n_sample} image(s) of the workload, the UNMODIFIED reference (yolort.models.YOLOv5, fp32 eager, torch CPU, "
                       f"{cores} threads); torchvision.ops.nms = oracle/_tv_compat stand-in (plain C)"}
 
@@ -211,6 +211,8 @@ def cpu_baseline(args, sd, images_cpu, budget_s=14.0):
             rec = json.load(f).get(args.config)
         if rec is not None:
             out["reference_on_build_container"] = rec
+            out["reference_timing_measured_on"] = "build container (another host: /root/reference does not exist on the GPU box); `value` above is the oracle port timed live on this box"
+    out["measured_on"] = "this box's host cores (the oracle port, live)"
     return out
 
 
@@ -694,7 +696,7 @@ def main():
     dets = run_steps(max(args.warmup, 1))
     torch.cuda.synchronize()
     e = next(iter(yolo._entries.values()))
-    yolo.bracket = {"pre": ([], []), "conv": ([], []), "post": ([], [])}   # event pairs recorded on the launching streams inside the timed region
+    yolo.bracket = None   # the timed regions run the product's default submit path (two C-ABI calls per batch); the event brackets get a region of their own below
 
     if world > 1:
         import torch.distributed as dist
@@ -734,6 +736,10 @@ def main():
     order = sorted(range(len(reps)), key=lambda i: reps[i][0])
     elapsed, host_enqueue_ms, dets = reps[order[len(order) // 2]]
     rep_ips = [round(world * args.batch * args.steps / r[0], 1) for r in reps]
+    # one more region, NOT part of `value`: event pairs recorded on the launching streams around each batch's conv / post-process launches while batches overlap (the
+    # brackets take the torch-level submit sequence: 0.05 ms more host time per batch than the default path -- which is why they are no longer inside the timed regions)
+    yolo.bracket = {"pre": ([], []), "conv": ([], []), "post": ([], [])}
+    timed_region()
     region = {k: _elapsed(v) for k, v in yolo.bracket.items()}
     # the SERIAL regime as a throughput: one batch in flight, every batch collected before the next is submitted (what a latency-bound caller sees)
     torch.cuda.synchronize()
@@ -905,7 +911,7 @@ def main():
                                                        "note": "the same per-layer bound priced at what this chip was measured to deliver on these shapes (vendor GEMM <= 0.99 PFLOP/s, "
                                                                "copy 5 TB/s; shader clock 1.58 GHz under LDS + MFMA load) -- context, not the contract's fraction"},
                          "traffic": traffic,
-                         "kernel": "conv family: conv_igemm_v2_kernel, conv_igemm8_kernel, conv_halo8_kernel, conv3x3_c32_kernel, conv1x1_stream_kernel, c3_fused32_kernel, conv_stem_planar_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
+                         "kernel": "conv family: c3_tile_kernel (the C3 strip kernel: 8 of the 29 launches, 39 % of the time), conv_igemm_v2_kernel, conv_igemm8_kernel, conv_halo8_kernel, conv3x3_rs_kernel, c3_fused32_kernel, stem_body1_fused_kernel, conv_head_decode_group_kernel (all conv launches of one step)",
                          "shader_clock_mhz_measured": clock_mhz,
                          "peaks_priced_at": "2.4 GHz (2.5 PFLOP/s dense fp16 / bf16) and 8 TB/s, as the contract demands; the chip sustains the measured clock under this load",
                          "launches_per_step": n_conv, "algorithmic_bytes_per_step": bytes_step, "algorithmic_bytes_per_launch": round(bytes_step / max(n_conv, 1)),

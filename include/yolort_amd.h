@@ -366,8 +366,8 @@ int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, void* stream);
 /* ---- one batch of a serving loop in two calls (the host side of yolo.py:141-183 per batch: YOLO._acquire / _submit_entry) ----
  * ymi_plan_begin: the next batch's inputs were produced on `caller_stream`; `main_stream` (the stream this plan instance launches its conv stack on) waits for
  *   them and for the plan's previous batch to have drained (its buffers are about to be overwritten).  No host synchronisation.
- * ymi_plan_submit: ops [first, n_conv) on `main_stream` (hipGraph replay when use_graph != 0), then ops [n_conv, end) -- the post-process -- on `side_stream`
- *   behind them, then `result_bytes` of `dev_result` copied to the PINNED `host_result` on `side_stream`, then the plan's completion event.  main_waits_done != 0
+ * ymi_plan_submit: ops [first, n_conv) on `main_stream` (hipGraph replay when use_graph & 1), then ops [n_conv, end) -- the post-process -- on `side_stream`
+ *   behind them (a second captured graph when use_graph & 2; a plan keeps two captured ranges), then `result_bytes` of `dev_result` copied to the PINNED `host_result` on `side_stream`, then the plan's completion event.  main_waits_done != 0
  *   additionally makes `main_stream` wait for that event (one batch in flight).  Neither call synchronises the host or allocates after the first use.
  * ymi_plan_done_query: 1 = the last submitted batch has completed (or none was submitted), 0 = still running.  ymi_plan_done_sync blocks the host on it. */
 int ymi_plan_begin(ymi_plan* p, void* caller_stream, void* main_stream);

@@ -97,10 +97,13 @@ static int run_op(const Op& op, hipStream_t s) {
 struct ymi_plan {
     std::vector<ymi::Op> ops;
     bool fuse_stem = false;   // ops 0 + 1 (stem, body.1) run as ONE launch whenever a run covers both (ymi_plan_set_fuse_stem)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    int graph_first = -1, graph_last = -1;
-    hipStream_t graph_stream = nullptr;
+    // captured op ranges: the conv stack and the post-process of a batch are one graph launch each (ymi_plan_submit); a third range evicts the older of the two
+    struct Captured {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int first = -1, last = -1;
+    } captured[2];
+    int captured_next = 0;
     // ymi_plan_begin / ymi_plan_submit: inputs ready (caller's stream), conv stack done (main stream), batch done (side stream); created at first use
     hipEvent_t ev_in = nullptr, ev_conv = nullptr, ev_done = nullptr;
     bool submitted = false;
@@ -148,12 +151,13 @@ extern "C" int ymi_clock_probe(uint64_t* out, int spin_us, void* stream) {
 
 extern "C" ymi_plan* ymi_plan_create(void) { return new (std::nothrow) ymi_plan(); }
 
+static void drop_captured(ymi_plan::Captured& c) {
+    if (c.exec) (void)hipGraphExecDestroy(c.exec);
+    if (c.graph) (void)hipGraphDestroy(c.graph);
+    c = ymi_plan::Captured();
+}
 static void drop_graph(ymi_plan* p) {
-    if (p->exec) (void)hipGraphExecDestroy(p->exec);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
-    p->exec = nullptr;
-    p->graph = nullptr;
-    p->graph_first = p->graph_last = -1;
+    for (auto& c : p->captured) drop_captured(c);
 }
 
 extern "C" void ymi_plan_destroy(ymi_plan* p) {
@@ -321,8 +325,15 @@ extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, voi
         }
         return YMI_OK;
     }
-    if (!p->exec || p->graph_first != first || p->graph_last != last) {
-        drop_graph(p);
+    ymi_plan::Captured* c = nullptr;
+    for (auto& k : p->captured)
+        if (k.exec && k.first == first && k.last == last) c = &k;
+    if (c == nullptr) {
+        for (auto& k : p->captured)
+            if (!k.exec && c == nullptr) c = &k;
+        if (c == nullptr) c = &p->captured[p->captured_next];
+        p->captured_next = (int)(c - p->captured) ^ 1;
+        drop_captured(*c);
         YMI_REQUIRE(s != nullptr, "ymi_plan_run: graph capture needs a non-default stream");
         YMI_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = YMI_OK;
@@ -337,12 +348,12 @@ extern "C" int ymi_plan_run(ymi_plan* p, int first, int last, int use_graph, voi
             set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
             return YMI_EHIP;
         }
-        p->graph = g;
-        YMI_CHECK_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
-        p->graph_first = first;
-        p->graph_last = last;
+        c->graph = g;
+        YMI_CHECK_HIP(hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0));
+        c->first = first;
+        c->last = last;
     }
-    YMI_CHECK_HIP(hipGraphLaunch(p->exec, s));
+    YMI_CHECK_HIP(hipGraphLaunch(c->exec, s));
     return YMI_OK;
 }
 
@@ -377,7 +388,7 @@ extern "C" int ymi_plan_submit(ymi_plan* p, int first, int n_conv, int use_graph
     if (rc != YMI_OK) return rc;
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
     if (first < n_conv) {
-        rc = ymi_plan_run(p, first, n_conv, use_graph, main_stream);
+        rc = ymi_plan_run(p, first, n_conv, use_graph & 1, main_stream);
         if (rc != YMI_OK) return rc;
     }
     if (ss != ms) {
@@ -385,7 +396,7 @@ extern "C" int ymi_plan_submit(ymi_plan* p, int first, int n_conv, int use_graph
         YMI_CHECK_HIP(hipStreamWaitEvent(ss, p->ev_conv, 0));
     }
     if (n_conv < nops) {
-        rc = ymi_plan_run(p, n_conv, nops, 0, side_stream);
+        rc = ymi_plan_run(p, n_conv, nops, (use_graph & 2) && ss != nullptr ? 1 : 0, side_stream);   // bit 1: the post-process range as a graph launch of its own
         if (rc != YMI_OK) return rc;
     }
     if (result_bytes) YMI_CHECK_HIP(hipMemcpyAsync(host_result, dev_result, result_bytes, hipMemcpyDeviceToHost, ss));

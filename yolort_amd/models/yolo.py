@@ -190,6 +190,9 @@ class YOLO(nn.Module):
         # kernel launches from the host: same kernels, same order, same results (tests/test_boundary_gpu.py), 0.12 ms less host time per batch (profiles/r04n_pipeline_depth_graph.txt).
         # Default since round 5; YOLORT_AMD_GRAPH=0 restores the per-kernel launches.
         self.use_graph = os.environ.get("YOLORT_AMD_GRAPH", "1") != "0"
+        # round 6: the post-process range (memsets, selection, sort, NMS, top-k: ~14 enqueues) is a captured graph launch of its own on the side stream -- the same
+        # launches in the same order; YOLORT_AMD_POST_GRAPH=0 restores the per-kernel enqueues (the A/B partner of tests/test_boundary_gpu.py)
+        self.post_graph = os.environ.get("YOLORT_AMD_POST_GRAPH", "1") != "0"
         self.cand_cap_per_image = int(os.environ.get("YOLORT_AMD_CAND_CAP", "16384"))
         self._entries: Dict[Tuple, _PlanEntry] = {}
         self._ring: Dict[Tuple, List[_PlanEntry]] = {}
@@ -375,7 +378,7 @@ class YOLO(nn.Module):
         br = self.bracket
         gather = self._gather_on and not self._in_redo
         if e.c_submit and br is None and not gather and not _SKIP_POST:
-            check(e.plan.lib.ymi_plan_submit(e.plan.handle, first_op, e.n_conv_ops, 1 if self.use_graph else 0, main.cuda_stream, e.side_ptr, e.post.status_count.data_ptr(),
+            check(e.plan.lib.ymi_plan_submit(e.plan.handle, first_op, e.n_conv_ops, (3 if self.post_graph else 1) if self.use_graph else 0, main.cuda_stream, e.side_ptr, e.post.status_count.data_ptr(),
                                              e.result_host.data_ptr(), e.result_bytes, 1 if self.pipeline_depth <= 1 else 0), "ymi_plan_submit")
             e.done = e.c_done
             pd = PendingDetections(self, e, rescale_rows, planar=planar)
