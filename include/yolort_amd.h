@@ -154,8 +154,8 @@ int ymi_conv_f32_pick_tile(int m_pixels, int cout_pad);
  * Two instances:
  *   (1) c_in = 64, c_hidden = 32, c_out = 64, one shortcut Bottleneck (yolov5s backbone.body.2): resident weights,
  *       csrc/c3_fused32.hip; wblob = NULL, mode = 0.
- *   (2) ABI 6 -- c_hidden = 64 or 128, c_out = 2 * c_hidden, c_in % 32 == 0, feature maps whose halo strip of whole rows
- *       fits the LDS patch (80 x 80 / 40 x 40 of yolov5s; ymi_c3_tile_supported says): the strip kernel of csrc/c3_tile.hip,
+ *   (2) ABI 6 -- c_hidden = 64 or 128, c_out = 2 * c_hidden, c_in % 32 == 0: the strip kernel of csrc/c3_tile.hip (strips of whole rows where a
+ *       row fits the LDS patch -- 80 x 80 / 40 x 40 of yolov5s --, column tiles with a halo column either side on wider maps; ymi_c3_tile_supported says),
  *       weights streamed in MFMA fragment order from `wblob` (ymi_c3_blob_bytes / ymi_c3_pack build it from w12 .. b3).
  *       A C3 with n > 1 Bottlenecks is a chain of launches over the same descriptor fields (`mode`):
  *         0  whole block, one Bottleneck:   x -> y
@@ -201,6 +201,9 @@ int64_t ymi_c3_blob_bytes(const ymi_c3_desc* d);
 int ymi_c3_pack(const ymi_c3_desc* d, void* blob, void* stream);
 /* 1 when a strip geometry exists for (n, h, w, c_hidden) of d, i.e. ymi_c3_fused would take instance (2) for it */
 int ymi_c3_tile_supported(const ymi_c3_desc* d);
+/* ... and which one: out6 = {rows per strip R, slot origin delta, column tiles per row band, output columns per tile, patch slots, tiles}; returns 0 (out6 untouched) when
+ * none exists.  Column tiles == 1: full-width strips (the rows of the patch share one pad slot); > 1: maps wider than the patch holds, a halo column either side of a tile. */
+int ymi_c3_tile_geometry(const ymi_c3_desc* d, int* out6);
 
 /* ------------------------------------------------------------------------------------------
  * SPP max-pool pyramid: given x = channels [0,c) of a (n,h,w,4c) concat buffer, writes

@@ -255,6 +255,9 @@ def _run_strip(dev, m, x, dtype, strip, t3x3):
     (torch.bfloat16, 2, 50, 76, 64, 64, 1, True),
     (torch.float16, 5, 20, 20, 128, 128, 1, False),
     (torch.float16, 300, 13, 24, 64, 64, 1, False),    # more strips than blocks: the ring runs across strips
+    (torch.float16, 8, 320, 320, 128, 64, 3, True),    # yolov5l6 @ 1280 backbone.body.2: wider than the patch -> column tiles (HEAD, MID, TAIL)
+    (torch.float16, 8, 160, 160, 256, 128, 2, True),   # ... backbone.body.4's first two Bottlenecks: hidden 128 on a 160-wide map
+    (torch.bfloat16, 3, 45, 203, 64, 128, 1, False),   # ragged rows and columns
 ])
 def test_c3_strip_kernel_equals_the_separate_launches(dev, case):
     dtype, n, h, w, c1, c_, nb, shortcut = case

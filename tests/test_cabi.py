@@ -64,8 +64,11 @@ def test_abi_version_and_error_channel(lib):
     assert lib.ymi_c3_blob_bytes(C.byref(d)) == 0 and lib.ymi_c3_tile_supported(C.byref(d)) == 0
     d.c_hidden, d.c_out = 128, 256
     assert lib.ymi_c3_tile_supported(C.byref(d)) == 1
+    geo = (C.c_int * 6)()
+    assert lib.ymi_c3_tile_geometry(C.byref(d), geo) == 1 and list(geo)[:4] == [5, 1, 1, 40] and geo[5] == 32 * 8   # yolov5s @ 40 x 40: full-width strips of 5 rows
     d.h, d.w = 320, 320
-    assert lib.ymi_c3_tile_supported(C.byref(d)) == 0                              # a 322-slot row does not leave room for three of them in the LDS patch
+    assert lib.ymi_c3_tile_supported(C.byref(d)) == 1                              # a 321-slot row does not leave room for three of them in the LDS patch:
+    assert lib.ymi_c3_tile_geometry(C.byref(d), geo) == 1 and geo[2] > 1 and geo[2] * geo[3] >= 320 and geo[4] <= 10 * 32   # ... column tiles, (R + 2) x (wc + 2) slots
     assert lib.ymi_c3_pack(C.byref(d), None, None) == -1 and b"ymi_c3_pack" in lib.ymi_last_error()
     assert lib.ymi_c3_fused(C.byref(d), None) == -1 and b"ymi_c3" in lib.ymi_last_error()   # (no weights: refused before anything is launched)
     assert lib.ymi_act(None, 8, 4, 8, 0, 2, None, 0, None) == -1 and b"ymi_act" in lib.ymi_last_error()

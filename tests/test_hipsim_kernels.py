@@ -1388,7 +1388,7 @@ def _c3_pack(sim, d):
     return blob
 
 
-def _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t1x1=21, t3x3=91, blocks=None):
+def _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t1x1=21, t3x3=91, blocks=None, geom=None):
     cpu = torch.device("cpu")
     m = _make_c3_wide(c_in, 2 * c_, nb, shortcut, seed=h * 7 + w + nb)
     x = torch.randn(n, c_in, h, w, generator=torch.Generator().manual_seed(n + h + c_)).to(dtype).float()
@@ -1412,6 +1412,8 @@ def _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t1x1=21, t3x3
     # ---- the strip kernel: one launch (nb == 1) or HEAD, MID ..., TAIL ----
     if blocks is not None:
         os.environ["YOLORT_AMD_C3T_BLOCKS"] = str(blocks)
+    if geom is not None:
+        os.environ["YOLORT_AMD_C3T_GEOM"] = geom
     try:
         wide = Buf(n, h, w, 2 * c_ + 32, dtype)   # the output is a channel slice of a wider buffer
         out_f = wide.slice_c(16, 2 * c_)
@@ -1445,6 +1447,7 @@ def _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t1x1=21, t3x3
             _check(sim, sim.sim_c3_tile(C.byref(d)))
     finally:
         os.environ.pop("YOLORT_AMD_C3T_BLOCKS", None)
+        os.environ.pop("YOLORT_AMD_C3T_GEOM", None)
 
     a, b = out_sep.view(), out_f.view()
     assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"strip kernel vs separate launches: max difference {(a.float() - b.float()).abs().max().item()}"
@@ -1473,3 +1476,17 @@ def _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t1x1=21, t3x3
 def test_c3_strip_kernel_equals_the_separate_launches_and_torch(sim, case):
     dtype, n, h, w, c_in, c_, nb, shortcut, blocks = case
     _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t3x3=91 if c_ == 128 else 92, blocks=blocks)
+
+
+@pytest.mark.parametrize("case", [
+    # (dtype, n, h, w, c_in, hidden, bottlenecks, shortcut, blocks, forced geometry "R,delta,column tiles" or None = the library's choice)
+    (torch.float16, 1, 9, 60, 64, 128, 1, True, 2, "3,1,2"),       # two column tiles of 30 + a halo column either side; image edges left / right / between the tiles
+    (torch.float16, 2, 10, 150, 64, 64, 2, True, 3, "4,1,3"),      # HEAD + TAIL over 3 x 50 columns, a ragged last row band, three blocks walk 18 tiles
+    (torch.bfloat16, 1, 5, 200, 32, 128, 1, False, None, None),    # a 200-wide map at hidden 128: no full-width strip fits -- the library cuts columns by itself
+    (torch.float16, 1, 6, 70, 64, 64, 1, False, 1, "2,3,4"),       # 4 tiles of 18 columns over 70 (the last one holds 16): ragged columns, one block
+])
+def test_c3_strip_kernel_with_column_tiles(sim, case):
+    """maps wider than the LDS patch holds (yolov5l6 at 1280: hidden 64 @ 320 x 320, hidden 128 @ 160 x 160): a row band is cut into column tiles with one halo column either
+    side (recomputed); results bit-identical to the separate launches, like the full-width strips"""
+    dtype, n, h, w, c_in, c_, nb, shortcut, blocks, geom = case
+    _run_c3_tile_case(sim, dtype, n, h, w, c_in, c_, nb, shortcut, t3x3=91 if c_ == 128 else 92, blocks=blocks, geom=geom)

@@ -97,6 +97,7 @@ _SIGS = {
     "ymi_c3_blob_bytes": (C.c_int64, [C.POINTER(C3Desc)]),
     "ymi_c3_pack": (C.c_int, [C.POINTER(C3Desc), C.c_void_p, C.c_void_p]),
     "ymi_c3_tile_supported": (C.c_int, [C.POINTER(C3Desc)]),
+    "ymi_c3_tile_geometry": (C.c_int, [C.POINTER(C3Desc), C.POINTER(C.c_int)]),
     "ymi_conv_stem_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "ymi_stem_body1_planar": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "ymi_stem_body1": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),

@@ -71,6 +71,8 @@ struct C3TArgs {
 
 struct C3TGeom {
     int R, pw, delta, nslot, tiles_per_img, ntiles;
+    int ncol, wc, coff;       // column tiles per row band, output columns per tile, the patch column of a tile's first output column: ncol == 1 -> wc = w, pw = w + 1 (ONE shared
+                              // pad slot per row), coff = 0; ncol > 1 -> pw = wc + 2 (a halo column either side: the neighbours' pixels, recomputed), coff = 1
     unsigned magic_pw;
     signed char role[8];      // per wave: which static job list it runs (C3TRole)
     signed char grp[8][3];    // per wave: the patch-slot groups of its jobs (-1: none -- the job runs on clamped addresses and writes nothing)
@@ -326,15 +328,17 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
     // per-tile pixel geometry of the groups, packed: pixel index (clamped into the image) * 4 + bit 0 (inside the image; else: zero padding) + bit 1 (an output pixel of this tile)
     int pmf[NG];
     auto tile_geom = [&](int t, int (&pmf_)[NG]) {
-        const int img = t / g.tiles_per_img, ty = t - img * g.tiles_per_img;
+        const int img = t / g.tiles_per_img, rem = t - img * g.tiles_per_img;
+        const int ty = rem / g.ncol, c0 = (rem - ty * g.ncol) * g.wc - g.coff;   // image column of patch column 0
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int r = (jrc[k] >> 16) - 8, c = jrc[k] & 0xffff;
-            const int iy = ty * g.R + r - 1;
-            const bool slot_ok = jg[k] >= 0 && r >= 0 && r <= g.R + 1 && c < a.w;
+            const int iy = ty * g.R + r - 1, ix = c0 + c;
+            const bool slot_ok = jg[k] >= 0 && r >= 0 && r <= g.R + 1 && ix >= 0 && ix < a.w;   // (full-width strips: c == w is the pad slot)
             const bool inside = slot_ok && iy >= 0 && iy < a.h;
-            const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = c < a.w ? c : a.w - 1;
-            pmf_[k] = (((img * a.h + cy) * a.w + cx) << 2) | (inside ? 1 : 0) | ((inside && r >= 1 && r <= g.R) ? 2 : 0);
+            const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = ix < 0 ? 0 : (ix < a.w ? ix : a.w - 1);
+            const bool out = inside && r >= 1 && r <= g.R && c >= g.coff && c < g.coff + g.wc;
+            pmf_[k] = (((img * a.h + cy) * a.w + cx) << 2) | (inside ? 1 : 0) | (out ? 2 : 0);
         }
     };
     // Phase A's activations.  Straight from memory into registers one k32 chunk ahead they bound the phase: ~1.4 us per round trip (HBM / the infinity cache under
@@ -347,7 +351,8 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
 #pragma unroll
     for (int j = 0; j < NP; ++j) xseq[j] = 0;
     auto x_offsets = [&](int t) {
-        const int img = t / g.tiles_per_img, ty = t - img * g.tiles_per_img;
+        const int img = t / g.tiles_per_img, rem = t - img * g.tiles_per_img;
+        const int ty = rem / g.ncol, c0 = (rem - ty * g.ncol) * g.wc - g.coff;
 #pragma unroll
         for (int k = 0; k < NG; ++k)
 #pragma unroll
@@ -357,8 +362,8 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
                 const int qp = qq >= 0 ? qq : 0;
                 const int r0 = fast_div(qp, g.pw, g.magic_pw);
                 const int c = qp - r0 * g.pw;
-                const int iy = ty * g.R + (qq >= 0 ? r0 : 0) - 1;
-                const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = c < a.w ? c : a.w - 1;   // (slots outside the image read a pixel inside it: masked later)
+                const int iy = ty * g.R + (qq >= 0 ? r0 : 0) - 1, ix = c0 + c;
+                const int cy = iy < 0 ? 0 : (iy < a.h ? iy : a.h - 1), cx = ix < 0 ? 0 : (ix < a.w ? ix : a.w - 1);   // (slots outside the image read a pixel inside it: masked later)
                 const int oct = (lane & 3) ^ ((q >> 2) & 3);
                 xqo[k][p] = ((unsigned)((img * a.h + cy) * a.w + cx) * (unsigned)a.x_cs + 8u * (unsigned)oct) * 2u;
             }
@@ -690,7 +695,7 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int r = (jrc[c] >> 16) - 8, cc = jrc[c] & 0xffff;
-                const bool out_px = jg[c] >= 0 && r >= 1 && r <= g.R && cc < a.w;
+                const bool out_px = jg[c] >= 0 && r >= 1 && r <= g.R && cc >= g.coff && cc < g.coff + g.wc;
                 const int q = out_px ? jg[c] * 32 + fr : g.delta + g.pw;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -1007,17 +1012,22 @@ int c3_pack_launch(const ymi_c3_desc* d, void* blob, hipStream_t s) {
 template <int CH>
 static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
     constexpr int NP = CH / 32, GC = CH == 128 ? 1 : 2;   // centre groups per wave
-    const int pw = w + 1;
     const int lds_max = 160 * 1024;
     const int fixed = 6 * NP * 32 * 4 + 1024 + 2 * 36 * 1024;   // biases, the dump, the weight ring
     const int max_groups = (lds_max - fixed) / (NP * 32 * 64);
     double best = 1e30;
-    int bR = 0, bD = 0;
-    if (const char* e = getenv("YOLORT_AMD_C3T_GEOM")) {   // tuning aid: "R,delta"
-        int r_ = 0, d_ = 0;
-        if (sscanf(e, "%d,%d", &r_, &d_) == 2) { bR = r_; bD = d_; best = 0; }
+    int bR = 0, bD = 0, bN = 0;
+    if (const char* e = getenv("YOLORT_AMD_C3T_GEOM")) {   // tuning aid: "R,delta[,column tiles]"
+        int r_ = 0, d_ = 0, n_ = 1;
+        const int got = sscanf(e, "%d,%d,%d", &r_, &d_, &n_);
+        if (got >= 2 && n_ >= 1) { bR = r_; bD = d_; bN = n_; best = 0; }
     }
-    auto eval = [&](int R, int delta, int& ng_t, int& gc0, int& ncen) -> bool {
+    // column tiles: ncol == 1 is a full-width strip (pw = w + 1: the rows share one pad slot); wider maps than the patch holds are cut into ncol tiles of wc output columns with
+    // a halo column either side (pw = wc + 2)
+    auto pw_of = [&](int ncol) { return ncol == 1 ? w + 1 : (w + ncol - 1) / ncol + 2; };
+    auto eval = [&](int R, int delta, int ncol, int& ng_t, int& gc0, int& ncen) -> bool {
+        const int pw = pw_of(ncol);
+        if (ncol > 1 && ((w + ncol - 1) / ncol) * (ncol - 1) >= w) return false;   // (the last column tile would be empty)
         const int h_end = delta + (R + 2) * pw;
         ng_t = (h_end + 31) / 32;
         if (ng_t > max_groups || ng_t > 127) return false;
@@ -1030,24 +1040,27 @@ static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
         return nhalo <= 8;
     };
     if (best != 0) {
-        for (int R = 1; R <= h; ++R)
-            for (int delta = 1; delta <= 32; ++delta) {
-                int ng_t, gc0, ncen;
-                if (!eval(R, delta, ng_t, gc0, ncen)) continue;
-                const int tiles = n * ((h + R - 1) / R);
-                const double rounds = (double)((tiles + 255) / 256);
-                const int cen_per_wave = (ncen + 7) / 8;
-                const double tile_cost = 6.0 * cen_per_wave + 1.0 + 0.02 * ng_t;
-                const double cost = rounds * tile_cost * (1.0 + 1e-3 * delta);   // ties: the smaller delta
-                if (cost < best) { best = cost; bR = R; bD = delta; }
-            }
+        for (int ncol = 1; ncol <= 32 && ncol <= w; ++ncol)
+            for (int R = 1; R <= h; ++R)
+                for (int delta = 1; delta <= 32; ++delta) {
+                    int ng_t, gc0, ncen;
+                    if (!eval(R, delta, ncol, ng_t, gc0, ncen)) continue;
+                    const int tiles = n * ((h + R - 1) / R) * ncol;
+                    const double rounds = (double)((tiles + 255) / 256);
+                    const int cen_per_wave = (ncen + 7) / 8;
+                    const double tile_cost = 6.0 * cen_per_wave + 1.0 + 0.02 * ng_t;
+                    const double cost = rounds * tile_cost * (1.0 + 1e-3 * delta) * (ncol > 1 ? 1.05 : 1.0);   // ties: the smaller delta; full-width strips where they fit
+                    if (cost < best) { best = cost; bR = R; bD = delta; bN = ncol; }
+                }
         if (bR == 0) return false;
     }
     int ng_t, gc0, ncen;
-    if (!eval(bR, bD, ng_t, gc0, ncen)) return false;
+    if (!eval(bR, bD, bN, ng_t, gc0, ncen)) return false;
+    const int pw = pw_of(bN);
     memset(&g, 0, sizeof(g));
     g.R = bR; g.pw = pw; g.delta = bD; g.nslot = ng_t * 32;
-    g.tiles_per_img = (h + bR - 1) / bR;
+    g.ncol = bN; g.wc = bN == 1 ? w : (w + bN - 1) / bN; g.coff = bN == 1 ? 0 : 1;
+    g.tiles_per_img = ((h + bR - 1) / bR) * bN;
     g.ntiles = n * g.tiles_per_img;
     const uint64_t mg = (((uint64_t)1 << 32) / (uint64_t)pw) + 1u;
     g.magic_pw = (unsigned)(mg > 0xffffffffull ? 0xffffffffull : mg);
@@ -1148,3 +1161,11 @@ extern "C" int ymi_debug_stamps_c3t_clear(void) {
 extern "C" int64_t ymi_c3_blob_bytes(const ymi_c3_desc* d) { return ymi::c3_blob_bytes(d); }
 extern "C" int ymi_c3_pack(const ymi_c3_desc* d, void* blob, void* stream) { return ymi::c3_pack_launch(d, blob, (hipStream_t)stream); }
 extern "C" int ymi_c3_tile_supported(const ymi_c3_desc* d) { return ymi::c3_tile_supported(d); }
+extern "C" int ymi_c3_tile_geometry(const ymi_c3_desc* d, int* out6) {
+    if (d == nullptr || out6 == nullptr || !ymi::c3_tile_supported(d)) return 0;
+    ymi::C3TGeom g;
+    const bool ok = d->c_hidden == 128 ? ymi::c3t_geometry<128>(d->n, d->h, d->w, g) : ymi::c3t_geometry<64>(d->n, d->h, d->w, g);
+    if (!ok) return 0;
+    out6[0] = g.R; out6[1] = g.delta; out6[2] = g.ncol; out6[3] = g.wc; out6[4] = g.nslot; out6[5] = g.ntiles;
+    return 1;
+}
