@@ -1299,16 +1299,25 @@ static int post_validate(const ymi_post_desc* d, bool need_logits, PostLayout& L
     return YMI_OK;
 }
 
+// the three counter arrays of a batch in ONE launch (three hipMemsetAsync were three fill kernels of ~5.7 us each on the conv stack's stream, in front of the head:
+// profiles/r06u_layer_table_c2.csv "other kernels")
+__global__ __launch_bounds__(256) void post_reset_kernel(int* a, int na, int* b, int nb, int* c, int nc) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += gridDim.x * 256) {
+        if (i < na) a[i] = 0;
+        else if (i < na + nb) b[i - na] = 0;
+        else c[i - na - nb] = 0;
+    }
+}
+
 // stage 1 of 3: reset the counters the candidate producers append to
 int post_begin_launch(const ymi_post_desc* d, hipStream_t s) {
     PostLayout L;
     Workspace w;
     int rc = post_validate(d, false, L, w);
     if (rc != YMI_OK) return rc;
-    YMI_CHECK_HIP(hipMemsetAsync(d->status, 0, ST_WORDS * sizeof(int), s));
-    YMI_CHECK_HIP(hipMemsetAsync(d->out_count, 0, (size_t)d->n * sizeof(int), s));
-    if (L.per_image) YMI_CHECK_HIP(hipMemsetAsync(w.img_count, 0, (size_t)d->n * sizeof(int), s));
-    return YMI_OK;
+    const int nc = L.per_image ? d->n : 0;
+    hipLaunchKernelGGL(post_reset_kernel, dim3(cdiv(ST_WORDS + d->n + nc, 256)), dim3(256), 0, s, (int*)d->status, (int)ST_WORDS, (int*)d->out_count, d->n, nc ? (int*)w.img_count : nullptr, nc);
+    return check_launch("post_reset_kernel");
 }
 
 // stage 2 of 3 (unfused form): decode + threshold of the fp32 head outputs
