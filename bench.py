@@ -894,7 +894,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "score_thresh": args.score_thresh, "nms_thresh": 0.45, "detections_per_img": 300,
                        "weights": f"seeded synthetic (workloads/synth.py, head_gain {args.head_gain})", "parallelism": f"dp{world} (one shard per rank, slab all-gather)",
-                       "gather_second_rounds_rank0": second_rounds[0], "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4), "serving_mode_rank0": serving,
+                       "gather_second_rounds_rank0": second_rounds[0], "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
+                       "submit_path_of_timed_regions": ("ymi_plan_begin + ymi_plan_submit (the product's default: two C-ABI calls per batch, conv stack and post-process as one graph launch each)"
+                                                        if world == 1 else "torch-level sequence (the slab all-gather is enqueued from Python behind each batch)"),
+                       "serving_mode_rank0": serving,
                        "canvas": [e.x.h, e.x.w], "detections_per_step_rank0": int(sum(len(d["scores"]) for d in dets)),
                        "candidates_per_step_rank0": n_cand, "records_sorted_per_step_rank0": n_cand_sorted, "conv_tiles": "pinned table yolort_amd/data/tiles_gfx950.json" if not e.plan.autotune else "autotuned at plan build"},
             # `frac` is the PER-LAYER fraction SURVEY.md 8d prescribes (sum over the conv launches of max(flops / MFMA peak, bytes / HBM peak),
@@ -924,6 +927,7 @@ def main():
                                        "frac_of_per_layer_bound": round(bound_s / step_s, 4), "frac_of_hbm_peak": round(bytes_step / step_s / HBM_PEAK, 4),
                                        "tflops": round(flops_step / step_s / 1e12, 2),
                                        "conv_bracket_ms": round(conv_s_region * 1e3, 4),
+                                       "conv_bracket_submit_path": "torch-level sequence with event pairs, in a region of its own that is not part of `value`",
                                        "note": "per-layer bound / ms_per_step of the timed region: a LOWER bound on the conv stack's fraction there (the step also holds the "
                                                "post-process launches); conv_bracket_ms = event brackets around one batch's conv launches while they share the GPU with its neighbours' kernels"},
                          "other_kernels": kernels},

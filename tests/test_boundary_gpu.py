@@ -300,6 +300,35 @@ def test_more_batches_in_flight_than_plan_instances(dev):
             assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["scores"], y["scores"]) and torch.equal(x["boxes"], y["boxes"])
 
 
+def test_capacity_redo_while_later_batches_are_in_flight(dev):
+    """the default submit path (ymi_plan_begin / ymi_plan_submit, ONE completion event per plan instance) with `pipeline_depth` 2 and a candidate capacity
+    that the very first batches overflow: each overflowing batch is redone (on grown buffers) while later batches already occupy the instances.  Every batch's detections
+    equal those of a model that never overflowed, whatever the order of collection"""
+    from yolort_amd.models import YOLOv5
+    from workloads.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_n_r60"
+    def make(cap):
+        m = YOLOv5(arch=arch, size=(160, 160), score_thresh=0.05)
+        m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=1.0))
+        m = m.to(dev).half().eval()
+        m.model.pipeline_depth = 2
+        m.model.cand_cap_per_image = cap
+        return m
+    batches = [[synth_images(1, 160, 160, seed=300 + 2 * i)[0].to(dev).half(), synth_images(1, 160, 160, seed=301 + 2 * i)[0].to(dev).half()] for i in range(6)]
+    ref = make(1 << 16)
+    want = [ref.forward(b) for b in batches]
+    assert sum(len(d["scores"]) for r in want for d in r) > 100
+    m = make(64)
+    assert m.model.post_graph and m.model.use_graph                     # the default path is the one under test
+    pend = [m.forward_async(b) for b in batches]                        # six submitted on two instances before any is collected; the first ones overflow 64 records
+    got = [p.result() for p in pend[::2]] + [p.result() for p in pend[1::2]]
+    got = [got[i // 2 + (3 if i % 2 else 0)] for i in range(6)]         # back into submission order
+    assert m.model.cand_cap_per_image > 64                                # (the overflow was seen and the batch redone)
+    for w_, g_ in zip(want, got):
+        for x, y in zip(w_, g_):
+            assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["scores"], y["scores"]) and torch.equal(x["boxes"], y["boxes"])
+
+
 def test_alternating_canvases_keep_their_plans(dev):
     """a variable-size stream alternates between canvases; each keeps its plan instances (small LRU) instead of
     rebuilding `pipeline_depth` plans per call"""

@@ -494,3 +494,13 @@ def test_weights_signature_sees_every_way_a_module_tree_can_change(walk, monkeyp
     assert changed(lambda m: m.backbone.body["0"].act.register_buffer("k", torch.zeros(1)))   # a buffer on a module that had no tensors
     assert changed(lambda m: m.backbone.body["0"].act.add_module("extra", nn.Conv2d(1, 1, 1)))  # a child under a former leaf
     assert changed(lambda m: m.head.head.__setitem__(1, nn.Conv2d(256, 255, 1)))              # a replaced sub-module
+
+    def delete_then_recreate_the_last_child(m):                                               # the freed address is what CPython hands the new instance of the same class;
+        last = list(m.head.head._modules)[-1]                                                 # the cache keeps the old child alive, so the identities differ
+        old = m.head.head._modules[last]
+        spec = (old.in_channels, old.out_channels, old.kernel_size)
+        del m.head.head._modules[last]
+        del old
+        m.head.head._modules[last] = nn.Conv2d(*spec)
+    for _ in range(5):
+        assert changed(delete_then_recreate_the_last_child)

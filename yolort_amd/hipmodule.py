@@ -68,7 +68,9 @@ def _collect(module: nn.Module):
     t_full, t_empty = [d for d in t_all if d], [d for d in t_all if not d]
     m_full, m_empty = [d for d in m_all if d], [d for d in m_all if not d]
     kids = _SIG_EXT.scan(t_full, m_full, t_empty, m_empty)[3] if _SIG_EXT is not None else tuple(map(id, _values_of(m_full)))
-    return t_full, t_empty, m_full, m_empty, kids
+    # (`mods`: the module objects themselves stay referenced for as long as this collection is the cache -- `kids` compares ADDRESSES, and after `del m.sub; m.sub = New()`
+    # CPython likes to hand the new instance of the same class the address that was just freed: with the old child still alive here that cannot happen.  ADVICE r5)
+    return t_full, t_empty, m_full, m_empty, kids, mods
 
 
 def weights_signature(module: nn.Module) -> Tuple:
@@ -98,7 +100,7 @@ def weights_signature(module: nn.Module) -> Tuple:
             module.__dict__["_ymi_sig_tensors"] = (ids, list(_values_of(cache[0])))
         return (ids, versions, ptrs)
     if cache is not None:
-        t_full, t_empty, m_full, m_empty, child_ids = cache
+        t_full, t_empty, m_full, m_empty, child_ids = cache[:5]
         if tuple(map(id, _values_of(m_full))) != child_ids or sum(map(len, m_empty)) or sum(map(len, t_empty)):
             cache = None
     if cache is None:
