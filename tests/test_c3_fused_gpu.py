@@ -271,3 +271,4 @@ def test_c3_strip_kernel_equals_the_separate_launches(dev, case):
     tol = (4e-3 if dtype == torch.float16 else 3.2e-2) * (1 + nb) / 2
     err = (got[: min(n, 4)].float() - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), err
+

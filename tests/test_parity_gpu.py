@@ -138,6 +138,11 @@ def _err_vs(view, ref_nchw):
     ("yolov5_darknet_pan_l_r31", torch.float16, 2, 320, 2e-3, False, 2),
     ("yolov5_darknet_pan_m_r40", torch.bfloat16, 2, 320, 1.6e-2, False, 2),
     ("yolov5_darknet_pan_l_r40", torch.float16, 2, 320, 2e-3, False, 2),
+    # round 6: canvases nobody tuned, for the strip kernel's geometry search -- 52 / 26-wide maps (full-width strips, ragged last strip), yolov5s at 1280 (160-wide maps at
+    # hidden 64: full-width strips of 2 rows or column tiles, whatever the search picks; 80-wide at hidden 128), yolov5l at 1024 (hidden 64 @ 256 x 256, 128 @ 128 x 128: column tiles)
+    ("yolov5_darknet_pan_s_r60", torch.float16, 1, 416, 2e-3, False, 1),
+    ("yolov5_darknet_pan_s_r60", torch.float16, 2, 1280, 2e-3, False, 1),
+    ("yolov5_darknet_pan_l_r60", torch.float16, 1, 1024, 2e-3, False, 1),
     ("yolov5_darknet_pan_s_r31", torch.float16, 32, 640, 2e-3, False, 2),      # the r3.1 plan at the headline's batch -- body.3 runs with YMI_ACT_NONE on a key the table pins to a SiLU-only tile
 ])
 def test_every_conv_launch_of_the_plan_vs_oracle_layer(dev, arch, dtype, n, size, tol, dynamic, n_oracle):
