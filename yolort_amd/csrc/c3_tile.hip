@@ -32,6 +32,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace ymi {
 
@@ -1010,7 +1012,7 @@ int c3_pack_launch(const ymi_c3_desc* d, void* blob, hipStream_t s) {
 // Feasible (R, delta): the centre groups (those holding output pixels) fit the waves' centre jobs, the halo-only groups their spare jobs, the patch fits the LDS.
 // Cost model: rounds of tiles over 256 CUs x per-tile time (a centre group ~6x a halo-only group: the 3x3 and cv3 dominate).
 template <int CH>
-static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
+static bool c3t_geometry_search(int n, int h, int w, C3TGeom& g) {
     constexpr int NP = CH / 32, GC = CH == 128 ? 1 : 2;   // centre groups per wave
     const int lds_max = 160 * 1024;
     const int fixed = 6 * NP * 32 * 4 + 1024 + 2 * 36 * 1024;   // biases, the dump, the weight ring
@@ -1092,6 +1094,30 @@ static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
                 if (ncw[wv] == pass && g.grp[wv][2] < 0) g.grp[wv][2] = (signed char)hq[hi_++];
     }
     return hi_ == nh;
+}
+
+// The search walks ~40 k candidates: once per (n, h, w, hidden width, override), not once per launch (a plan replays a captured graph, but plan building, per-op profiling
+// and direct ymi_c3_fused calls launch from the host every time: 70 us of host time per launch before this memo -- profiles/r06ab_*)
+template <int CH>
+static bool c3t_geometry(int n, int h, int w, C3TGeom& g) {
+    struct Entry { int n, h, w; unsigned long env; bool ok; C3TGeom g; };
+    static std::mutex mu;
+    static std::vector<Entry> memo;
+    const char* e = getenv("YOLORT_AMD_C3T_GEOM");
+    unsigned long ev = 5381;
+    for (const char* p = e; p && *p; ++p) ev = ev * 33 + (unsigned char)*p;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry& m : memo)
+            if (m.n == n && m.h == h && m.w == w && m.env == ev) { g = m.g; return m.ok; }
+    }
+    Entry m{n, h, w, ev, false, {}};
+    m.ok = c3t_geometry_search<CH>(n, h, w, m.g);
+    g = m.g;
+    std::lock_guard<std::mutex> lk(mu);
+    if (memo.size() >= 64) memo.erase(memo.begin());
+    memo.push_back(m);
+    return m.ok;
 }
 
 template <int DT, int CH>
