@@ -287,7 +287,7 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
     // One stage of a 1x1 GEMM phase: `nch` units (k32 chunks / k64 groups, CB bytes each) of NSUB sub-steps of NP weight fragments (Off::at(sub, i) = byte offset
     // inside the unit), read through a two-deep register ring one sub-step ahead across the units (c3t_lds_read: a buffer is refilled right behind the MFMAs that read
     // it -- its new contents arrive a full LDS round trip, >= 64 cycles, after the refill issues; the MFMAs, issued before it in order, have read their operands by
-    // then).  mma(kc, sub, w) issues a sub-step's MFMAs.  The reads run one sub-step past the stage's end (bytes of the slot nobody uses: no branch in the loop).
+    // then).  mma(kc, sub, w) issues a sub-step's MFMAs.
     const unsigned ring_lds = c3t_lds_addr(ring);
     auto w_stage = [&](auto nsubt, auto off, auto&& mma) {
         constexpr int NSUB = decltype(nsubt)::value;
@@ -314,11 +314,14 @@ __device__ __forceinline__ void c3t_run(const C3TArgs& a, const C3TGeom& g, unsi
             wn_lds = kc + 1 < KC ? ws_lds + CB : ws0_lds;
             static_for<0, NSUB>([&](auto subt) {
                 constexpr int sub = decltype(subt)::value;
-                c3t_lds_wait<NP>(w[sub % 2][0]);
+                // the stage's last two sub-steps read nothing ahead: a read still in flight when the stage ends lands in registers the compiler may have handed to something
+                // else (profiles/r06ab5_*: a GPU fault as soon as the wait at the top of the next step was not there to cover it)
+                constexpr bool tail = kc == KC - 1 && sub + 2 >= NSUB;
+                c3t_lds_wait<(kc == KC - 1 && sub == NSUB - 1) ? 0 : NP>(w[sub % 2][0]);
 #pragma unroll
                 for (int i = 1; i < NP; ++i) c3t_lds_dep(w[sub % 2][i]);
                 mma(kct, subt, w[sub % 2]);
-                rd(std::integral_constant<int, sub + 2>{});
+                if constexpr (!tail) rd(std::integral_constant<int, sub + 2>{});
                 if constexpr (sub == 0 && kc == 0) send_stage();   // ONE burst behind the first MFMA group (see step_sync)
                 __builtin_amdgcn_sched_barrier(0);                 // (the next sub-step's wait names other registers: without the fence hipcc sinks this group's MFMAs below it)
             });
