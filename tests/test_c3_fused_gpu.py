@@ -272,3 +272,28 @@ def test_c3_strip_kernel_equals_the_separate_launches(dev, case):
     err = (got[: min(n, 4)].float() - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), err
 
+
+@pytest.mark.parametrize("geom,blocks", [("4,1,2", 50), ("3,5,3", 7), ("2,9,1", 300)])
+def test_strip_geometry_never_changes_a_detection(dev, geom, blocks, monkeypatch):
+    """a strip's arithmetic does not depend on how the map is cut: whole yolov5s, the library's geometry against a forced one ("rows per strip, slot origin, column tiles")
+    walked by few blocks (many strips per block: the weight ring runs across strips and images) -- detections bit for bit"""
+    from yolort_amd.models import YOLOv5
+    from workloads.synth import synth_images, synth_weights
+    arch = "yolov5_darknet_pan_s_r60"
+    imgs = [im.to(dev).half() for im in synth_images(6, 640, 640, seed=77)]
+    outs = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("YOLORT_AMD_C3T_GEOM", geom)
+            monkeypatch.setenv("YOLORT_AMD_C3T_BLOCKS", str(blocks))
+        m = YOLOv5(arch=arch, size=(640, 640), score_thresh=0.1)
+        m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=0.8))
+        m = m.to(dev).half().eval()
+        outs.append(m(imgs))
+        e = next(iter(m.model._entries.values()))
+        assert sum(".tile" in nm for nm in e.plan.names) == 8
+    assert sum(len(d["scores"]) for d in outs[0]) > 20
+    for a, b in zip(*outs):
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), (geom, k)
+
