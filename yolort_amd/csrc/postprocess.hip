@@ -831,43 +831,68 @@ __global__ __launch_bounds__(1024) void select_prefix_kernel(uint64_t* in_hi, ui
 //     hundred blocks, and no block-wide barrier in the loop.
 // ------------------------------------------------------------------------------------------
 constexpr int RANK_IT = 256;    // keys ranked per block
-constexpr int RANK_JT = 1024;   // keys of a j-slice (16 KiB of LDS: G and P key of each)
+constexpr int RANK_JT = 256;    // keys of a j-slice (4 KiB of LDS: G and P key of each)
+constexpr int RANK_GRID = 1024; // blocks of the ranking kernel (they walk the pair list of the whole batch)
+constexpr int RANK_NIMG = 1024; // images per batch the ranking kernel's per-block table holds (larger batches: the one-block-per-image sort)
 
 __device__ __forceinline__ uint64_t p_key_of(uint64_t g, int label_bits) {
     return ((g & ((1ull << label_bits) - 1ull)) << (64 - label_bits)) | (g >> label_bits);
 }
 
-__global__ __launch_bounds__(RANK_IT) void rank_image_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* sel_count, int cap_img, int label_bits,
+__global__ __launch_bounds__(RANK_IT) void rank_image_kernel(const uint64_t* in_hi, const uint32_t* in_lo, const int* sel_count, int n_img, int cap_img, int label_bits,
                                                              uint32_t* rank_g, uint32_t* rank_p) {
+    // round 6: a fixed grid walks the (256-key tile, 256-key j-slice) pairs of ALL images as one list.  The grid used to be sized for RANK_MAX records per image (24 x 6
+    // tiles: on C2 -- 1 k records per image, 5 k in one -- 97 % of 4 608 blocks found nothing to do and the others each scanned 1 024 keys: 42 us); blocks per image
+    // fixed at 16 made the crowded image's 400 pairs the tail (124 us).  profiles/r06zz_post_kernels.txt
     __shared__ __attribute__((aligned(16))) uint64_t keys[RANK_JT][2];
-    const int img = blockIdx.z;
-    const int n_i = sel_count[img];
-    const int i0 = blockIdx.x * RANK_IT, j0 = blockIdx.y * RANK_JT;
-    if (n_i > RANK_MAX || i0 >= n_i || j0 >= n_i) return;   // block-uniform
-    const int64_t base = (int64_t)img * cap_img;
-    const int jn = n_i - j0 < RANK_JT ? n_i - j0 : RANK_JT;
-    for (int t = threadIdx.x; t < jn; t += RANK_IT) {
-        const uint64_t g = ((uint64_t)(uint32_t)in_hi[base + j0 + t] << 32) | in_lo[base + j0 + t];   // ~score << 32 | cand
-        keys[t][0] = g;
-        keys[t][1] = p_key_of(g, label_bits);
+    __shared__ int s_cnt[RANK_NIMG];   // records per image (0: none of this kernel's), read ONCE per block (a chain of dependent scalar loads per pair cost 15 us)
+    for (int m = threadIdx.x; m < n_img; m += RANK_IT) {
+        const int c = sel_count[m];
+        s_cnt[m] = (c > 0 && c <= RANK_MAX) ? c : 0;
     }
     __syncthreads();
-    const int i = i0 + threadIdx.x;
-    uint64_t gi = 0ull, pi = 0ull;   // threads past the end count nothing
-    if (i < n_i) {
-        gi = ((uint64_t)(uint32_t)in_hi[base + i] << 32) | in_lo[base + i];
-        pi = p_key_of(gi, label_bits);
+    int total = 0;
+    for (int m = 0; m < n_img; ++m) {   // block-uniform
+        const int c = s_cnt[m];
+        total += ((c + RANK_IT - 1) / RANK_IT) * ((c + RANK_JT - 1) / RANK_JT);
     }
-    uint32_t cg = 0u, cp = 0u;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {   // block-uniform trip count
+        int img = 0, local = item, n_i = 0, nti = 1;
+        for (; img < n_img; ++img) {
+            n_i = s_cnt[img];
+            nti = (n_i + RANK_IT - 1) / RANK_IT;
+            const int cnt = nti * ((n_i + RANK_JT - 1) / RANK_JT);
+            if (local < cnt) break;
+            local -= cnt;
+        }
+        const int64_t base = (int64_t)img * cap_img;
+        const int bj = local / nti, bi = local - bj * nti;
+        const int i0 = bi * RANK_IT, j0 = bj * RANK_JT;
+        const int jn = n_i - j0 < RANK_JT ? n_i - j0 : RANK_JT;
+        __syncthreads();   // the previous pair's scan is over: the slice may be replaced
+        for (int t = threadIdx.x; t < jn; t += RANK_IT) {
+            const uint64_t g = ((uint64_t)(uint32_t)in_hi[base + j0 + t] << 32) | in_lo[base + j0 + t];   // ~score << 32 | cand
+            keys[t][0] = g;
+            keys[t][1] = p_key_of(g, label_bits);
+        }
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        uint64_t gi = 0ull, pi = 0ull;   // threads past the end count nothing
+        if (i < n_i) {
+            gi = ((uint64_t)(uint32_t)in_hi[base + i] << 32) | in_lo[base + i];
+            pi = p_key_of(gi, label_bits);
+        }
+        uint32_t cg = 0u, cp = 0u;
 #pragma unroll 8
-    for (int t = 0; t < jn; ++t) {   // wave-uniform LDS address: one broadcast 16-byte read per key
-        const uint64_t kg = keys[t][0], kp = keys[t][1];
-        cg += kg < gi ? 1u : 0u;
-        cp += kp < pi ? 1u : 0u;
-    }
-    if (i < n_i) {
-        atomicAdd(&rank_g[base + i], cg);
-        atomicAdd(&rank_p[base + i], cp);
+        for (int t = 0; t < jn; ++t) {   // wave-uniform LDS address: one broadcast 16-byte read per key
+            const uint64_t kg = keys[t][0], kp = keys[t][1];
+            cg += kg < gi ? 1u : 0u;
+            cp += kp < pi ? 1u : 0u;
+        }
+        if (i < n_i) {
+            atomicAdd(&rank_g[base + i], cg);
+            atomicAdd(&rank_p[base + i], cp);
+        }
     }
 }
 
@@ -1379,7 +1404,8 @@ int post_finish_launch(const ymi_post_desc* d, hipStream_t s) {
             hipLaunchKernelGGL(sel_copyback_kernel, dim3(cdiv(RANK_MAX, 256), d->n), dim3(256), 0, s, w.hi[0], w.lo[0], w.hi[1], w.lo[1], sel_state, w.sel_count, cap_img);
         }
         const int rank_cap = cap_img < RANK_MAX ? cap_img : RANK_MAX;   // no image holds more than cap_img records
-        hipLaunchKernelGGL(rank_image_kernel, dim3(cdiv(rank_cap, RANK_IT), cdiv(rank_cap, RANK_JT), d->n), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.sel_count, cap_img,
+        YMI_REQUIRE(d->n <= RANK_NIMG, "ymi_postprocess: more than %d images in a batch", RANK_NIMG);
+        hipLaunchKernelGGL(rank_image_kernel, dim3(RANK_GRID), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.sel_count, d->n, cap_img,
                            L.label_bits, rank_g, rank_p);
         hipLaunchKernelGGL(scatter_ranks_kernel, dim3(cdiv(rank_cap, RANK_IT), d->n), dim3(RANK_IT), 0, s, w.hi[0], w.lo[0], w.img_count, w.sel_count, cap_img, L.label_bits,
                            rank_g, rank_p, w.hi[1], w.lo[1], w.p_hi, w.p_lo, w.keep, d->status);
