@@ -273,6 +273,34 @@ def test_c3_strip_kernel_equals_the_separate_launches(dev, case):
     assert err <= tol * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("arch,n,h,w,geom,blocks", [
+    ("yolov5_darknet_pan_s_r60", 3, 544, 960, "3,2,2", 40),      # non-square canvas: 68 x 120 / 34 x 60 maps, ragged rows and columns
+    ("yolov5_darknet_pan_l6_r60", 1, 768, 1024, "2,1,5", 64),    # four levels; hidden 64 @ 192 x 256, hidden 128 @ 96 x 128: column tiles either way
+    ("yolov5_darknet_pan_n_r60", 5, 352, 416, "1,1,1", 3),       # yolov5n: hidden 64 at 44 x 52, 128 at 22 x 26; one row per strip, three blocks
+])
+def test_strip_geometry_never_changes_a_detection_on_other_models_and_canvases(dev, arch, n, h, w, geom, blocks, monkeypatch):
+    from yolort_amd.models import YOLOv5
+    from workloads.synth import synth_images, synth_weights
+    imgs = [im.to(dev).half() for im in synth_images(n, h, w, seed=h + n)]
+    kw = dict(size_divisible=64) if arch.endswith("6_r60") else {}
+    outs, strips = [], []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("YOLORT_AMD_C3T_GEOM", geom)
+            monkeypatch.setenv("YOLORT_AMD_C3T_BLOCKS", str(blocks))
+        m = YOLOv5(arch=arch, size=(h, w), score_thresh=0.1, **kw)
+        m.load_state_dict(synth_weights(m.state_dict(), arch, seed=0, head_gain=0.8))
+        m = m.to(dev).half().eval()
+        outs.append(m(imgs))
+        e = next(iter(m.model._entries.values()))
+        strips.append(sum(".tile" in nm for nm in e.plan.names))
+    assert strips[0] == strips[1] and strips[0] >= 2, strips   # (a forced geometry the kernel cannot run would silently fall back to the separate launches: not here)
+    assert sum(len(d["scores"]) for d in outs[0]) > 5
+    for a, b in zip(*outs):
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k]), (arch, geom, k)
+
+
 @pytest.mark.parametrize("geom,blocks", [("4,1,2", 50), ("3,5,3", 7), ("2,9,1", 300)])
 def test_strip_geometry_never_changes_a_detection(dev, geom, blocks, monkeypatch):
     """a strip's arithmetic does not depend on how the map is cut: whole yolov5s, the library's geometry against a forced one ("rows per strip, slot origin, column tiles")
