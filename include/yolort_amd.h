@@ -248,7 +248,7 @@ typedef struct ymi_post_desc {
     int32_t lh[YMI_MAX_LEVELS], lw[YMI_MAX_LEVELS], lcstride[YMI_MAX_LEVELS];
     float stride[YMI_MAX_LEVELS];
     float anchors[YMI_MAX_LEVELS][6]; /* 3 anchors x (w,h) in pixels */
-    int32_t num_levels, n, num_classes;
+    int32_t num_levels, n, num_classes;   /* n: images of the batch, at most 1024 (the ranking kernel's per-block table; larger batches are refused, not truncated) */
     float score_thresh, nms_thresh;
     int32_t detections_per_img;
     /* per-image rescale (transform.py:358-367): box = (box - pad) / gain; gain<=0 disables */
